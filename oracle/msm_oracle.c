@@ -1,0 +1,368 @@
+/* CPU ORACLE (test infrastructure only) — NOT PRODUCT CODE.
+ *
+ * Plain-C restatement of the reference's CPU MSM path:
+ *   <G1Projective as VariableBaseMSM>::msm   /root/reference/src/g1.rs:602-619
+ *   <G2Projective as VariableBaseMSM>::msm   /root/reference/src/g2.rs:582-599
+ *   Scalar::into_bigint                      /root/reference/src/scalar.rs:450-463,503-505
+ * which delegate to blstrs ^0.6.1 (git branch feat/arkwork, unpinned) -> blst =0.3.10
+ * `blst_p{1,2}s_mult_pippenger` — third-party code ABSENT from /root/reference.  The algorithm restated is
+ * blst's published Pippenger (see curve_tmpl.h).  Semantics kept from the reference call sites:
+ * n = min(len) is the caller's job; result is a Jacobian point; scalars are 255-bit integers mod r.
+ *
+ * PINNING: field/encoding layer pinned by the reference's embedded constants (orc_selfcheck);
+ * MSM-level **parity unpinned** (the reference has no golden vectors / fixed seeds: src/tests.rs:50-67
+ * is a randomized property) — anchored instead on the definition sum_i s_i*P_i (orc_*_msm_naive) and the
+ * committed fixtures in tests/golden/ produced by oracle/bls12_381.py (independent big-int code).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * Build: make -C oracle   (gcc -O3 -march=native -shared -fPIC -pthread)
+ */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include "field.h"
+
+static inline fp fp_one(void) { return FP_ONE; }
+static inline fp2 fp2_one(void) { fp2 r; r.c0 = FP_ONE; memset(&r.c1, 0, sizeof r.c1); return r; }
+
+#define FE fp
+#define F(x) fp_##x
+#define G(x) g1_##x
+#include "curve_tmpl.h"
+#undef FE
+#undef F
+#undef G
+
+#define FE fp2
+#define F(x) fp2_##x
+#define G(x) g2_##x
+#include "curve_tmpl.h"
+#undef FE
+#undef F
+#undef G
+
+/* generators in Montgomery form (re-derived in orc_selfcheck from canonical values) */
+static const uint64_t G1X_C[6] = {0xfb3af00adb22c6bbULL, 0x6c55e83ff97a1aefULL, 0xa14e3a3f171bac58ULL, 0xc3688c4f9774b905ULL, 0x2695638c4fa9ac0fULL, 0x17f1d3a73197d794ULL};
+static const uint64_t G1Y_C[6] = {0x0caa232946c5e7e1ULL, 0xd03cc744a2888ae4ULL, 0x00db18cb2c04b3edULL, 0xfcf5e095d5d00af6ULL, 0xa09e30ed741d8ae4ULL, 0x08b3f481e3aaa0f1ULL};
+static const uint64_t G2X0_C[6] = {0xd48056c8c121bdb8ULL, 0x0bac0326a805bbefULL, 0xb4510b647ae3d177ULL, 0xc6e47ad4fa403b02ULL, 0x260805272dc51051ULL, 0x024aa2b2f08f0a91ULL};
+static const uint64_t G2X1_C[6] = {0xe5ac7d055d042b7eULL, 0x334cf11213945d57ULL, 0xb5da61bbdc7f5049ULL, 0x596bd0d09920b61aULL, 0x7dacd3a088274f65ULL, 0x13e02b6052719f60ULL};
+static const uint64_t G2Y0_C[6] = {0xe193548608b82801ULL, 0x923ac9cc3baca289ULL, 0x6d429a695160d12cULL, 0xadfd9baa8cbdd3a7ULL, 0x8cc9cdc6da2e351aULL, 0x0ce5d527727d6e11ULL};
+static const uint64_t G2Y1_C[6] = {0xaaa9075ff05f79beULL, 0x3f370d275cec1da1ULL, 0x267492ab572e99abULL, 0xcb3e287e85a763afULL, 0x32acd2b02bc28b99ULL, 0x0606c4a02ea734ccULL};
+
+static void fp_from_canon(fp *r, const uint64_t *c) { fp t; memcpy(t.l, c, 48); fp_to_mont(r, &t); }
+static void g1_generator(g1_affine *g) { fp_from_canon(&g->x, G1X_C); fp_from_canon(&g->y, G1Y_C); }
+static void g2_generator(g2_affine *g) {
+    fp_from_canon(&g->x.c0, G2X0_C); fp_from_canon(&g->x.c1, G2X1_C);
+    fp_from_canon(&g->y.c0, G2Y0_C); fp_from_canon(&g->y.c1, G2Y1_C);
+}
+
+/* ------------------------------------------------------------------ tiny thread pool: parallel_for */
+typedef void (*task_fn)(void *ctx, size_t idx);
+typedef struct { task_fn fn; void *ctx; size_t n; size_t next; pthread_mutex_t mu; } pf_state;
+static void *pf_worker(void *arg) {
+    pf_state *s = (pf_state *)arg;
+    for (;;) {
+        pthread_mutex_lock(&s->mu);
+        size_t i = s->next++;
+        pthread_mutex_unlock(&s->mu);
+        if (i >= s->n) break;
+        s->fn(s->ctx, i);
+    }
+    return NULL;
+}
+static void parallel_for(size_t n, int nthreads, task_fn fn, void *ctx) {
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > n) nthreads = (int)(n ? n : 1);
+    pf_state s; s.fn = fn; s.ctx = ctx; s.n = n; s.next = 0;
+    pthread_mutex_init(&s.mu, NULL);
+    if (nthreads == 1) { pf_worker(&s); pthread_mutex_destroy(&s.mu); return; }
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, pf_worker, &s);
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    free(th);
+    pthread_mutex_destroy(&s.mu);
+}
+
+/* ------------------------------------------------------------------ scalars */
+/* fmt 0: canonical LE integer (BigInteger256, what src/gpu.rs ships); fmt 1: blst_fr Montgomery (what g1.rs:613 ships) */
+static uint64_t *scalars_canonical(const uint8_t *scalars, size_t n, int fmt) {
+    uint64_t *out = (uint64_t *)malloc(n * 32 + 32);
+    for (size_t i = 0; i < n; i++) {
+        fr s; memcpy(s.l, scalars + 32 * i, 32);
+        if (fmt == 1) fr_from_mont(&s, &s);
+        memcpy(out + 4 * i, s.l, 32);
+    }
+    return out;
+}
+
+/* SplitMix64 in counter mode: word j of element i */
+static inline uint64_t sm64(uint64_t seed, uint64_t ctr) {
+    uint64_t z = seed + (ctr + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+/* uniform in [0, r): 255-bit rejection, up to 8 attempts (then one subtraction; prob ~1e-8) */
+static void gen_scalar(uint64_t seed, uint64_t i, uint64_t out[4]) {
+    for (unsigned t = 0; t < 8; t++) {
+        for (int j = 0; j < 4; j++) out[j] = sm64(seed, (i * 8 + t) * 4 + j);
+        out[3] &= 0x7fffffffffffffffULL;
+        if (!fr_geq_r(out)) return;
+    }
+    fr_sub_r(out);
+}
+/* discrete log of base i: 255 bits reduced mod r, never 0 */
+static void gen_dlog(uint64_t seed, uint64_t i, uint64_t out[4]) {
+    for (int j = 0; j < 4; j++) out[j] = sm64(seed, i * 4 + j);
+    out[3] &= 0x7fffffffffffffffULL;
+    if (fr_geq_r(out)) fr_sub_r(out);
+    if ((out[0] | out[1] | out[2] | out[3]) == 0) out[0] = 1;
+}
+
+void orc_gen_scalars(uint64_t seed, size_t n, int mont, uint8_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        fr s; gen_scalar(seed, i, s.l);
+        if (mont) fr_to_mont(&s, &s);
+        memcpy(out + 32 * i, s.l, 32);
+    }
+}
+void orc_gen_dlogs(uint64_t seed, size_t n, uint8_t *out) {
+    for (size_t i = 0; i < n; i++) { uint64_t k[4]; gen_dlog(seed, i, k); memcpy(out + 32 * i, k, 32); }
+}
+/* out = sum_i s_i * k_i mod r (canonical), scalars canonical */
+void orc_dot_mod_r(const uint8_t *scalars, uint64_t seed_bases, size_t n, uint8_t out[32]) {
+    fr acc; memset(&acc, 0, sizeof acc);
+    for (size_t i = 0; i < n; i++) {
+        fr s, k, t;
+        memcpy(s.l, scalars + 32 * i, 32);
+        gen_dlog(seed_bases, i, k.l);
+        fr_to_mont(&s, &s);          /* sR */
+        fr_mul(&t, &s, &k);          /* sR*k/R = s*k */
+        fr_add(&acc, &acc, &t);
+    }
+    memcpy(out, acc.l, 32);
+}
+
+/* ------------------------------------------------------------------ per-group drivers (macro-instantiated) */
+#define DEFINE_GROUP(G1, FEt, Fpre, AFF_BYTES, JAC_BYTES)                                                            \
+    typedef struct {                                                                                                 \
+        const G1##_affine *bases; const uint64_t *scalars; size_t n; unsigned w, nwin; size_t nslices, slice_len;    \
+        G1##_jac *partials;                                                                                          \
+    } G1##_msm_ctx;                                                                                                  \
+    static void G1##_msm_task(void *vctx, size_t idx) {                                                              \
+        G1##_msm_ctx *c = (G1##_msm_ctx *)vctx;                                                                      \
+        unsigned win = (unsigned)(idx / c->nslices);                                                                 \
+        size_t sl = idx % c->nslices;                                                                                \
+        size_t lo = sl * c->slice_len, hi = lo + c->slice_len;                                                       \
+        if (hi > c->n) hi = c->n;                                                                                    \
+        G1##_xyzz *buckets = (G1##_xyzz *)malloc(sizeof(G1##_xyzz) * (((size_t)1 << (c->w - 1)) + 1));              \
+        G1##_pippenger_tile(&c->partials[idx], c->bases, c->scalars, lo, hi, win, c->w, buckets);                    \
+        free(buckets);                                                                                               \
+    }                                                                                                                \
+    int orc_##G1##_msm(const uint8_t *bases, const uint8_t *scalars, size_t n, int scalar_fmt, int nthreads,         \
+                       uint8_t *out) {                                                                               \
+        G1##_jac acc; G1##_jac_set_inf(&acc);                                                                        \
+        if (n == 0) { memcpy(out, &acc, JAC_BYTES); return 0; }                                                      \
+        uint64_t *sc = scalars_canonical(scalars, n, scalar_fmt);                                                    \
+        G1##_msm_ctx c;                                                                                              \
+        c.bases = (const G1##_affine *)bases; c.scalars = sc; c.n = n;                                               \
+        c.w = G1##_pippenger_window(n); c.nwin = (256 + c.w - 1) / c.w;                                              \
+        size_t want = (size_t)(nthreads > 1 ? 2 * nthreads : 1);                                                     \
+        c.nslices = (want + c.nwin - 1) / c.nwin;                                                                    \
+        if (c.nslices < 1) c.nslices = 1;                                                                            \
+        if (c.nslices > n) c.nslices = n;                                                                            \
+        c.slice_len = (n + c.nslices - 1) / c.nslices;                                                               \
+        c.partials = (G1##_jac *)malloc(sizeof(G1##_jac) * c.nwin * c.nslices);                                      \
+        parallel_for((size_t)c.nwin * c.nslices, nthreads, G1##_msm_task, &c);                                       \
+        for (int win = (int)c.nwin - 1; win >= 0; win--) {                                                           \
+            for (unsigned k = 0; k < c.w; k++) G1##_jac_double(&acc, &acc);                                          \
+            for (size_t s = 0; s < c.nslices; s++) G1##_jac_add(&acc, &acc, &c.partials[win * c.nslices + s]);       \
+        }                                                                                                            \
+        free(c.partials); free(sc);                                                                                  \
+        memcpy(out, &acc, JAC_BYTES);                                                                                \
+        return 0;                                                                                                    \
+    }                                                                                                                \
+    int orc_##G1##_msm_naive(const uint8_t *bases, const uint8_t *scalars, size_t n, int scalar_fmt, uint8_t *out) { \
+        G1##_jac acc, t; G1##_jac_set_inf(&acc);                                                                     \
+        uint64_t *sc = scalars_canonical(scalars, n, scalar_fmt);                                                    \
+        for (size_t i = 0; i < n; i++) {                                                                             \
+            G1##_mul_naive(&t, (const G1##_affine *)bases + i, sc + 4 * i);                                          \
+            G1##_jac_add(&acc, &acc, &t);                                                                            \
+        }                                                                                                            \
+        free(sc);                                                                                                    \
+        memcpy(out, &acc, JAC_BYTES);                                                                                \
+        return 0;                                                                                                    \
+    }                                                                                                                \
+    void orc_##G1##_to_affine(const uint8_t *in, uint8_t *out) {                                                     \
+        G1##_jac p; memcpy(&p, in, JAC_BYTES);                                                                       \
+        G1##_affine a; G1##_jac_to_affine(&a, &p);                                                                   \
+        memcpy(out, &a, AFF_BYTES);                                                                                  \
+    }                                                                                                                \
+    void orc_##G1##_sum_jac(const uint8_t *pts, size_t n, uint8_t *out) {                                            \
+        G1##_jac acc, t; G1##_jac_set_inf(&acc);                                                                     \
+        for (size_t i = 0; i < n; i++) { memcpy(&t, pts + (size_t)JAC_BYTES * i, JAC_BYTES); G1##_jac_add(&acc, &acc, &t); } \
+        memcpy(out, &acc, JAC_BYTES);                                                                                \
+    }                                                                                                                \
+    /* Horner fold of window sums, low window first in memory: sum_k 2^(c*k) * W_k  (cf. src/gpu.rs:193-209) */      \
+    void orc_##G1##_fold_windows(const uint8_t *wins, unsigned nwin, unsigned c, uint8_t *out) {                     \
+        G1##_jac acc, t; G1##_jac_set_inf(&acc);                                                                     \
+        for (int k = (int)nwin - 1; k >= 0; k--) {                                                                   \
+            for (unsigned d = 0; d < c; d++) G1##_jac_double(&acc, &acc);                                            \
+            memcpy(&t, wins + (size_t)JAC_BYTES * k, JAC_BYTES);                                                     \
+            G1##_jac_add(&acc, &acc, &t);                                                                            \
+        }                                                                                                            \
+        memcpy(out, &acc, JAC_BYTES);                                                                                \
+    }                                                                                                                \
+    /* fixed-base table: T[w][d-1] = d * 2^(8w) * Gen, w < 32, d in 1..255 */                                        \
+    static G1##_affine *G1##_table = NULL;                                                                           \
+    static pthread_mutex_t G1##_table_mu = PTHREAD_MUTEX_INITIALIZER;                                                \
+    static void G1##_batch_to_affine(G1##_affine *out, const G1##_jac *in, size_t n) {                               \
+        FEt *pref = (FEt *)malloc(sizeof(FEt) * (n + 1));                                                            \
+        FEt acc = Fpre##_one();                                                                                      \
+        for (size_t i = 0; i < n; i++) {                                                                             \
+            pref[i] = acc;                                                                                           \
+            if (!G1##_jac_is_inf(&in[i])) Fpre##_mul(&acc, &acc, &in[i].z);                                          \
+        }                                                                                                            \
+        FEt inv; Fpre##_inv(&inv, &acc);                                                                             \
+        for (size_t i = n; i-- > 0;) {                                                                               \
+            if (G1##_jac_is_inf(&in[i])) { memset(&out[i], 0, sizeof out[i]); continue; }                            \
+            FEt zi, zi2, zi3;                                                                                        \
+            Fpre##_mul(&zi, &inv, &pref[i]);                                                                         \
+            Fpre##_mul(&inv, &inv, &in[i].z);                                                                        \
+            Fpre##_sqr(&zi2, &zi);                                                                                   \
+            Fpre##_mul(&zi3, &zi2, &zi);                                                                             \
+            Fpre##_mul(&out[i].x, &in[i].x, &zi2);                                                                   \
+            Fpre##_mul(&out[i].y, &in[i].y, &zi3);                                                                   \
+        }                                                                                                            \
+        free(pref);                                                                                                  \
+    }                                                                                                                \
+    static void G1##_build_table(void) {                                                                             \
+        pthread_mutex_lock(&G1##_table_mu);                                                                          \
+        if (!G1##_table) {                                                                                           \
+            G1##_jac *tj = (G1##_jac *)malloc(sizeof(G1##_jac) * 32 * 255);                                          \
+            G1##_affine g; G1##_generator(&g);                                                                       \
+            G1##_jac base; G1##_jac_from_affine(&base, &g);                                                          \
+            for (int w = 0; w < 32; w++) {                                                                           \
+                tj[w * 255] = base;                                                                                  \
+                for (int d = 1; d < 255; d++) G1##_jac_add(&tj[w * 255 + d], &tj[w * 255 + d - 1], &base);           \
+                for (int k = 0; k < 8; k++) G1##_jac_double(&base, &base);                                           \
+            }                                                                                                        \
+            G1##_affine *t = (G1##_affine *)malloc(sizeof(G1##_affine) * 32 * 255);                                  \
+            G1##_batch_to_affine(t, tj, 32 * 255);                                                                   \
+            free(tj);                                                                                                \
+            G1##_table = t;                                                                                          \
+        }                                                                                                            \
+        pthread_mutex_unlock(&G1##_table_mu);                                                                        \
+    }                                                                                                                \
+    static void G1##_fixed_mul(G1##_jac *r, const uint64_t k[4]) {                                                   \
+        G1##_xyzz acc; G1##_xyzz_set_inf(&acc);                                                                      \
+        for (int w = 0; w < 32; w++) {                                                                               \
+            unsigned d = (unsigned)((k[w >> 3] >> ((w & 7) * 8)) & 0xff);                                            \
+            if (d) G1##_xyzz_add_affine(&acc, &G1##_table[w * 255 + d - 1], 0);                                      \
+        }                                                                                                            \
+        G1##_xyzz_to_jac(r, &acc);                                                                                   \
+    }                                                                                                                \
+    /* out = k * Gen as affine, k canonical 32 B */                                                                  \
+    void orc_##G1##_mul_gen(const uint8_t k[32], uint8_t *out) {                                                     \
+        G1##_build_table();                                                                                          \
+        uint64_t kk[4]; memcpy(kk, k, 32);                                                                           \
+        G1##_jac j; G1##_fixed_mul(&j, kk);                                                                          \
+        G1##_affine a; G1##_jac_to_affine(&a, &j);                                                                   \
+        memcpy(out, &a, AFF_BYTES);                                                                                  \
+    }                                                                                                                \
+    typedef struct { uint64_t seed; size_t n; uint8_t *out; } G1##_gen_ctx;                                          \
+    static void G1##_gen_task(void *vctx, size_t chunk) {                                                            \
+        G1##_gen_ctx *c = (G1##_gen_ctx *)vctx;                                                                      \
+        size_t lo = chunk * 256, hi = lo + 256;                                                                      \
+        if (hi > c->n) hi = c->n;                                                                                    \
+        G1##_jac tmp[256];                                                                                           \
+        for (size_t i = lo; i < hi; i++) { uint64_t k[4]; gen_dlog(c->seed, i, k); G1##_fixed_mul(&tmp[i - lo], k); }\
+        G1##_batch_to_affine((G1##_affine *)c->out + lo, tmp, hi - lo);                                              \
+    }                                                                                                                \
+    /* bases P_i = k_i * Gen, k_i = gen_dlog(seed, i) */                                            \
+    void orc_##G1##_gen_bases(uint64_t seed, size_t n, int nthreads, uint8_t *out) {                                 \
+        G1##_build_table();                                                                                          \
+        G1##_gen_ctx c = {seed, n, out};                                                                             \
+        parallel_for((n + 255) / 256, nthreads, G1##_gen_task, &c);                                                  \
+    }                                                                                                                \
+    int orc_##G1##_on_curve(const uint8_t *aff) {                                                                    \
+        G1##_affine p; memcpy(&p, aff, AFF_BYTES);                                                                   \
+        if (G1##_aff_is_inf(&p)) return 1;                                                                           \
+        FEt l, r, b; Fpre##_sqr(&l, &p.y); Fpre##_sqr(&r, &p.x); Fpre##_mul(&r, &r, &p.x);                           \
+        G1##_curve_b(&b); Fpre##_add(&r, &r, &b);                                                                    \
+        return Fpre##_eq(&l, &r);                                                                                    \
+    }
+
+static void g1_curve_b(fp *b) { uint64_t c[6] = {4, 0, 0, 0, 0, 0}; fp_from_canon(b, c); }
+static void g2_curve_b(fp2 *b) { uint64_t c[6] = {4, 0, 0, 0, 0, 0}; fp_from_canon(&b->c0, c); b->c1 = b->c0; }
+
+DEFINE_GROUP(g1, fp, fp, 96, 144)
+DEFINE_GROUP(g2, fp2, fp2, 192, 288)
+
+/* ------------------------------------------------------------------ raw field entry points (HIP Fp parity tests) */
+void orc_fp_mul(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        fp x, y, z; memcpy(&x, a + 48 * i, 48); memcpy(&y, b + 48 * i, 48);
+        fp_mul(&z, &x, &y);
+        memcpy(out + 48 * i, &z, 48);
+    }
+}
+void orc_fp_add(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        fp x, y, z; memcpy(&x, a + 48 * i, 48); memcpy(&y, b + 48 * i, 48);
+        fp_add(&z, &x, &y);
+        memcpy(out + 48 * i, &z, 48);
+    }
+}
+void orc_fp_sub(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        fp x, y, z; memcpy(&x, a + 48 * i, 48); memcpy(&y, b + 48 * i, 48);
+        fp_sub(&z, &x, &y);
+        memcpy(out + 48 * i, &z, 48);
+    }
+}
+void orc_fp_to_mont(const uint8_t *a, uint8_t *out) { fp x, z; memcpy(&x, a, 48); fp_to_mont(&z, &x); memcpy(out, &z, 48); }
+void orc_fp_from_mont(const uint8_t *a, uint8_t *out) { fp x, z; memcpy(&x, a, 48); fp_from_mont(&z, &x); memcpy(out, &z, 48); }
+void orc_fr_from_mont(const uint8_t *a, uint8_t *out, size_t n) {
+    for (size_t i = 0; i < n; i++) { fr x; memcpy(&x, a + 32 * i, 32); fr_from_mont(&x, &x); memcpy(out + 32 * i, &x, 32); }
+}
+void orc_fr_to_mont(const uint8_t *a, uint8_t *out, size_t n) {
+    for (size_t i = 0; i < n; i++) { fr x; memcpy(&x, a + 32 * i, 32); fr_to_mont(&x, &x); memcpy(out + 32 * i, &x, 32); }
+}
+
+/* known-answer self check against the reference's embedded constants; returns 0 on success */
+int orc_selfcheck(void) {
+    /* src/fp.rs:714-721 : Montgomery limbs of (p-1)/2 */
+    static const uint64_t kat[6] = {0xa1fafffffffe5557ULL, 0x995bfff976a3fffeULL, 0x03f41d24d174ceb4ULL,
+                                    0xf6547998c1995dbdULL, 0x778a468f507a6034ULL, 0x020559931f7f8103ULL};
+    fp h; /* (p-1)/2 canonical */
+    uint64_t carry = 0;
+    for (int i = 5; i >= 0; i--) { uint64_t v = FP_P.l[i]; h.l[i] = (v >> 1) | (carry << 63); carry = v & 1; }
+    fp hm; fp_to_mont(&hm, &h);
+    if (memcmp(hm.l, kat, 48) != 0) return 1;
+    /* R mod p = mont(1) */
+    fp one; memset(&one, 0, sizeof one); one.l[0] = 1;
+    fp om; fp_to_mont(&om, &one);
+    if (!fp_eq(&om, &FP_ONE)) return 2;
+    /* src/g1.rs:46-51 : COFACTOR_INV Montgomery limbs * h1 == 1 (mod r) */
+    fr ci = {{288839107172787499ULL, 1152722415086798946ULL, 2612889808468387987ULL, 5124657601728438008ULL}};
+    fr h1 = {{0x8c00aaab0000aaabULL, 0x396c8c005555e156ULL, 0, 0}};
+    fr h1m, prod; fr_to_mont(&h1m, &h1); fr_mul(&prod, &ci, &h1m);
+    if (memcmp(&prod, &FR_ONE, 32) != 0) return 3;
+    /* generators on curve; inversion */
+    g1_affine g; g1_generator(&g);
+    if (!orc_g1_on_curve((const uint8_t *)&g)) return 4;
+    g2_affine g2; g2_generator(&g2);
+    if (!orc_g2_on_curve((const uint8_t *)&g2)) return 5;
+    fp inv, chk; fp_inv(&inv, &g.x); fp_mul(&chk, &inv, &g.x);
+    if (!fp_eq(&chk, &FP_ONE)) return 6;
+    /* r * G == infinity */
+    g1_jac t; g1_mul_naive(&t, &g, FR_R.l);
+    if (!g1_jac_is_inf(&t)) return 7;
+    g2_jac t2; g2_mul_naive(&t2, &g2, FR_R.l);
+    if (!g2_jac_is_inf(&t2)) return 8;
+    return 0;
+}
