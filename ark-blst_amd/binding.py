@@ -1,0 +1,161 @@
+"""ctypes binding of include/arkblst_amd.h.  Plumbing only — every computation happens in the HIP library."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SCALAR_CANONICAL, SCALAR_MONTGOMERY = 0, 1
+G1_AFF, G1_JAC, G2_AFF, G2_JAC = 96, 144, 192, 288
+
+
+class MsmError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str = ""):
+        self.code = code
+        super().__init__(f"{where}: error {code} ({detail})")
+
+
+class Profile(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("h2d_ms", "ingest_ms", "digits_ms", "scan_ms", "scatter_ms", "accumulate_ms",
+                                          "reduce_ms", "d2h_ms", "host_fold_ms", "total_ms")] + [
+        ("window_bits", C.c_uint32), ("num_windows", C.c_uint32), ("n", C.c_uint64), ("accumulate_adds", C.c_uint64)]
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "lib", "libarkblst_amd.so")
+
+
+_LIB = None
+
+
+def load_library():
+    """Load the HIP library; raises (never falls back) when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(path)
+        vp, sz, u, i = C.c_void_p, C.c_size_t, C.c_uint, C.c_int
+        L.mi_msm_init.argtypes = [C.POINTER(vp), C.POINTER(i), i]
+        L.mi_msm_destroy.argtypes = [vp]
+        L.mi_msm_destroy.restype = None
+        L.mi_msm_num_devices.argtypes = [vp]
+        for g in ("g1", "g2"):
+            getattr(L, f"mi_msm_{g}_set_bases").argtypes = [vp, vp, sz]
+            getattr(L, f"mi_msm_{g}").argtypes = [vp, vp, vp, sz, u, vp]
+            getattr(L, f"mi_msm_{g}_device").argtypes = [vp, vp, sz, u, vp]
+            getattr(L, f"mi_{g}_sum").argtypes = [vp, sz, vp]
+        L.mi_msm_set_window_bits.argtypes = [vp, u]
+        L.mi_msm_last_profile.argtypes = [vp, C.POINTER(Profile)]
+        L.mi_msm_last_error.argtypes = [vp]
+        L.mi_msm_last_error.restype = C.c_char_p
+        L.mi_msm_strerror.argtypes = [i]
+        L.mi_msm_strerror.restype = C.c_char_p
+        L.mi_test_fp_op.argtypes = [vp, i, vp, vp, vp, sz]
+        _LIB = L
+    return _LIB
+
+
+def _buf(b):
+    """bytes / bytearray / memoryview / numpy array -> (pointer, keepalive)."""
+    if b is None:
+        return None, None
+    if isinstance(b, int):
+        return C.c_void_p(b), None
+    if isinstance(b, bytes):
+        return C.cast(C.c_char_p(b), C.c_void_p), b
+    mv = memoryview(b)
+    arr = (C.c_char * mv.nbytes).from_buffer(mv) if not mv.readonly else (C.c_char * mv.nbytes).from_buffer_copy(mv)
+    return C.cast(arr, C.c_void_p), arr
+
+
+class Context:
+    """Owns one mi_ctx (streams, resident bases, scratch).  device_ids=None -> device 0 only."""
+
+    def __init__(self, device_ids=None):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        if device_ids is None:
+            device_ids = [0]
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        rc = self._L.mi_msm_init(C.byref(self._h), ids, len(device_ids))
+        if rc != 0:
+            raise MsmError(rc, "mi_msm_init", self._L.mi_msm_strerror(rc).decode())
+
+    def close(self):
+        if self._h:
+            self._L.mi_msm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, where):
+        if rc != 0:
+            raise MsmError(rc, where, (self._L.mi_msm_last_error(self._h) or b"").decode())
+
+    def num_devices(self) -> int:
+        return self._L.mi_msm_num_devices(self._h)
+
+    def set_window_bits(self, c: int):
+        self._check(self._L.mi_msm_set_window_bits(self._h, c), "mi_msm_set_window_bits")
+
+    def set_bases(self, group: str, bases, n: int):
+        p, keep = _buf(bases)
+        self._check(getattr(self._L, f"mi_msm_{group}_set_bases")(self._h, p, n), f"mi_msm_{group}_set_bases")
+
+    def msm(self, group: str, bases, scalars, n: int, scalar_fmt: int = SCALAR_CANONICAL) -> bytes:
+        """bases=None uses the resident set. Returns the Jacobian result bytes (blst_p1 / blst_p2)."""
+        out = C.create_string_buffer(G1_JAC if group == "g1" else G2_JAC)
+        pb, kb = _buf(bases)
+        ps, ks = _buf(scalars)
+        self._check(getattr(self._L, f"mi_msm_{group}")(self._h, pb, ps, n, scalar_fmt, out), f"mi_msm_{group}")
+        return out.raw
+
+    def msm_device(self, group: str, d_scalars_ptr: int, n: int, scalar_fmt: int = SCALAR_CANONICAL) -> bytes:
+        out = C.create_string_buffer(G1_JAC if group == "g1" else G2_JAC)
+        self._check(getattr(self._L, f"mi_msm_{group}_device")(self._h, C.c_void_p(d_scalars_ptr), n, scalar_fmt, out),
+                    f"mi_msm_{group}_device")
+        return out.raw
+
+    def profile(self) -> dict:
+        p = Profile()
+        self._check(self._L.mi_msm_last_profile(self._h, C.byref(p)), "mi_msm_last_profile")
+        return {f: getattr(p, f) for f, _ in Profile._fields_}
+
+    def test_fp_op(self, op: int, a: bytes, b: bytes) -> bytes:
+        n = len(a) // 48
+        out = C.create_string_buffer(48 * n)
+        self._check(self._L.mi_test_fp_op(self._h, op, a, b, out, n), "mi_test_fp_op")
+        return out.raw
+
+
+def _sum(group: str, partials) -> bytes:
+    L = load_library()
+    size = G1_JAC if group == "g1" else G2_JAC
+    blob = b"".join(partials)
+    assert len(blob) % size == 0
+    out = C.create_string_buffer(size)
+    rc = getattr(L, f"mi_{group}_sum")(blob, len(blob) // size, out)
+    if rc != 0:
+        raise MsmError(rc, f"mi_{group}_sum")
+    return out.raw
+
+
+def g1_sum(partials) -> bytes:
+    return _sum("g1", partials)
+
+
+def g2_sum(partials) -> bytes:
+    return _sum("g2", partials)

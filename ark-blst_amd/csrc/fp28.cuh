@@ -1,0 +1,231 @@
+// BLS12-381 base-field arithmetic for gfx950 (MI355X): radix 2^28, 14 limbs, Montgomery R' = 2^392.
+//
+// Why this shape (measured with tools/ubench_valu.hip on MI355X):
+//   v_mad_u64_u32 issues at HALF rate (~4.7 cyc/wave) — the same cost as ONE v_add_co/v_addc — so the
+//   cheapest 384-bit multiply is the one with the fewest carry instructions, not the fewest products.
+//   28-bit limbs leave 8 bits of headroom in a 64-bit column: 14 a*b products + 14 m*p products
+//   (each < 2^56) accumulate with plain v_mad_u64_u32 and NO carry handling; add/sub are 14 carry-less
+//   v_add_u32; modular reduction is lazy (R' = 2^392 leaves 2^11 of slack over p).
+//
+// Replaces: the ec-gpu-gen generated FIELD_mul/add/sub templates that /root/reference/build.rs:9-11
+// instantiates for blstrs::Fp (Montgomery, 12 x u32 limbs on CUDA), driven from /root/reference/src/gpu.rs.
+// Field constants: /root/reference/src/fp.rs:25-32 (modulus), src/gpu.rs:253-273 (one / r2 / modulus).
+//
+// Representation invariants
+//   N-form  : limbs l[0..12] <= 2^28 + 7, l[13] small; value = sum l[k] 2^(28k)   (not canonical)
+//   value   : every function documents the bound (multiples of p) it needs / produces.
+//   Montgomery multiplication accepts any a, b with a*b < 2^392 * p (i.e. a, b < ~50p) and returns < 2p.
+#pragma once
+#include <cstdint>
+#include "fp28_consts.h"
+
+#if defined(__HIPCC__)
+#define FP_HD __host__ __device__ __forceinline__
+#define FP_HD_NOINLINE __host__ __device__ __noinline__
+#else
+#define FP_HD inline
+#define FP_HD_NOINLINE inline
+#endif
+
+namespace fp28 {
+
+using namespace fp28c;
+
+struct Fp {
+    uint32_t l[NL];
+};
+
+FP_HD Fp fp_zero() {
+    Fp r;
+#pragma unroll
+    for (int k = 0; k < NL; k++) r.l[k] = 0;
+    return r;
+}
+FP_HD Fp fp_const(const uint32_t (&c)[NL]) {
+    Fp r;
+#pragma unroll
+    for (int k = 0; k < NL; k++) r.l[k] = c[k];
+    return r;
+}
+FP_HD Fp fp_one() { return fp_const(ONE); }
+
+// One parallel carry pass: any limbs < 2^32  ->  N-form (l[k] <= 2^28 - 1 + 15).
+FP_HD void fp_norm1(Fp& r) {
+    uint32_t cprev = 0;
+#pragma unroll
+    for (int k = 0; k < NL - 1; k++) {
+        uint32_t c = r.l[k] >> W;
+        r.l[k] = (r.l[k] & MASK) + cprev;
+        cprev = c;
+    }
+    r.l[NL - 1] += cprev;
+}
+
+// r = a + b   (value bound adds)
+FP_HD Fp fp_add(const Fp& a, const Fp& b) {
+    Fp r;
+#pragma unroll
+    for (int k = 0; k < NL; k++) r.l[k] = a.l[k] + b.l[k];
+    fp_norm1(r);
+    return r;
+}
+
+// r = a - b + K*p, K in {2,4,8,16,32,64}; requires b in N-form with value < (K-1)p. Result < a + K*p.
+template <int K>
+FP_HD Fp fp_sub(const Fp& a, const Fp& b) {
+    Fp r;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        uint32_t s = K == 2 ? S2[k] : K == 4 ? S4[k] : K == 8 ? S8[k] : K == 16 ? S16[k] : K == 32 ? S32[k] : S64[k];
+        r.l[k] = a.l[k] + s - b.l[k];
+    }
+    fp_norm1(r);
+    return r;
+}
+
+// r = K*p - b
+template <int K>
+FP_HD Fp fp_neg(const Fp& b) {
+    Fp z = fp_zero();
+    return fp_sub<K>(z, b);
+}
+
+// lane-wise select without branches
+FP_HD Fp fp_select(bool take_b, const Fp& a, const Fp& b) {
+    Fp r;
+#pragma unroll
+    for (int k = 0; k < NL; k++) r.l[k] = take_b ? b.l[k] : a.l[k];
+    return r;
+}
+
+// Montgomery reduction of 28 64-bit columns (each < 2^61) holding a product < 2^392 * p.  Returns N-form < 2p.
+FP_HD Fp fp_mont_reduce(uint64_t (&c)[2 * NL]) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        uint32_t m = ((uint32_t)c[i] * PINV) & MASK;
+#pragma unroll
+        for (int j = 0; j < NL; j++) c[i + j] += (uint64_t)m * P[j];
+        c[i + 1] += c[i] >> W;  // low 28 bits of c[i] are now zero
+    }
+    // columns c[14..27]: split each into 28-bit pieces and recombine without a carry chain
+    Fp r;
+    uint32_t mid_prev = 0, hi_prev = 0, hi_prev2 = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        uint64_t d = c[NL + k];
+        uint32_t lo = (uint32_t)d & MASK;
+        uint32_t mid = (uint32_t)(d >> W) & MASK;
+        uint32_t hi = (uint32_t)(d >> (2 * W));
+        r.l[k] = lo + mid_prev + hi_prev2;
+        mid_prev = mid;
+        hi_prev2 = hi_prev;
+        hi_prev = hi;
+    }
+    fp_norm1(r);
+    return r;
+}
+
+// r = a*b / 2^392 mod p.  a, b in N-form (limbs < 2^29.5 are still safe), a*b < 2^392 p.  Result N-form, < 2p.
+FP_HD Fp fp_mul(const Fp& a, const Fp& b) {
+    uint64_t c[2 * NL];
+#pragma unroll
+    for (int k = 0; k < 2 * NL; k++) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+#pragma unroll
+        for (int j = 0; j < NL; j++) c[i + j] += (uint64_t)a.l[i] * b.l[j];
+    }
+    return fp_mont_reduce(c);
+}
+
+// r = a^2 / 2^392 mod p (105 products instead of 196)
+FP_HD Fp fp_sqr(const Fp& a) {
+    uint64_t c[2 * NL];
+#pragma unroll
+    for (int k = 0; k < 2 * NL; k++) c[k] = 0;
+    uint32_t a2[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) a2[k] = a.l[k] << 1;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        c[2 * i] += (uint64_t)a.l[i] * a.l[i];
+#pragma unroll
+        for (int j = i + 1; j < NL; j++) c[i + j] += (uint64_t)a.l[i] * a2[j];
+    }
+    return fp_mont_reduce(c);
+}
+
+// Exact carry propagation of an N-form value that fits 392 bits: limbs -> [0, 2^28), l[13] holds the rest.
+FP_HD void fp_carry_exact(Fp& r) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < NL - 1; k++) {
+        uint32_t v = r.l[k] + carry;
+        r.l[k] = v & MASK;
+        carry = v >> W;
+    }
+    r.l[NL - 1] += carry;
+}
+
+// a == 0 (mod p) for an N-form value < 2p (any Montgomery product).
+FP_HD bool fp_is_zero_2p(const Fp& a) {
+    Fp t = a;
+    fp_carry_exact(t);
+    uint32_t z = 0, e = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        z |= t.l[k];
+        e |= t.l[k] ^ P[k];
+    }
+    return z == 0 || e == 0;
+}
+
+// a == 0 (mod p) for any N-form value < ~50p: one multiplication by the internal one brings it below 2p.
+FP_HD bool fp_is_zero_any(const Fp& a) { return fp_is_zero_2p(fp_mul(a, fp_one())); }
+
+// Canonical representative in [0, p) with exact 28-bit limbs, for an N-form value < 2p.
+FP_HD Fp fp_canon_2p(const Fp& a) {
+    Fp t = a;
+    fp_carry_exact(t);
+    Fp d;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        uint32_t v = t.l[k] - P[k] - borrow;
+        borrow = v >> 31;
+        d.l[k] = v & MASK;
+    }
+    return fp_select(borrow != 0, d, t);  // borrow => t < p, keep t
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conversions to / from the reference's in-memory form: blst_fp = 12 x u32 LE words of x*2^384 mod p
+// (the raw bytes /root/reference/src/gpu.rs:149 uploads and :185-186 downloads).
+// ------------------------------------------------------------------------------------------------
+FP_HD Fp fp_unpack384(const uint32_t (&w)[12]) {  // plain re-limbing, no domain change
+    Fp r;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        int bit = W * k, wi = bit >> 5, sh = bit & 31;
+        uint32_t lo = w[wi] >> sh;
+        if (sh > 4 && wi + 1 < 12) lo |= w[wi + 1] << (32 - sh);
+        r.l[k] = lo & MASK;
+    }
+    return r;
+}
+FP_HD void fp_pack384(uint32_t (&w)[12], const Fp& a) {  // a: exact limbs, value < 2^384
+#pragma unroll
+    for (int i = 0; i < 12; i++) w[i] = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        int bit = W * k, wi = bit >> 5, sh = bit & 31;
+        if (wi < 12) w[wi] |= a.l[k] << sh;
+        if (sh > 4 && wi + 1 < 12) w[wi + 1] |= a.l[k] >> (32 - sh);
+    }
+}
+// blst Montgomery words (x*2^384 mod p)  ->  internal (x*2^392 mod p), N-form < 2p
+FP_HD Fp fp_from_blst(const uint32_t (&w)[12]) { return fp_mul(fp_unpack384(w), fp_const(C_IN)); }
+// internal (any value < ~50p) -> blst Montgomery words, canonical
+FP_HD void fp_to_blst(uint32_t (&w)[12], const Fp& a) { fp_pack384(w, fp_canon_2p(fp_mul(a, fp_const(C_OUT)))); }
+
+}  // namespace fp28

@@ -1,0 +1,161 @@
+// Host-side (CPU) BLS12-381 arithmetic used by the shipped library for the O(windows) tail of an MSM:
+// combining the per-chunk bucket sums the GPU returns and the Horner fold over windows — the step the
+// reference also performs on the host (/root/reference/src/gpu.rs:193-209) — plus folding per-GPU partials.
+// Operates directly on the reference's in-memory form: blst_fp = 6 x u64 LE limbs, Montgomery R = 2^384
+// (/root/reference/src/fp.rs:25-32 modulus), Jacobian (X, Y, Z) with Z = 0 <=> infinity.
+//
+// Independent of oracle/ (which is test infrastructure): nothing here includes or links it.
+#pragma once
+#include <cstdint>
+#include <cstring>
+
+namespace hostec {
+
+typedef unsigned __int128 u128;
+
+struct Fp {
+    uint64_t l[6];
+    static constexpr uint64_t MOD[6] = {0xb9feffffffffaaabULL, 0x1eabfffeb153ffffULL, 0x6730d2a0f6b0f624ULL,
+                                        0x64774b84f38512bfULL, 0x4b1ba7b6434bacd7ULL, 0x1a0111ea397fe69aULL};
+    static constexpr uint64_t NINV = 0x89f3fffcfffcfffdULL;  // -p^-1 mod 2^64
+    static Fp zero() { Fp r; memset(r.l, 0, sizeof r.l); return r; }
+    static Fp one() {  // 2^384 mod p
+        Fp r = {{0x760900000002fffdULL, 0xebf4000bc40c0002ULL, 0x5f48985753c758baULL, 0x77ce585370525745ULL,
+                 0x5c071a97a256ec6dULL, 0x15f65ec3fa80e493ULL}};
+        return r;
+    }
+    bool is_zero() const { return (l[0] | l[1] | l[2] | l[3] | l[4] | l[5]) == 0; }
+    bool operator==(const Fp& o) const { return memcmp(l, o.l, sizeof l) == 0; }
+
+    static bool geq_mod(const uint64_t* t) {
+        for (int i = 5; i >= 0; i--) {
+            if (t[i] != MOD[i]) return t[i] > MOD[i];
+        }
+        return true;
+    }
+    static void sub_mod(uint64_t* t) {
+        uint64_t borrow = 0;
+        for (int i = 0; i < 6; i++) {
+            u128 d = (u128)t[i] - MOD[i] - borrow;
+            t[i] = (uint64_t)d;
+            borrow = (uint64_t)(d >> 64) & 1;
+        }
+    }
+    Fp operator+(const Fp& o) const {
+        Fp r;
+        u128 c = 0;
+        for (int i = 0; i < 6; i++) { c += (u128)l[i] + o.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+        if (geq_mod(r.l)) sub_mod(r.l);
+        return r;
+    }
+    Fp operator-(const Fp& o) const {
+        Fp r;
+        uint64_t borrow = 0;
+        for (int i = 0; i < 6; i++) {
+            u128 d = (u128)l[i] - o.l[i] - borrow;
+            r.l[i] = (uint64_t)d;
+            borrow = (uint64_t)(d >> 64) & 1;
+        }
+        if (borrow) {
+            u128 c = 0;
+            for (int i = 0; i < 6; i++) { c += (u128)r.l[i] + MOD[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+        }
+        return r;
+    }
+    // separated operand scanning: full 768-bit product, then six Montgomery reduction rounds
+    Fp operator*(const Fp& o) const {
+        uint64_t t[13];
+        memset(t, 0, sizeof t);
+        for (int i = 0; i < 6; i++) {
+            uint64_t carry = 0;
+            for (int j = 0; j < 6; j++) {
+                u128 v = (u128)l[j] * o.l[i] + t[i + j] + carry;
+                t[i + j] = (uint64_t)v;
+                carry = (uint64_t)(v >> 64);
+            }
+            t[i + 6] = carry;
+        }
+        for (int i = 0; i < 6; i++) {
+            uint64_t m = t[i] * NINV, carry = 0;
+            for (int j = 0; j < 6; j++) {
+                u128 v = (u128)m * MOD[j] + t[i + j] + carry;
+                t[i + j] = (uint64_t)v;
+                carry = (uint64_t)(v >> 64);
+            }
+            for (int k = i + 6; carry && k < 13; k++) {
+                u128 v = (u128)t[k] + carry;
+                t[k] = (uint64_t)v;
+                carry = (uint64_t)(v >> 64);
+            }
+        }
+        Fp r;
+        memcpy(r.l, t + 6, sizeof r.l);
+        if (t[12] || geq_mod(r.l)) sub_mod(r.l);
+        return r;
+    }
+    Fp sqr() const { return *this * *this; }
+    Fp dbl() const { return *this + *this; }
+};
+
+struct Fp2 {
+    Fp c0, c1;  // c0 + c1*u, u^2 = -1  (/root/reference/src/fp2.rs:228)
+    static Fp2 zero() { return {Fp::zero(), Fp::zero()}; }
+    static Fp2 one() { return {Fp::one(), Fp::zero()}; }
+    bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    bool operator==(const Fp2& o) const { return c0 == o.c0 && c1 == o.c1; }
+    Fp2 operator+(const Fp2& o) const { return {c0 + o.c0, c1 + o.c1}; }
+    Fp2 operator-(const Fp2& o) const { return {c0 - o.c0, c1 - o.c1}; }
+    Fp2 operator*(const Fp2& o) const {
+        Fp a = c0 * o.c0, b = c1 * o.c1;
+        Fp m = (c0 + c1) * (o.c0 + o.c1);
+        return {a - b, m - a - b};
+    }
+    Fp2 sqr() const {
+        Fp s = c0 + c1, d = c0 - c1, m = c0 * c1;
+        return {s * d, m + m};
+    }
+    Fp2 dbl() const { return *this + *this; }
+};
+
+template <class FE>
+struct Jac {
+    FE x, y, z;
+    static Jac inf() { return {FE::zero(), FE::zero(), FE::zero()}; }
+    bool is_inf() const { return z.is_zero(); }
+
+    Jac dbl() const {  // a = 0 short Weierstrass
+        if (is_inf() || y.is_zero()) return inf();
+        FE xx = x.sqr(), yy = y.sqr(), yyyy = yy.sqr();
+        FE s = ((x + yy).sqr() - xx - yyyy).dbl();
+        FE m = xx.dbl() + xx;
+        FE x3 = m.sqr() - s.dbl();
+        FE y3 = m * (s - x3) - yyyy.dbl().dbl().dbl();
+        FE z3 = (y * z).dbl();
+        return {x3, y3, z3};
+    }
+    Jac add(const Jac& q) const {
+        if (is_inf()) return q;
+        if (q.is_inf()) return *this;
+        FE z1z1 = z.sqr(), z2z2 = q.z.sqr();
+        FE u1 = x * z2z2, u2 = q.x * z1z1;
+        FE s1 = y * q.z * z2z2, s2 = q.y * z * z1z1;
+        if (u1 == u2) return s1 == s2 ? dbl() : inf();
+        FE h = u2 - u1, r = s2 - s1;
+        FE hh = h.sqr(), hhh = h * hh, v = u1 * hh;
+        FE x3 = r.sqr() - hhh - v.dbl();
+        FE y3 = r * (v - x3) - s1 * hhh;
+        FE z3 = z * q.z * h;
+        return {x3, y3, z3};
+    }
+    Jac dbl_n(unsigned k) const {
+        Jac r = *this;
+        for (unsigned i = 0; i < k; i++) r = r.dbl();
+        return r;
+    }
+};
+
+using G1 = Jac<Fp>;    // 144 B == blst_p1
+using G2 = Jac<Fp2>;   // 288 B == blst_p2
+static_assert(sizeof(G1) == 144 && sizeof(G2) == 288, "layout must match blst_p1 / blst_p2");
+
+}  // namespace hostec

@@ -1,0 +1,506 @@
+// C-ABI host driver of the MI355X MSM backend (see include/arkblst_amd.h for the contract and the
+// reference interfaces each entry point replaces: /root/reference/src/gpu.rs:101-241, src/g1.rs:602-632,
+// src/g2.rs:582-612).
+//
+// One mi_ctx owns, per device: a HIP stream, a resident base set in device form, and reusable scratch
+// (histogram / offsets / sorted indices / buckets / chunk sums) sized for the largest call seen so far —
+// the reference rebuilds its program and re-allocates every buffer on every call (src/gpu.rs:148-156,235).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/arkblst_amd.h"
+#include "host_curve.hpp"
+#include "msm_kernels.cuh"
+
+namespace {
+
+using hostec::G1;
+
+struct HipFail {
+    std::string msg;
+};
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) {                                                                           \
+            char _b[512];                                                                                 \
+            snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            throw HipFail{_b};                                                                            \
+        }                                                                                                 \
+    } while (0)
+
+struct Plan {
+    uint32_t c, nwin, nb, logL, chunks_per_win;
+    uint64_t nbuckets, nchunks;
+};
+
+// Window size: minimise (mixed adds in accumulate) + (full adds in reduce, ~1.4x the cost each), subject to
+// enough buckets to fill 256 CUs.  Plays the role of calc_window_size (/root/reference/src/gpu.rs:218-223).
+Plan make_plan(size_t n, unsigned forced_c) {
+    Plan best{};
+    double best_cost = 1e300;
+    for (unsigned c = 7; c <= 22; c++) {
+        if (forced_c && c != forced_c) continue;
+        uint32_t nwin = (256 + c - 1) / c;
+        double nb = (double)(1u << (c - 1));
+        double cost = (double)n * nwin + 6.0 * nb * nwin;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best.c = c;
+            best.nwin = nwin;
+        }
+    }
+    best.nb = 1u << (best.c - 1);
+    best.logL = std::min<uint32_t>(3, best.c - 7);
+    best.chunks_per_win = best.nb >> (6 + best.logL);
+    best.nbuckets = (uint64_t)best.nb * best.nwin;
+    best.nchunks = (uint64_t)best.chunks_per_win * best.nwin;
+    return best;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) HIP_TRY(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        HIP_TRY(hipMalloc(&p, bytes));
+        cap = bytes;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct DevState {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[10] = {};
+    // resident bases (device form) for G1
+    DevBuf g1_bases;
+    size_t g1_resident = 0;      // points resident on this device
+    size_t g1_shard_lo = 0;      // global index of the first resident point
+    // scratch
+    DevBuf raw, call_bases, scalars, hist, offsets, cursor, sorted, buckets, pairs;
+    void* h_pairs = nullptr;
+    size_t h_pairs_cap = 0;
+    mi_profile prof{};
+};
+
+}  // namespace
+
+struct mi_ctx {
+    std::vector<DevState> devs;
+    std::mutex mu;
+    unsigned forced_c = 0;
+    mi_profile prof{};
+    std::string err;
+};
+
+namespace {
+
+void ensure_host(DevState& d, size_t bytes) {
+    if (bytes <= d.h_pairs_cap) return;
+    if (d.h_pairs) HIP_TRY(hipHostFree(d.h_pairs));
+    d.h_pairs = nullptr;
+    HIP_TRY(hipHostMalloc(&d.h_pairs, bytes, hipHostMallocDefault));
+    d.h_pairs_cap = bytes;
+}
+
+double ev_ms(hipEvent_t a, hipEvent_t b) {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    return ms;
+}
+
+// bases raw (host or device) -> device form in `dst`
+void ingest_g1(DevState& d, const void* bases, bool bases_on_device, size_t n, DevBuf& dst) {
+    dst.ensure(n * msmk::G1_PT_WORDS * 4);
+    const void* src = bases;
+    if (!bases_on_device) {
+        d.raw.ensure(n * 96);
+        HIP_TRY(hipMemcpyAsync(d.raw.p, bases, n * 96, hipMemcpyHostToDevice, d.stream));
+        src = d.raw.p;
+    }
+    uint32_t grid = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(msmk::k_ingest_g1, dim3(grid), dim3(256), 0, d.stream, (const uint32_t*)src, (uint32_t*)dst.p, (uint32_t)n);
+    HIP_TRY(hipGetLastError());
+}
+
+// Host tail: combine chunk sums per window and Horner-fold the windows (cf. /root/reference/src/gpu.rs:193-209).
+G1 host_fold_g1(const G1* pairs, const Plan& pl) {
+    std::vector<G1> win(pl.nwin);
+    auto do_window = [&](uint32_t w) {
+        const G1* p = pairs + (size_t)w * pl.chunks_per_win * 2;
+        G1 run = G1::inf(), acc = G1::inf(), tsum = G1::inf();
+        for (int j = (int)pl.chunks_per_win - 1; j >= 0; j--) {
+            tsum = tsum.add(p[2 * j + 1]);
+            if (j >= 1) {
+                run = run.add(p[2 * j]);
+                acc = acc.add(run);
+            }
+        }
+        win[w] = acc.dbl_n(6 + pl.logL).add(tsum);
+    };
+    size_t work = (size_t)pl.nwin * pl.chunks_per_win;
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    unsigned nt = work >= 256 ? std::min<unsigned>(hw, pl.nwin) : 1;
+    if (nt <= 1) {
+        for (uint32_t w = 0; w < pl.nwin; w++) do_window(w);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t] {
+                for (uint32_t w = t; w < pl.nwin; w += nt) do_window(w);
+            });
+        for (auto& x : th) x.join();
+    }
+    G1 r = G1::inf();
+    for (int w = (int)pl.nwin - 1; w >= 0; w--) r = r.dbl_n(pl.c).add(win[w]);
+    return r;
+}
+
+// The pipeline on one device.  d_bases: device-form points for indices [0, n); d_scalars: n x 32 B on device.
+G1 run_g1(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, unsigned fmt, int ev0) {
+    Plan pl = make_plan(n, ctx->forced_c);
+    d.prof.window_bits = pl.c;
+    d.prof.num_windows = pl.nwin;
+    d.prof.n = n;
+    d.hist.ensure(pl.nbuckets * 4);
+    d.offsets.ensure((pl.nbuckets + 1) * 4);
+    d.cursor.ensure(pl.nbuckets * 4);
+    d.sorted.ensure((size_t)n * pl.nwin * 4);
+    d.buckets.ensure(pl.nbuckets * msmk::G1_BK_WORDS * 4);
+    d.pairs.ensure(pl.nchunks * 2 * 144);
+    ensure_host(d, pl.nchunks * 2 * 144 + 16);
+
+    hipStream_t s = d.stream;
+    uint32_t grid_n = (uint32_t)((n + 255) / 256);
+    HIP_TRY(hipEventRecord(d.ev[ev0], s));
+    HIP_TRY(hipMemsetAsync(d.hist.p, 0, pl.nbuckets * 4, s));
+    hipLaunchKernelGGL(msmk::k_digits_hist, dim3(grid_n), dim3(256), 0, s, d_scalars, d_bases, (uint32_t)msmk::G1_PT_WORDS,
+                       (uint32_t)n, fmt, pl.c, pl.nwin, (uint32_t*)d.hist.p);
+    HIP_TRY(hipEventRecord(d.ev[ev0 + 1], s));
+    hipLaunchKernelGGL(msmk::k_scan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets,
+                       (uint32_t*)d.offsets.p, (uint32_t*)d.cursor.p);
+    HIP_TRY(hipEventRecord(d.ev[ev0 + 2], s));
+    hipLaunchKernelGGL(msmk::k_scatter, dim3(grid_n), dim3(256), 0, s, d_scalars, d_bases, (uint32_t)msmk::G1_PT_WORDS, (uint32_t)n,
+                       fmt, pl.c, pl.nwin, (uint32_t*)d.cursor.p, (uint32_t*)d.sorted.p);
+    HIP_TRY(hipEventRecord(d.ev[ev0 + 3], s));
+    hipLaunchKernelGGL(msmk::k_accumulate_g1, dim3((uint32_t)((pl.nbuckets + 255) / 256)), dim3(256), 0, s, d_bases,
+                       (const uint32_t*)d.sorted.p, (const uint32_t*)d.offsets.p, (uint32_t*)d.buckets.p, (uint32_t)pl.nbuckets);
+    HIP_TRY(hipEventRecord(d.ev[ev0 + 4], s));
+    hipLaunchKernelGGL(msmk::k_reduce_g1, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.buckets.p,
+                       (uint32_t*)d.pairs.p, pl.logL);
+    HIP_TRY(hipEventRecord(d.ev[ev0 + 5], s));
+    HIP_TRY(hipMemcpyAsync(d.h_pairs, d.pairs.p, pl.nchunks * 2 * 144, hipMemcpyDeviceToHost, s));
+    // total number of scattered entries = mixed additions (+ first-touch copies)
+    HIP_TRY(hipMemcpyAsync((char*)d.h_pairs + pl.nchunks * 2 * 144, (char*)d.offsets.p + pl.nbuckets * 4, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(d.ev[ev0 + 6], s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+
+    d.prof.digits_ms = ev_ms(d.ev[ev0], d.ev[ev0 + 1]);
+    d.prof.scan_ms = ev_ms(d.ev[ev0 + 1], d.ev[ev0 + 2]);
+    d.prof.scatter_ms = ev_ms(d.ev[ev0 + 2], d.ev[ev0 + 3]);
+    d.prof.accumulate_ms = ev_ms(d.ev[ev0 + 3], d.ev[ev0 + 4]);
+    d.prof.reduce_ms = ev_ms(d.ev[ev0 + 4], d.ev[ev0 + 5]);
+    d.prof.d2h_ms = ev_ms(d.ev[ev0 + 5], d.ev[ev0 + 6]);
+    uint32_t entries;
+    memcpy(&entries, (char*)d.h_pairs + pl.nchunks * 2 * 144, 4);
+    d.prof.accumulate_adds = entries;
+
+    auto t0 = std::chrono::steady_clock::now();
+    G1 r = host_fold_g1(reinterpret_cast<const G1*>(d.h_pairs), pl);
+    d.prof.host_fold_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return r;
+}
+
+// One device's share of an MSM call. bases: host raw pointer for this shard or nullptr (= resident).
+G1 device_msm_g1(mi_ctx* ctx, DevState& d, const mi_g1_affine* bases, const uint8_t* scalars, bool scalars_on_device, size_t n,
+                 unsigned fmt) {
+    HIP_TRY(hipSetDevice(d.dev));
+    d.prof = mi_profile{};
+    auto t0 = std::chrono::steady_clock::now();
+    if (n == 0) return G1::inf();
+    hipStream_t s = d.stream;
+    HIP_TRY(hipEventRecord(d.ev[0], s));
+    const uint32_t* d_scalars;
+    if (scalars_on_device) {
+        d_scalars = reinterpret_cast<const uint32_t*>(scalars);
+    } else {
+        d.scalars.ensure(n * 32);
+        HIP_TRY(hipMemcpyAsync(d.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, s));
+        d_scalars = reinterpret_cast<const uint32_t*>(d.scalars.p);
+    }
+    const uint32_t* d_bases;
+    if (bases) {
+        d.raw.ensure(n * 96);
+        HIP_TRY(hipMemcpyAsync(d.raw.p, bases, n * 96, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(d.ev[1], s));
+        ingest_g1(d, d.raw.p, true, n, d.call_bases);
+        d_bases = reinterpret_cast<const uint32_t*>(d.call_bases.p);
+    } else {
+        HIP_TRY(hipEventRecord(d.ev[1], s));
+        d_bases = reinterpret_cast<const uint32_t*>(d.g1_bases.p);
+    }
+    G1 r = run_g1(ctx, d, d_bases, d_scalars, n, fmt, 2);
+    d.prof.h2d_ms = ev_ms(d.ev[0], d.ev[1]);
+    d.prof.ingest_ms = ev_ms(d.ev[1], d.ev[2]);
+    d.prof.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return r;
+}
+
+int fail(mi_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+template <class Fn>
+int guarded(mi_ctx* ctx, Fn fn) {
+    try {
+        return fn();
+    } catch (const HipFail& e) {
+        bool oom = e.msg.find("out of memory") != std::string::npos;
+        return fail(ctx, oom ? MI_E_NOMEM : MI_E_HIP, e.msg);
+    } catch (const std::bad_alloc&) {
+        return fail(ctx, MI_E_NOMEM, "host allocation failed");
+    } catch (...) {
+        return fail(ctx, MI_E_HIP, "unexpected exception");
+    }
+}
+
+// contiguous shard [lo, hi) of n items for device k of g
+void shard_range(size_t n, size_t g, size_t k, size_t& lo, size_t& hi) {
+    size_t per = (n + g - 1) / g;
+    lo = std::min(n, k * per);
+    hi = std::min(n, lo + per);
+}
+
+int msm_g1_impl(mi_ctx* ctx, const mi_g1_affine* bases, const uint8_t* scalars, bool scalars_on_device, size_t n, unsigned fmt,
+                mi_g1* out) {
+    if (!ctx || !out || (n && !scalars) || fmt > 1) return fail(ctx, MI_E_INVALID, "invalid argument");
+    if (n > 0x7fffffffull) return fail(ctx, MI_E_INVALID, "n exceeds 2^31-1 points per call");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return guarded(ctx, [&]() -> int {
+        size_t g = ctx->devs.size();
+        if (scalars_on_device && g != 1) return fail(ctx, MI_E_INVALID, "device-resident scalars need a single-device context");
+        std::vector<G1> part(g, G1::inf());
+        std::vector<std::string> errs(g);
+        // resident path: each device covers the overlap of [0, n) with its resident shard
+        if (!bases) {
+            size_t have = 0;
+            for (auto& d : ctx->devs) have += d.g1_resident;
+            if (have == 0 && n) return fail(ctx, MI_E_NO_BASES, "no resident G1 base set");
+            if (n > have) return fail(ctx, MI_E_INVALID, "n exceeds the resident G1 base set");
+        }
+        auto work = [&](size_t k) {
+            DevState& d = ctx->devs[k];
+            try {
+                size_t lo, hi;
+                if (bases) {
+                    shard_range(n, g, k, lo, hi);
+                } else {
+                    lo = std::min(n, d.g1_shard_lo);
+                    hi = std::min(n, d.g1_shard_lo + d.g1_resident);
+                }
+                const uint8_t* sc = scalars_on_device ? scalars : scalars + lo * 32;
+                part[k] = device_msm_g1(ctx, d, bases ? bases + lo : nullptr, sc, scalars_on_device, hi - lo, fmt);
+            } catch (const HipFail& e) {
+                errs[k] = e.msg;
+            }
+        };
+        auto t0 = std::chrono::steady_clock::now();
+        if (g == 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> th;
+            for (size_t k = 0; k < g; k++) th.emplace_back(work, k);
+            for (auto& t : th) t.join();
+        }
+        for (size_t k = 0; k < g; k++)
+            if (!errs[k].empty()) return fail(ctx, MI_E_HIP, errs[k]);
+        G1 r = G1::inf();
+        for (size_t k = 0; k < g; k++) r = r.add(part[k]);
+        memcpy(out, &r, sizeof r);
+        // report the slowest device's profile
+        size_t slow = 0;
+        for (size_t k = 1; k < g; k++)
+            if (ctx->devs[k].prof.total_ms > ctx->devs[slow].prof.total_ms) slow = k;
+        ctx->prof = ctx->devs[slow].prof;
+        ctx->prof.n = n;
+        ctx->prof.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return MI_OK;
+    });
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_msm_init(mi_ctx** out, const int* device_ids, int n_devices) {
+    if (!out || n_devices < 0) return MI_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MI_E_NO_DEVICE;
+    if (n_devices == 0) n_devices = device_ids ? 0 : count;
+    if (n_devices <= 0 || n_devices > count) return MI_E_NO_DEVICE;
+    mi_ctx* ctx = new (std::nothrow) mi_ctx();
+    if (!ctx) return MI_E_NOMEM;
+    int rc = guarded(ctx, [&]() -> int {
+        ctx->devs.resize(n_devices);
+        for (int k = 0; k < n_devices; k++) {
+            int id = device_ids ? device_ids[k] : k;
+            if (id < 0 || id >= count) return MI_E_NO_DEVICE;
+            DevState& d = ctx->devs[k];
+            d.dev = id;
+            HIP_TRY(hipSetDevice(id));
+            HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+            for (auto& e : d.ev) HIP_TRY(hipEventCreate(&e));
+        }
+        return MI_OK;
+    });
+    if (rc != MI_OK) {
+        mi_msm_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return MI_OK;
+}
+
+void mi_msm_destroy(mi_ctx* ctx) {
+    if (!ctx) return;
+    for (auto& d : ctx->devs) {
+        (void)hipSetDevice(d.dev);
+        if (d.stream) (void)hipStreamSynchronize(d.stream);
+        for (DevBuf* b : {&d.g1_bases, &d.raw, &d.call_bases, &d.scalars, &d.hist, &d.offsets, &d.cursor, &d.sorted, &d.buckets, &d.pairs})
+            b->release();
+        if (d.h_pairs) (void)hipHostFree(d.h_pairs);
+        for (auto& e : d.ev)
+            if (e) (void)hipEventDestroy(e);
+        if (d.stream) (void)hipStreamDestroy(d.stream);
+    }
+    delete ctx;
+}
+
+int mi_msm_num_devices(const mi_ctx* ctx) { return ctx ? (int)ctx->devs.size() : 0; }
+
+int mi_msm_g1_set_bases(mi_ctx* ctx, const mi_g1_affine* bases, size_t n) {
+    if (!ctx || (n && !bases)) return fail(ctx, MI_E_INVALID, "invalid argument");
+    if (n > 0x7fffffffull) return fail(ctx, MI_E_INVALID, "n exceeds 2^31-1 points");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return guarded(ctx, [&]() -> int {
+        size_t g = ctx->devs.size();
+        for (size_t k = 0; k < g; k++) {
+            DevState& d = ctx->devs[k];
+            size_t lo, hi;
+            shard_range(n, g, k, lo, hi);
+            HIP_TRY(hipSetDevice(d.dev));
+            d.g1_shard_lo = lo;
+            d.g1_resident = hi - lo;
+            if (hi > lo) {
+                ingest_g1(d, bases + lo, false, hi - lo, d.g1_bases);
+                HIP_TRY(hipStreamSynchronize(d.stream));
+            }
+        }
+        return MI_OK;
+    });
+}
+
+int mi_msm_g1(mi_ctx* ctx, const mi_g1_affine* bases, const uint8_t* scalars, size_t n, unsigned scalar_fmt, mi_g1* out) {
+    return msm_g1_impl(ctx, bases, scalars, false, n, scalar_fmt, out);
+}
+
+int mi_msm_g1_device(mi_ctx* ctx, const void* d_scalars, size_t n, unsigned scalar_fmt, mi_g1* out) {
+    return msm_g1_impl(ctx, nullptr, static_cast<const uint8_t*>(d_scalars), true, n, scalar_fmt, out);
+}
+
+int mi_msm_g2_set_bases(mi_ctx* ctx, const mi_g2_affine*, size_t) { return fail(ctx, MI_E_UNSUPPORTED, "G2 not built yet"); }
+int mi_msm_g2(mi_ctx* ctx, const mi_g2_affine*, const uint8_t*, size_t, unsigned, mi_g2*) { return fail(ctx, MI_E_UNSUPPORTED, "G2 not built yet"); }
+int mi_msm_g2_device(mi_ctx* ctx, const void*, size_t, unsigned, mi_g2*) { return fail(ctx, MI_E_UNSUPPORTED, "G2 not built yet"); }
+
+int mi_g1_sum(const mi_g1* partials, size_t n, mi_g1* out) {
+    if (!out || (n && !partials)) return MI_E_INVALID;
+    G1 r = G1::inf();
+    for (size_t i = 0; i < n; i++) {
+        G1 p;
+        memcpy(&p, &partials[i], sizeof p);
+        r = r.add(p);
+    }
+    memcpy(out, &r, sizeof r);
+    return MI_OK;
+}
+
+int mi_g2_sum(const mi_g2* partials, size_t n, mi_g2* out) {
+    if (!out || (n && !partials)) return MI_E_INVALID;
+    hostec::G2 r = hostec::G2::inf();
+    for (size_t i = 0; i < n; i++) {
+        hostec::G2 p;
+        memcpy(&p, &partials[i], sizeof p);
+        r = r.add(p);
+    }
+    memcpy(out, &r, sizeof r);
+    return MI_OK;
+}
+
+int mi_msm_set_window_bits(mi_ctx* ctx, unsigned window_bits) {
+    if (!ctx || (window_bits != 0 && (window_bits < 7 || window_bits > 22))) return fail(ctx, MI_E_INVALID, "window_bits must be 0 or 7..22");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->forced_c = window_bits;
+    return MI_OK;
+}
+
+int mi_msm_last_profile(const mi_ctx* ctx, mi_profile* out) {
+    if (!ctx || !out) return MI_E_INVALID;
+    *out = ctx->prof;
+    return MI_OK;
+}
+
+const char* mi_msm_last_error(const mi_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+const char* mi_msm_strerror(int code) {
+    switch (code) {
+        case MI_OK: return "ok";
+        case MI_E_INVALID: return "invalid argument";
+        case MI_E_NO_DEVICE: return "no usable HIP device";
+        case MI_E_HIP: return "HIP runtime error";
+        case MI_E_NOMEM: return "out of memory";
+        case MI_E_NO_BASES: return "no resident base set";
+        case MI_E_UNSUPPORTED: return "not supported in this build";
+        default: return "unknown error";
+    }
+}
+
+int mi_test_fp_op(mi_ctx* ctx, int op, const mi_fp* a, const mi_fp* b, mi_fp* out, size_t n) {
+    if (!ctx || !a || !b || !out || op < 0 || op > 3) return fail(ctx, MI_E_INVALID, "invalid argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return guarded(ctx, [&]() -> int {
+        DevState& d = ctx->devs[0];
+        HIP_TRY(hipSetDevice(d.dev));
+        DevBuf da, db, dout;
+        da.ensure(n * 48); db.ensure(n * 48); dout.ensure(n * 48);
+        HIP_TRY(hipMemcpyAsync(da.p, a, n * 48, hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(hipMemcpyAsync(db.p, b, n * 48, hipMemcpyHostToDevice, d.stream));
+        hipLaunchKernelGGL(msmk::k_test_fp_op, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, d.stream, op, (const uint32_t*)da.p,
+                           (const uint32_t*)db.p, (uint32_t*)dout.p, (uint32_t)n);
+        HIP_TRY(hipMemcpyAsync(out, dout.p, n * 48, hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        da.release(); db.release(); dout.release();
+        return MI_OK;
+    });
+}
+
+}  // extern "C"

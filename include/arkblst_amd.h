@@ -1,0 +1,122 @@
+/* arkblst_amd.h — C ABI of the MI355X-native BLS12-381 MSM backend.
+ *
+ * Drop-in boundary for ONE path of nikkolasg/ark-blst: everything below
+ *     <G1Projective as VariableBaseMSM>::msm      /root/reference/src/g1.rs:602-619 (CPU), 621-632 (GPU)
+ *     <G2Projective as VariableBaseMSM>::msm      /root/reference/src/g2.rs:582-599 (CPU), 601-612 (GPU)
+ * i.e. it replaces crate::gpu::msm + SingleMultiexpKernel (/root/reference/src/gpu.rs:101-241) and the
+ * ec-gpu-gen generated kernels (/root/reference/build.rs:5-13).  The Rust binding a maintainer adds is in
+ * INTEGRATION.md.  Plain pointers and sizes only; no exceptions or aborts cross this boundary.
+ *
+ * Data layouts are the reference's own in-memory types, passed zero-copy exactly as src/gpu.rs:149-150
+ * uploads them and :185-186 reads them back (all #[repr(transparent)] newtypes, src/g1.rs:55-56,436-437):
+ *     mi_fp         blst_fp        6 x u64 LE limbs, Montgomery R = 2^384, fully reduced (< p)
+ *     mi_g1_affine  blst_p1_affine 96 B  (x, y); all-zero = point at infinity
+ *     mi_g1         blst_p1        144 B Jacobian (X, Y, Z); Z == 0 = infinity
+ *     mi_g2_affine  blst_p2_affine 192 B, coordinates in Fp2 = (c0, c1)        (src/fp2.rs:228)
+ *     mi_g2         blst_p2        288 B
+ *     scalars       n x 32 B little-endian: MI_SCALAR_CANONICAL = BigInteger256 integer < r (what
+ *                   src/g1.rs:624-627 builds via Scalar::into_bigint), or MI_SCALAR_MONTGOMERY = blst_fr
+ *                   (4 x u64, R = 2^256: the raw `Scalar` slice, src/scalar.rs:23-25) which is converted on
+ *                   the GPU, removing the per-element heap round trip of src/scalar.rs:450-463,503-505.
+ *
+ * Error model: 0 = success, negative = MI_E_* (mi_msm_strerror).  The reference maps every GPU failure to
+ * Err(0) (src/g1.rs:628-630) and panics on length mismatch (src/gpu.rs:131); here the caller passes one n.
+ * Thread safety: a context serialises concurrent calls internally (rayon callers are safe); result is
+ * deterministic (as a curve point) for identical inputs and independent of the number of devices.
+ */
+#ifndef ARKBLST_AMD_H
+#define ARKBLST_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint64_t l[6]; } mi_fp;
+typedef struct { mi_fp x, y; } mi_g1_affine;
+typedef struct { mi_fp x, y, z; } mi_g1;
+typedef struct { mi_fp c[2]; } mi_fp2;
+typedef struct { mi_fp2 x, y; } mi_g2_affine;
+typedef struct { mi_fp2 x, y, z; } mi_g2;
+
+typedef struct mi_ctx mi_ctx;
+
+enum { MI_SCALAR_CANONICAL = 0, MI_SCALAR_MONTGOMERY = 1 };
+
+enum {
+    MI_OK = 0,
+    MI_E_INVALID = -1,      /* bad argument (NULL pointer, unknown scalar_fmt, n too large for resident set) */
+    MI_E_NO_DEVICE = -2,    /* no usable HIP device / bad device id */
+    MI_E_HIP = -3,          /* a HIP runtime call failed; mi_msm_last_error() has the text */
+    MI_E_NOMEM = -4,        /* device or host allocation failed */
+    MI_E_NO_BASES = -5,     /* bases == NULL but no resident base set was uploaded */
+    MI_E_UNSUPPORTED = -6   /* entry point not available in this build */
+};
+
+/* Per-call timing of the last MSM on this context, milliseconds, measured with HIP events on the
+ * library's own stream (bench.py reads these for the roofline line). */
+typedef struct {
+    double h2d_ms;          /* host->device copies (0 for the device-resident entry points) */
+    double ingest_ms;       /* base conversion to the device field representation (0 when resident) */
+    double digits_ms;       /* signed-window digit extraction + histogram */
+    double scan_ms;         /* bucket offsets (prefix sum) */
+    double scatter_ms;      /* bucket scatter (sort by bucket) */
+    double accumulate_ms;   /* bucket accumulation: the dominant kernel */
+    double reduce_ms;       /* per-chunk weighted bucket reduction */
+    double d2h_ms;          /* partial sums device->host */
+    double host_fold_ms;    /* CPU tail: chunk combine + Horner fold over windows */
+    double total_ms;        /* wall time of the call */
+    uint32_t window_bits;   /* c */
+    uint32_t num_windows;   /* ceil(256 / c) */
+    uint64_t n;             /* points in the call */
+    uint64_t accumulate_adds; /* mixed additions executed by the accumulate kernel */
+} mi_profile;
+
+/* Replaces Device::all()[0] + ec_gpu_gen::program! + SingleMultiexpKernel::create (src/gpu.rs:233-237,101-119),
+ * which the reference repeats on EVERY call.  device_ids == NULL selects devices 0..n_devices-1;
+ * n_devices == 0 selects all visible devices.  With several devices the base set is split into contiguous
+ * shards, one per device, and the partial sums are folded in device order. */
+int mi_msm_init(mi_ctx **out, const int *device_ids, int n_devices);
+void mi_msm_destroy(mi_ctx *ctx);
+int mi_msm_num_devices(const mi_ctx *ctx);
+
+/* Optional: keep a base set resident in HBM across calls (an SRS).  The reference re-uploads the bases on
+ * every call (src/gpu.rs:149).  Copies; no pointer is retained. */
+int mi_msm_g1_set_bases(mi_ctx *ctx, const mi_g1_affine *bases, size_t n);
+int mi_msm_g2_set_bases(mi_ctx *ctx, const mi_g2_affine *bases, size_t n);
+
+/* out = sum_i scalars[i] * bases[i], i < n.   Replaces gpu::msm::<G1Affine> (src/gpu.rs:226-241) and the CPU
+ * multi_exp (src/g1.rs:614-617).  bases == NULL uses the first n resident bases.  Infinity bases contribute
+ * nothing (the reference's blst path fails on them, src/g1.rs:682-688).  n == 0 returns infinity.  Blocking. */
+int mi_msm_g1(mi_ctx *ctx, const mi_g1_affine *bases, const uint8_t *scalars, size_t n, unsigned scalar_fmt,
+              mi_g1 *out);
+int mi_msm_g2(mi_ctx *ctx, const mi_g2_affine *bases, const uint8_t *scalars, size_t n, unsigned scalar_fmt,
+              mi_g2 *out);
+
+/* Same computation with the scalars ALREADY in device memory of the context's first device (hipMalloc'd or
+ * a torch CUDA tensor's data_ptr) and the bases resident: nothing crosses PCIe except the few-KB partial sums.
+ * Single-device contexts only. */
+int mi_msm_g1_device(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g1 *out);
+int mi_msm_g2_device(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g2 *out);
+
+/* Deterministic fold of partial sums (one per GPU / rank), in index order: the "all-reduce under the curve
+ * group law" that follows the RCCL all-gather in the multi-process harness.  Host only. */
+int mi_g1_sum(const mi_g1 *partials, size_t n, mi_g1 *out);
+int mi_g2_sum(const mi_g2 *partials, size_t n, mi_g2 *out);
+
+/* Tuning / introspection. window_bits = 0 restores the built-in heuristic (cf. calc_window_size, src/gpu.rs:218-223). */
+int mi_msm_set_window_bits(mi_ctx *ctx, unsigned window_bits);
+int mi_msm_last_profile(const mi_ctx *ctx, mi_profile *out);
+const char *mi_msm_last_error(const mi_ctx *ctx);
+const char *mi_msm_strerror(int code);
+
+/* Field-level test hooks (batch Montgomery multiply / add / sub on the device representation, I/O in blst_fp
+ * form) — used by the parity tests to pin the device arithmetic against the oracle. op: 0 mul, 1 sqr(a), 2 add, 3 sub */
+int mi_test_fp_op(mi_ctx *ctx, int op, const mi_fp *a, const mi_fp *b, mi_fp *out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARKBLST_AMD_H */

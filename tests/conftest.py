@@ -1,0 +1,43 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    import __graft_entry__ as g
+
+    return g.load_package()
+
+
+@pytest.fixture(scope="session")
+def co():
+    """C oracle (test infrastructure)."""
+    from oracle import coracle
+
+    coracle.lib()
+    return coracle
+
+
+@pytest.fixture(scope="session")
+def o():
+    """Python big-int oracle (test infrastructure)."""
+    from oracle import bls12_381
+
+    return bls12_381
+
+
+@pytest.fixture(scope="session")
+def ctx(pkg):
+    c = pkg.Context([0])
+    yield c
+    c.close()
