@@ -18,7 +18,8 @@ class MsmError(RuntimeError):
 class Profile(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("h2d_ms", "ingest_ms", "digits_ms", "scan_ms", "scatter_ms", "accumulate_ms",
                                           "reduce_ms", "d2h_ms", "host_fold_ms", "total_ms")] + [
-        ("window_bits", C.c_uint32), ("num_windows", C.c_uint32), ("n", C.c_uint64), ("accumulate_adds", C.c_uint64)]
+        ("window_bits", C.c_uint32), ("num_windows", C.c_uint32), ("n", C.c_uint64), ("accumulate_adds", C.c_uint64),
+        ("work_items", C.c_uint32), ("max_items_per_bucket", C.c_uint32)]
 
 
 def lib_path() -> str:

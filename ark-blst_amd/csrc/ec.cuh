@@ -1,15 +1,26 @@
-// Short-Weierstrass (a = 0) group law in extended Jacobian "XYZZ" coordinates over a lazily reduced field.
-//   x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; infinity <=> ZZ has all-zero limbs (exact zero, never produced by a
-//   regular operation).  Formulas: EFD madd-2008-s / add-2008-s / dbl-2008-s-1 / mdbl-2008-s-1.
+// Short-Weierstrass (a = 0) group law over a lazily reduced field.  Every formula is straight-line code around
+// ONE shared, out-of-line field multiplication (F::mul is a real device function call, see fp28::fp_mul_call).
+//
+// Why: with the multiplier inlined, a mixed addition is ~80 KB of straight-line code.  MI355X shares a 64 KB
+// instruction cache between two CUs and the waves of a bucket kernel are NOT in lockstep, so that body thrashes
+// it: measured 962 ms for 10 M additions in the first version of this file (~1900 cycles per instruction), while
+// a lockstep micro-benchmark of the same size runs at full rate (tools/ubench_icache.hip).  With one ~4.5 KB
+// multiplier body per kernel the hot loop stays cache resident; the call costs ~42 register moves (~4 %).
+//
+// Two coordinate systems:
+//   * XYZZ (x = X/ZZ, y = Y/ZZZ) for the bucket ACCUMULATION hot loop: mixed addition madd-2008-s, 10 M.
+//     Its exceptional inputs (same x: doubling / cancellation) are only DETECTED there; the lane then leaves
+//     the hot loop and finishes its bucket on the complete path below.
+//   * homogeneous projective (X : Y : Z) with the COMPLETE addition of Renes-Costello-Batina 2016, Alg. 7
+//     (a = 0, b3 = 3b), 12 M, no exceptional cases at all (doubling, inverses, infinity (0:1:0)) — used for
+//     bucket reduction, the wave scan, doublings and the cold path.
 //
 // This is the bucket arithmetic of the MSM that replaces the generated POINT_multiexp kernels
-// (/root/reference/build.rs:9-11, driven by /root/reference/src/gpu.rs:165-183); unlike those it is complete:
-// P + P, P + (-P) and infinity operands are all handled (cf. the reference's known-bad case
-// /root/reference/src/g1.rs:682-688).
+// (/root/reference/build.rs:9-11, driven by /root/reference/src/gpu.rs:165-183); unlike those it handles
+// infinity among the bases (the reference's known-bad case, /root/reference/src/g1.rs:682-688).
 //
-// Value-bound invariants of a stored point (multiples of p, all coordinates N-form):
-//   X < 10p, Y < 6p, ZZ < 2p, ZZZ < 2p.     (affine inputs: x < 4p, y < 4p)
-// The template parameter F supplies the field: F::E element type and mul/sqr/add/sub<K>/is_zero_2p/...
+// Value bounds (multiples of p; all values N-form) are proved by tools/bounds_check.py:
+//   XYZZ accumulator: X < 10p, Y < 6p, ZZ, ZZZ < 2p; affine inputs x, y < 4p; projective coordinates < 8p.
 #pragma once
 #include "fp28.cuh"
 
@@ -17,17 +28,18 @@ namespace ec {
 
 struct FpOps {
     using E = fp28::Fp;
+    static constexpr int B3 = 12;  // 3b for y^2 = x^3 + 4
     static FP_HD E zero() { return fp28::fp_zero(); }
     static FP_HD E one() { return fp28::fp_one(); }
-    static FP_HD E mul(const E& a, const E& b) { return fp28::fp_mul(a, b); }
-    static FP_HD E sqr(const E& a) { return fp28::fp_sqr(a); }
+    static FP_HD E mul(const E& a, const E& b) { return fp28::fp_mul_call(a, b); }
     static FP_HD E add(const E& a, const E& b) { return fp28::fp_add(a, b); }
     template <int K>
     static FP_HD E sub(const E& a, const E& b) { return fp28::fp_sub<K>(a, b); }
     template <int K>
     static FP_HD E neg(const E& a) { return fp28::fp_neg<K>(a); }
+    static FP_HD E mul3(const E& a) { return fp28::fp_mul_small<3>(a); }
+    static FP_HD E mul_b3(const E& a) { return fp28::fp_mul_small<12>(a); }
     static FP_HD bool is_zero_2p(const E& a) { return fp28::fp_is_zero_2p(a); }
-    static FP_HD bool is_zero_any(const E& a) { return fp28::fp_is_zero_any(a); }
     static FP_HD E select(bool take_b, const E& a, const E& b) { return fp28::fp_select(take_b, a, b); }
     static FP_HD bool limbs_all_zero(const E& a) {
         uint32_t z = 0;
@@ -42,145 +54,97 @@ struct Xyzz {
     typename F::E x, y, zz, zzz;
 };
 template <class F>
-struct Affine {
-    typename F::E x, y;
+struct Proj {
+    typename F::E x, y, z;
 };
 
 template <class F>
-FP_HD Xyzz<F> xyzz_inf() {
-    Xyzz<F> r;
-    r.x = F::zero(); r.y = F::zero(); r.zz = F::zero(); r.zzz = F::zero();
+FP_HD Proj<F> proj_inf() {
+    Proj<F> r;
+    r.x = F::zero(); r.y = F::one(); r.z = F::zero();
     return r;
 }
 template <class F>
-FP_HD bool xyzz_is_inf(const Xyzz<F>& p) { return F::limbs_all_zero(p.zz); }
-
-template <class F>
-FP_HD Xyzz<F> xyzz_from_affine(const typename F::E& x, const typename F::E& y) {
-    Xyzz<F> r;
-    r.x = x; r.y = y; r.zz = F::one(); r.zzz = F::one();
+FP_HD Proj<F> proj_from_affine(const typename F::E& x, const typename F::E& y) {
+    Proj<F> r;
+    r.x = x; r.y = y; r.z = F::one();
     return r;
 }
 template <class F>
-FP_HD Xyzz<F> xyzz_select(bool take_b, const Xyzz<F>& a, const Xyzz<F>& b) {
-    Xyzz<F> r;
+FP_HD Proj<F> proj_select(bool take_b, const Proj<F>& a, const Proj<F>& b) {
+    Proj<F> r;
     r.x = F::select(take_b, a.x, b.x);
     r.y = F::select(take_b, a.y, b.y);
-    r.zz = F::select(take_b, a.zz, b.zz);
-    r.zzz = F::select(take_b, a.zzz, b.zzz);
+    r.z = F::select(take_b, a.z, b.z);
     return r;
 }
 
-// Regular-case mixed addition acc + (x2, y2), acc not infinity.  Sets p_is_zero when the x-coordinates agree
-// (P == 0 mod p): the result is then meaningless and the caller must take xyzz_madd_special().
+// a <- a + b, complete (RCB16 Alg. 7): 12 multiplications, no exceptional cases.
 template <class F>
-FP_HD Xyzz<F> xyzz_madd_core(const Xyzz<F>& a, const typename F::E& x2, const typename F::E& y2, bool& p_is_zero) {
+FP_HD void proj_add(Proj<F>& a, const Proj<F>& b) {
     using E = typename F::E;
-    E U2 = F::mul(x2, a.zz);                  // < 2p
-    E S2 = F::mul(y2, a.zzz);                 // < 2p
-    E Pp = F::template sub<16>(U2, a.x);      // X < 10p  -> < 18p
-    E Rr = F::template sub<8>(S2, a.y);       // Y < 6p   -> < 10p
-    E PP = F::sqr(Pp);
-    p_is_zero = F::is_zero_2p(PP);
-    E PPP = F::mul(Pp, PP);
-    E Q = F::mul(a.x, PP);
-    E t = F::add(F::add(PPP, Q), Q);          // < 6p
-    Xyzz<F> r;
-    r.x = F::template sub<8>(F::sqr(Rr), t);  // < 10p
-    E v = F::template sub<16>(Q, r.x);        // < 18p
-    r.y = F::template sub<4>(F::mul(Rr, v), F::mul(a.y, PPP));  // < 6p
-    r.zz = F::mul(a.zz, PP);
-    r.zzz = F::mul(a.zzz, PPP);
-    return r;
+    E t0 = F::mul(a.x, b.x);
+    E t1 = F::mul(a.y, b.y);
+    E t2 = F::mul(a.z, b.z);
+    E t3 = F::mul(F::add(a.x, a.y), F::add(b.x, b.y));
+    E t4 = F::mul(F::add(a.y, a.z), F::add(b.y, b.z));
+    E t5 = F::mul(F::add(a.x, a.z), F::add(b.x, b.z));
+    t3 = F::template sub<8>(t3, F::add(t0, t1));   // X1Y2 + X2Y1
+    t4 = F::template sub<8>(t4, F::add(t1, t2));   // Y1Z2 + Y2Z1
+    t5 = F::template sub<8>(t5, F::add(t0, t2));   // X1Z2 + X2Z1
+    t0 = F::mul3(t0);                              // 3 X1X2
+    t2 = F::mul_b3(t2);                            // b3 Z1Z2
+    E u = F::add(t1, t2);                          // Y1Y2 + b3 Z1Z2
+    t1 = F::template sub<32>(t1, t2);              // Y1Y2 - b3 Z1Z2
+    t5 = F::mul_b3(t5);                            // b3 (X1Z2 + X2Z1)
+    a.x = F::template sub<4>(F::mul(t3, t1), F::mul(t4, t5));
+    a.y = F::add(F::mul(t1, u), F::mul(t5, t0));
+    a.z = F::add(F::mul(u, t4), F::mul(t0, t3));
 }
 
-// Doubling of an affine point (mdbl-2008-s-1).  x, y < 4p.  y == 0 cannot happen on a prime-order subgroup;
-// it degrades to ZZ == 0 (mod p), which downstream code treats as a (non-canonical) infinity only via
-// xyzz_fix_inf(); callers that may see 2-torsion call that.
+// r = 2^k * a
 template <class F>
-FP_HD Xyzz<F> xyzz_mdbl(const typename F::E& x, const typename F::E& y) {
-    using E = typename F::E;
-    E U = F::add(y, y);                        // < 8p
-    E V = F::sqr(U);
-    E Wq = F::mul(U, V);
-    E S = F::mul(x, V);
-    E xx = F::sqr(x);
-    E M = F::add(F::add(xx, xx), xx);          // < 6p
-    Xyzz<F> r;
-    r.x = F::template sub<8>(F::sqr(M), F::add(S, S));   // < 10p
-    E v = F::template sub<16>(S, r.x);                     // < 18p
-    r.y = F::template sub<4>(F::mul(M, v), F::mul(Wq, y));  // < 6p
-    r.zz = V;
-    r.zzz = Wq;
-    return r;
-}
-
-// Slow path of the mixed addition, taken when P == 0: either the same point (double) or opposite points (inf).
-template <class F>
-FP_HD Xyzz<F> xyzz_madd_special(const Xyzz<F>& a, const typename F::E& x2, const typename F::E& y2) {
-    using E = typename F::E;
-    E S2 = F::mul(y2, a.zzz);
-    E Rr = F::template sub<8>(S2, a.y);
-    if (F::is_zero_any(Rr)) return xyzz_mdbl<F>(x2, y2);
-    return xyzz_inf<F>();
-}
-
-// Doubling of an XYZZ point (dbl-2008-s-1), a not infinity.
-template <class F>
-FP_HD Xyzz<F> xyzz_dbl(const Xyzz<F>& a) {
-    using E = typename F::E;
-    E U = F::add(a.y, a.y);                    // < 12p
-    E V = F::sqr(U);
-    E Wq = F::mul(U, V);
-    E S = F::mul(a.x, V);
-    E xx = F::sqr(a.x);
-    E M = F::add(F::add(xx, xx), xx);          // < 6p
-    Xyzz<F> r;
-    r.x = F::template sub<8>(F::sqr(M), F::add(S, S));
-    E v = F::template sub<16>(S, r.x);
-    r.y = F::template sub<4>(F::mul(M, v), F::mul(Wq, a.y));
-    r.zz = F::mul(V, a.zz);
-    r.zzz = F::mul(Wq, a.zzz);
-    return r;
-}
-
-// Complete addition of two XYZZ points (add-2008-s + the exceptional cases).
-template <class F>
-FP_HD Xyzz<F> xyzz_add(const Xyzz<F>& a, const Xyzz<F>& b) {
-    using E = typename F::E;
-    bool ainf = xyzz_is_inf(a), binf = xyzz_is_inf(b);
-    E U1 = F::mul(a.x, b.zz);
-    E U2 = F::mul(b.x, a.zz);
-    E S1 = F::mul(a.y, b.zzz);
-    E S2 = F::mul(b.y, a.zzz);
-    E Pp = F::template sub<4>(U2, U1);         // < 6p
-    E Rr = F::template sub<4>(S2, S1);         // < 6p
-    E PP = F::sqr(Pp);
-    bool pz = F::is_zero_2p(PP);
-    E PPP = F::mul(Pp, PP);
-    E Q = F::mul(U1, PP);
-    E t = F::add(F::add(PPP, Q), Q);           // < 6p
-    Xyzz<F> r;
-    r.x = F::template sub<8>(F::sqr(Rr), t);   // < 10p
-    E v = F::template sub<16>(Q, r.x);         // < 18p
-    r.y = F::template sub<4>(F::mul(Rr, v), F::mul(S1, PPP));  // < 6p
-    r.zz = F::mul(F::mul(a.zz, b.zz), PP);
-    r.zzz = F::mul(F::mul(a.zzz, b.zzz), PPP);
-    if (!ainf && !binf && pz) {  // rare: same x
-        if (F::is_zero_any(Rr)) r = xyzz_dbl<F>(a);
-        else r = xyzz_inf<F>();
+FP_HD void proj_dbl_n(Proj<F>& a, int k) {
+#pragma unroll 1
+    for (int i = 0; i < k; i++) {
+        Proj<F> c = a;
+        proj_add<F>(a, c);
     }
-    r = xyzz_select<F>(ainf, r, b);
-    r = xyzz_select<F>(binf && !ainf, r, a);
-    return r;
 }
 
-// k doublings (k small), infinity-safe
 template <class F>
-FP_HD Xyzz<F> xyzz_dbl_n(Xyzz<F> a, int k) {
-    bool inf = xyzz_is_inf(a);
-    for (int i = 0; i < k; i++) a = xyzz_dbl<F>(a);
-    return xyzz_select<F>(inf, a, xyzz_inf<F>());
+FP_HD bool proj_is_inf_exact(const Proj<F>& p) { return F::limbs_all_zero(p.z); }
+
+// Hot-loop mixed addition acc <- acc + (x2, y2) in XYZZ, acc NOT infinity.  Returns true ("special") without
+// touching acc when the x-coordinates agree (P == 0 mod p): the caller finishes that bucket on the complete path.
+// Scheduled for few live values: three temporaries besides the accumulator and the point.
+template <class F>
+FP_HD bool xyzz_madd(Xyzz<F>& acc, const typename F::E& x2, const typename F::E& y2) {
+    using E = typename F::E;
+    E t0 = F::template sub<16>(F::mul(x2, acc.zz), acc.x);    // P = U2 - X1          < 18p
+    E t2 = F::mul(t0, t0);                                     // PP
+    if (F::is_zero_2p(t2)) return true;
+    E t1 = F::template sub<8>(F::mul(y2, acc.zzz), acc.y);    // R = S2 - Y1          < 10p
+    t0 = F::mul(t0, t2);                                       // PPP
+    acc.zz = F::mul(acc.zz, t2);                               // ZZ3 = ZZ1 PP
+    t2 = F::mul(acc.x, t2);                                    // Q = X1 PP
+    acc.zzz = F::mul(acc.zzz, t0);                             // ZZZ3 = ZZZ1 PPP
+    acc.y = F::mul(acc.y, t0);                                 // Y1 PPP
+    t0 = F::add(F::add(t0, t2), t2);                           // PPP + 2Q             < 6p
+    acc.x = F::template sub<8>(F::mul(t1, t1), t0);            // X3 = R^2 - PPP - 2Q  < 10p
+    t2 = F::template sub<16>(t2, acc.x);                       // Q - X3               < 18p
+    acc.y = F::template sub<4>(F::mul(t1, t2), acc.y);         // Y3 = R (Q - X3) - Y1 PPP  < 6p
+    return false;
+}
+
+// XYZZ -> projective: (X ZZZ : Y ZZ : ZZ ZZZ)
+template <class F>
+FP_HD Proj<F> xyzz_to_proj(const Xyzz<F>& a) {
+    Proj<F> r;
+    r.x = F::mul(a.x, a.zzz);
+    r.y = F::mul(a.y, a.zz);
+    r.z = F::mul(a.zz, a.zzz);
+    return r;
 }
 
 }  // namespace ec

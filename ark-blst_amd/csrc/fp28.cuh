@@ -12,7 +12,7 @@
 // Field constants: /root/reference/src/fp.rs:25-32 (modulus), src/gpu.rs:253-273 (one / r2 / modulus).
 //
 // Representation invariants
-//   N-form  : limbs l[0..12] <= 2^28 + 7, l[13] small; value = sum l[k] 2^(28k)   (not canonical)
+//   N-form  : limbs l[0..12] <= 2^28 + 15 (what fp_norm1 leaves), l[13] small; value = sum l[k] 2^(28k)   (not canonical)
 //   value   : every function documents the bound (multiples of p) it needs / produces.
 //   Montgomery multiplication accepts any a, b with a*b < 2^392 * p (i.e. a, b < ~50p) and returns < 2p.
 #pragma once
@@ -49,7 +49,7 @@ FP_HD Fp fp_const(const uint32_t (&c)[NL]) {
 }
 FP_HD Fp fp_one() { return fp_const(ONE); }
 
-// One parallel carry pass: any limbs < 2^32  ->  N-form (l[k] <= 2^28 - 1 + 15).
+// One parallel carry pass: any limbs < 2^32  ->  N-form (l[k] <= 2^28 - 1 + 15 < SPREAD_LO = 2^28 + 64).
 FP_HD void fp_norm1(Fp& r) {
     uint32_t cprev = 0;
 #pragma unroll
@@ -88,6 +88,17 @@ template <int K>
 FP_HD Fp fp_neg(const Fp& b) {
     Fp z = fp_zero();
     return fp_sub<K>(z, b);
+}
+
+// r = K*a for a small constant K (K * limb must stay below 2^32: K <= 15)
+template <int K>
+FP_HD Fp fp_mul_small(const Fp& a) {
+    static_assert(K >= 1 && K <= 15, "small multiplier");
+    Fp r;
+#pragma unroll
+    for (int k = 0; k < NL; k++) r.l[k] = a.l[k] * (uint32_t)K;
+    fp_norm1(r);
+    return r;
 }
 
 // lane-wise select without branches
@@ -138,6 +149,15 @@ FP_HD Fp fp_mul(const Fp& a, const Fp& b) {
     return fp_mont_reduce(c);
 }
 
+// The shared multiplier instance.  On the device this is a REAL function (by-value args travel in v0..v27, the
+// result in v0..v13): one ~4.5 KB body per kernel instead of one per use keeps bucket kernels inside the
+// 64 KB instruction cache (see ec.cuh).  On the host it is plain inline code.
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __noinline__ Fp fp_mul_call(Fp a, Fp b) { return fp_mul(a, b); }
+#else
+FP_HD Fp fp_mul_call(const Fp& a, const Fp& b) { return fp_mul(a, b); }
+#endif
+
 // r = a^2 / 2^392 mod p (105 products instead of 196)
 FP_HD Fp fp_sqr(const Fp& a) {
     uint64_t c[2 * NL];
@@ -181,7 +201,7 @@ FP_HD bool fp_is_zero_2p(const Fp& a) {
 }
 
 // a == 0 (mod p) for any N-form value < ~50p: one multiplication by the internal one brings it below 2p.
-FP_HD bool fp_is_zero_any(const Fp& a) { return fp_is_zero_2p(fp_mul(a, fp_one())); }
+FP_HD bool fp_is_zero_any(const Fp& a) { return fp_is_zero_2p(fp_mul_call(a, fp_one())); }
 
 // Canonical representative in [0, p) with exact 28-bit limbs, for an N-form value < 2p.
 FP_HD Fp fp_canon_2p(const Fp& a) {
@@ -224,8 +244,8 @@ FP_HD void fp_pack384(uint32_t (&w)[12], const Fp& a) {  // a: exact limbs, valu
     }
 }
 // blst Montgomery words (x*2^384 mod p)  ->  internal (x*2^392 mod p), N-form < 2p
-FP_HD Fp fp_from_blst(const uint32_t (&w)[12]) { return fp_mul(fp_unpack384(w), fp_const(C_IN)); }
+FP_HD Fp fp_from_blst(const uint32_t (&w)[12]) { return fp_mul_call(fp_unpack384(w), fp_const(C_IN)); }
 // internal (any value < ~50p) -> blst Montgomery words, canonical
-FP_HD void fp_to_blst(uint32_t (&w)[12], const Fp& a) { fp_pack384(w, fp_canon_2p(fp_mul(a, fp_const(C_OUT)))); }
+FP_HD void fp_to_blst(uint32_t (&w)[12], const Fp& a) { fp_pack384(w, fp_canon_2p(fp_mul_call(a, fp_const(C_OUT)))); }
 
 }  // namespace fp28

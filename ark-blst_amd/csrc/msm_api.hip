@@ -39,7 +39,7 @@ struct HipFail {
     } while (0)
 
 struct Plan {
-    uint32_t c, nwin, nb, logL, chunks_per_win;
+    uint32_t c, nwin, nb, logL, chunks_per_win, logT;
     uint64_t nbuckets, nchunks;
 };
 
@@ -64,6 +64,10 @@ Plan make_plan(size_t n, unsigned forced_c) {
     best.chunks_per_win = best.nb >> (6 + best.logL);
     best.nbuckets = (uint64_t)best.nb * best.nwin;
     best.nchunks = (uint64_t)best.chunks_per_win * best.nwin;
+    // work-item size: twice the mean bucket load (uniform scalars then never split), at least 32 entries
+    double mean = (double)n / best.nb;
+    best.logT = 5;
+    while ((double)(1u << best.logT) < 2.0 * mean && best.logT < 20) best.logT++;
     return best;
 }
 
@@ -94,7 +98,7 @@ struct DevState {
     size_t g1_resident = 0;      // points resident on this device
     size_t g1_shard_lo = 0;      // global index of the first resident point
     // scratch
-    DevBuf raw, call_bases, scalars, hist, offsets, cursor, sorted, buckets, pairs;
+    DevBuf raw, call_bases, scalars, hist, offsets, cursor, woff, meta, sorted, partial, item_k, item_n, pairs;
     void* h_pairs = nullptr;
     size_t h_pairs_cap = 0;
     mi_profile prof{};
@@ -182,8 +186,9 @@ G1 run_g1(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_s
     d.hist.ensure(pl.nbuckets * 4);
     d.offsets.ensure((pl.nbuckets + 1) * 4);
     d.cursor.ensure(pl.nbuckets * 4);
+    d.woff.ensure((pl.nbuckets + 1) * 4);
+    d.meta.ensure(16);
     d.sorted.ensure((size_t)n * pl.nwin * 4);
-    d.buckets.ensure(pl.nbuckets * msmk::G1_BK_WORDS * 4);
     d.pairs.ensure(pl.nchunks * 2 * 144);
     ensure_host(d, pl.nchunks * 2 * 144 + 16);
 
@@ -194,21 +199,32 @@ G1 run_g1(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_s
     hipLaunchKernelGGL(msmk::k_digits_hist, dim3(grid_n), dim3(256), 0, s, d_scalars, d_bases, (uint32_t)msmk::G1_PT_WORDS,
                        (uint32_t)n, fmt, pl.c, pl.nwin, (uint32_t*)d.hist.p);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 1], s));
-    hipLaunchKernelGGL(msmk::k_scan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets,
-                       (uint32_t*)d.offsets.p, (uint32_t*)d.cursor.p);
+    hipLaunchKernelGGL(msmk::k_scan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, pl.logT,
+                       (uint32_t*)d.offsets.p, (uint32_t*)d.cursor.p, (uint32_t*)d.woff.p, (uint32_t*)d.meta.p);
+    // the item count sizes the next launches: one small read-back (the only mid-pipeline sync)
+    uint32_t meta[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(meta, d.meta.p, 12, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(d.ev[ev0 + 2], s));
     hipLaunchKernelGGL(msmk::k_scatter, dim3(grid_n), dim3(256), 0, s, d_scalars, d_bases, (uint32_t)msmk::G1_PT_WORDS, (uint32_t)n,
                        fmt, pl.c, pl.nwin, (uint32_t*)d.cursor.p, (uint32_t*)d.sorted.p);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 3], s));
-    hipLaunchKernelGGL(msmk::k_accumulate_g1, dim3((uint32_t)((pl.nbuckets + 255) / 256)), dim3(256), 0, s, d_bases,
-                       (const uint32_t*)d.sorted.p, (const uint32_t*)d.offsets.p, (uint32_t*)d.buckets.p, (uint32_t)pl.nbuckets);
+    HIP_TRY(hipStreamSynchronize(s));
+    uint32_t nitems = meta[0], max_items = meta[1];
+    d.partial.ensure((size_t)nitems * msmk::G1_BK_WORDS * 4);
+    d.item_k.ensure((size_t)nitems * 4);
+    d.item_n.ensure((size_t)nitems * 4);
+    uint32_t grid_items = (nitems + 255) / 256;
+    hipLaunchKernelGGL(msmk::k_accumulate_g1, dim3(grid_items), dim3(256), 0, s, d_bases, (const uint32_t*)d.sorted.p,
+                       (const uint32_t*)d.offsets.p, (const uint32_t*)d.woff.p, (uint32_t)pl.nbuckets, pl.logT, (uint32_t*)d.partial.p,
+                       (uint32_t*)d.item_k.p, (uint32_t*)d.item_n.p);
+    for (uint32_t dd = 1; dd < max_items; dd <<= 1)
+        hipLaunchKernelGGL(msmk::k_merge_g1, dim3(grid_items), dim3(256), 0, s, (uint32_t*)d.partial.p, (const uint32_t*)d.item_k.p,
+                           (const uint32_t*)d.item_n.p, nitems, dd);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 4], s));
-    hipLaunchKernelGGL(msmk::k_reduce_g1, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.buckets.p,
-                       (uint32_t*)d.pairs.p, pl.logL);
+    hipLaunchKernelGGL(msmk::k_reduce_g1, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
+                       (const uint32_t*)d.woff.p, (uint32_t*)d.pairs.p, pl.logL);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 5], s));
     HIP_TRY(hipMemcpyAsync(d.h_pairs, d.pairs.p, pl.nchunks * 2 * 144, hipMemcpyDeviceToHost, s));
-    // total number of scattered entries = mixed additions (+ first-touch copies)
-    HIP_TRY(hipMemcpyAsync((char*)d.h_pairs + pl.nchunks * 2 * 144, (char*)d.offsets.p + pl.nbuckets * 4, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(d.ev[ev0 + 6], s));
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipGetLastError());
@@ -219,9 +235,9 @@ G1 run_g1(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_s
     d.prof.accumulate_ms = ev_ms(d.ev[ev0 + 3], d.ev[ev0 + 4]);
     d.prof.reduce_ms = ev_ms(d.ev[ev0 + 4], d.ev[ev0 + 5]);
     d.prof.d2h_ms = ev_ms(d.ev[ev0 + 5], d.ev[ev0 + 6]);
-    uint32_t entries;
-    memcpy(&entries, (char*)d.h_pairs + pl.nchunks * 2 * 144, 4);
-    d.prof.accumulate_adds = entries;
+    d.prof.accumulate_adds = meta[2];
+    d.prof.work_items = nitems;
+    d.prof.max_items_per_bucket = max_items;
 
     auto t0 = std::chrono::steady_clock::now();
     G1 r = host_fold_g1(reinterpret_cast<const G1*>(d.h_pairs), pl);
@@ -386,7 +402,8 @@ void mi_msm_destroy(mi_ctx* ctx) {
     for (auto& d : ctx->devs) {
         (void)hipSetDevice(d.dev);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
-        for (DevBuf* b : {&d.g1_bases, &d.raw, &d.call_bases, &d.scalars, &d.hist, &d.offsets, &d.cursor, &d.sorted, &d.buckets, &d.pairs})
+        for (DevBuf* b : {&d.g1_bases, &d.raw, &d.call_bases, &d.scalars, &d.hist, &d.offsets, &d.cursor, &d.woff, &d.meta, &d.sorted,
+                          &d.partial, &d.item_k, &d.item_n, &d.pairs})
             b->release();
         if (d.h_pairs) (void)hipHostFree(d.h_pairs);
         for (auto& e : d.ev)

@@ -7,9 +7,11 @@
 //
 //   k_ingest      bases: blst_p1_affine (96 B, R = 2^384)  ->  device form (2 x 14 x 28-bit limbs, R' = 2^392)
 //   k_digits_hist scalars -> signed c-bit digits (NEGATION_IS_CHEAP, src/g1.rs:595), per-(window,bucket) histogram
-//   k_scan        exclusive prefix sum of the histogram -> bucket offsets
+//   k_scan        exclusive prefix sums of the histogram -> bucket offsets + work-item offsets (heavy buckets split)
 //   k_scatter     (point index | sign) scattered into bucket order
-//   k_accumulate  one lane per bucket: XYZZ mixed additions over its sorted run        <- dominant kernel
+//   k_accumulate  one lane per work item (bucket, chunk<=T): XYZZ mixed additions over its run   <- dominant kernel
+//                 (exceptional pairs finish on the complete projective formulas); bucket stored projective
+//   k_merge       (only if a bucket was split) binary-tree merge of a bucket's partial sums
 //   k_reduce      one wave per 64*L consecutive buckets: lane-serial running sums + wavefront suffix scan
 //                 -> (S, T) = (sum B_b, sum (b-b0+1) B_b) per chunk, written as blst_p1 Jacobian
 //   host          per-window chunk combine + Horner fold (hostec), as the reference folds on the host too.
@@ -25,8 +27,8 @@ using fp28::NL;
 // ---------------------------------------------------------------------------------------------- layouts
 // device affine point (G1): 32 words = 128 B: x limbs [0,14), y limbs [16,30), word 31 = 1 if infinity
 constexpr int G1_PT_WORDS = 32;
-// device bucket (G1 XYZZ): 64 words = 256 B: coordinate k at words [16k, 16k+14)
-constexpr int G1_BK_WORDS = 64;
+// device bucket (G1 projective, complete-formula form): 48 words = 192 B: coordinate k at words [16k, 16k+14)
+constexpr int G1_BK_WORDS = 48;
 
 __device__ __forceinline__ void load_fp16(Fp& r, const uint32_t* p) {  // 16-word aligned slot, 14 used
     const uint4* q = reinterpret_cast<const uint4*>(p);
@@ -46,18 +48,16 @@ __device__ __forceinline__ void store_fp16(uint32_t* p, const Fp& r, uint32_t w1
 
 using F1 = ec::FpOps;
 using X1 = ec::Xyzz<F1>;
+using P1 = ec::Proj<F1>;
 
-__device__ __forceinline__ X1 load_bucket(const uint32_t* p) {
-    X1 r;
-    load_fp16(r.x, p); load_fp16(r.y, p + 16); load_fp16(r.zz, p + 32); load_fp16(r.zzz, p + 48);
+__device__ __forceinline__ P1 load_bucket(const uint32_t* p) {
+    P1 r;
+    load_fp16(r.x, p); load_fp16(r.y, p + 16); load_fp16(r.z, p + 32);
     return r;
 }
-__device__ __forceinline__ void store_bucket(uint32_t* p, const X1& r) {
-    store_fp16(p, r.x); store_fp16(p + 16, r.y); store_fp16(p + 32, r.zz); store_fp16(p + 48, r.zzz);
+__device__ __forceinline__ void store_bucket(uint32_t* p, const P1& r) {
+    store_fp16(p, r.x); store_fp16(p + 16, r.y); store_fp16(p + 32, r.z);
 }
-
-// complete addition kept out of line: it is instantiated in three kernels' loops and is not the hot path
-__device__ __noinline__ X1 g1_add(const X1& a, const X1& b) { return ec::xyzz_add<F1>(a, b); }
 
 // ---------------------------------------------------------------------------------------------- ingest
 // raw: n x 24 words (blst_p1_affine).  One thread per point.
@@ -182,67 +182,146 @@ __global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ sc
     });
 }
 
-// Exclusive prefix sum of `m` counters by ONE workgroup of 1024 lanes (m <= a few 10^5; ~tens of us).
-// in: hist[m]; out: offsets[m+1] and cursor[m] (copy of offsets for the scatter pass).
-__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ hist, uint32_t m, uint32_t* __restrict__ offsets,
-                                               uint32_t* __restrict__ cursor) {
-    __shared__ uint32_t part[1024];
+// Exclusive prefix sums over the `m` bucket counters by ONE workgroup of 1024 lanes (m <= a few 10^5; ~tens of us):
+//   offsets[m+1] / cursor[m] : entry offsets (scatter destinations)
+//   woff[m+1]                : WORK-ITEM offsets.  A bucket with cnt entries becomes max(1, ceil(cnt / T)) items of at
+//                              most T = 2^logT entries each, so a heavy bucket (skewed scalars, or the short top window)
+//                              is spread over many lanes instead of serialising one lane for its whole length.
+//   meta[0] = total items, meta[1] = max items of any bucket, meta[2] = total entries.
+__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ hist, uint32_t m, uint32_t logT,
+                                               uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
+                                               uint32_t* __restrict__ woff, uint32_t* __restrict__ meta) {
+    __shared__ uint32_t part_e[1024];
+    __shared__ uint32_t part_i[1024];
+    __shared__ uint32_t max_items;
     uint32_t t = threadIdx.x;
+    if (t == 0) max_items = 1;
     uint32_t per = (m + 1023) / 1024;
     uint32_t lo = t * per, hi = lo + per < m ? lo + per : m;
-    uint32_t sum = 0;
-    for (uint32_t k = lo; k < hi; k++) sum += hist[k];
-    part[t] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t v = t >= d ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    uint32_t run = part[t] - sum;  // exclusive
+    uint32_t T1 = (1u << logT) - 1u;
+    uint32_t sum_e = 0, sum_i = 0, mx = 1;
     for (uint32_t k = lo; k < hi; k++) {
         uint32_t h = hist[k];
-        offsets[k] = run;
-        cursor[k] = run;
-        run += h;
+        uint32_t it = h == 0 ? 1u : (h + T1) >> logT;
+        sum_e += h;
+        sum_i += it;
+        mx = it > mx ? it : mx;
     }
-    if (t == 1023) offsets[m] = part[1023];
+    part_e[t] = sum_e;
+    part_i[t] = sum_i;
+    __syncthreads();
+    atomicMax(&max_items, mx);
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t ve = t >= d ? part_e[t - d] : 0, vi = t >= d ? part_i[t - d] : 0;
+        __syncthreads();
+        part_e[t] += ve;
+        part_i[t] += vi;
+        __syncthreads();
+    }
+    uint32_t run_e = part_e[t] - sum_e, run_i = part_i[t] - sum_i;  // exclusive
+    for (uint32_t k = lo; k < hi; k++) {
+        uint32_t h = hist[k];
+        offsets[k] = run_e;
+        cursor[k] = run_e;
+        woff[k] = run_i;
+        run_e += h;
+        run_i += h == 0 ? 1u : (h + T1) >> logT;
+    }
+    if (t == 1023) {
+        offsets[m] = part_e[1023];
+        woff[m] = part_i[1023];
+        meta[0] = part_i[1023];
+        meta[1] = max_items;
+        meta[2] = part_e[1023];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- accumulate
-// One lane per bucket.  sorted[offsets[b] .. offsets[b+1]) lists (index | sign<<31) of the points in bucket b.
+__device__ __forceinline__ void load_point(Fp& x, Fp& y, const uint32_t* bases, uint32_t ent) {
+    const uint32_t* p = bases + (size_t)(ent & 0x7fffffffu) * G1_PT_WORDS;
+    load_fp16(x, p);
+    load_fp16(y, p + 16);
+}
+
+// One lane per WORK ITEM = (bucket, chunk): item i of bucket b covers entries
+// sorted[offsets[b] + k*T .. min(offsets[b] + (k+1)*T, offsets[b+1])), k = i - woff[b]; entries are (index | sign<<31).
+// Hot loop: XYZZ mixed additions.  Register budget is the constraint (256 VGPRs at 2 waves/SIMD), so the next
+// point is not staged in registers: its index is fetched one iteration ahead and its 128-byte line is touched
+// early so the real load hits L2; the other resident wave covers what latency is left.
+// A lane that meets an exceptional pair (same x) leaves the hot loop and finishes on the complete formulas.
+// Output: partial[i] (projective), item_k[i] = k, item_n[i] = items of the bucket (for the merge passes).
 __global__ void __launch_bounds__(256, 2) k_accumulate_g1(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                                                          const uint32_t* __restrict__ offsets, uint32_t* __restrict__ buckets,
-                                                          uint32_t nbuckets) {
-    uint32_t b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= nbuckets) return;
-    uint32_t beg = offsets[b], end = offsets[b + 1];
-    X1 acc = ec::xyzz_inf<F1>();
-    bool inf = true;
-    for (uint32_t e = beg; e < end; e++) {
-        uint32_t ent = sorted[e];
-        const uint32_t* p = bases + (size_t)(ent & 0x7fffffffu) * G1_PT_WORDS;
-        Fp x, y;
-        load_fp16(x, p);
-        load_fp16(y, p + 16);
-        Fp yn = fp28::fp_neg<4>(y);
-        y = fp28::fp_select((ent >> 31) != 0, y, yn);
-        if (inf) {
-            acc = ec::xyzz_from_affine<F1>(x, y);
-            inf = false;
-            continue;
+                                                          const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ woff,
+                                                          uint32_t nbuckets, uint32_t logT, uint32_t* __restrict__ partial,
+                                                          uint32_t* __restrict__ item_k, uint32_t* __restrict__ item_n) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t nitems = woff[nbuckets];
+    if (i >= nitems) return;
+    // item -> bucket: identity when nothing before it was split, else binary search (largest b with woff[b] <= i)
+    uint32_t b = i < nbuckets ? i : nbuckets - 1;
+    if (!(woff[b] <= i && i < woff[b + 1])) {
+        uint32_t lo = 0, hi = b;  // woff[b] > i here is impossible to the right: items >= buckets, so woff[b] >= b
+        while (lo < hi) {
+            uint32_t mid = (lo + hi + 1) >> 1;
+            if (woff[mid] <= i) lo = mid; else hi = mid - 1;
         }
-        bool pz;
-        X1 r = ec::xyzz_madd_core<F1>(acc, x, y, pz);
-        if (pz) {  // same x: doubling or cancellation (never on random inputs; crafted tests cover it)
-            r = ec::xyzz_madd_special<F1>(acc, x, y);
-            inf = ec::xyzz_is_inf<F1>(r);
-        }
-        acc = r;
+        b = lo;
     }
-    if (inf) acc = ec::xyzz_inf<F1>();
-    store_bucket(buckets + (size_t)b * G1_BK_WORDS, acc);
+    uint32_t k = i - woff[b];
+    uint32_t e = offsets[b] + (k << logT), bend = offsets[b + 1];
+    uint32_t end = e + (1u << logT) < bend ? e + (1u << logT) : bend;
+    item_k[i] = k;
+    item_n[i] = woff[b + 1] - woff[b];
+    X1 acc;
+    acc.x = fp28::fp_zero(); acc.y = fp28::fp_zero(); acc.zz = fp28::fp_zero(); acc.zzz = fp28::fp_zero();
+    bool inf = true;
+    uint32_t nent = e < end ? sorted[e] : 0u;
+    while (e < end) {
+        uint32_t ent = nent;
+        Fp x, y;
+        load_point(x, y, bases, ent);
+        if (e + 1 < end) {
+            nent = sorted[e + 1];
+            __builtin_prefetch(bases + (size_t)(nent & 0x7fffffffu) * G1_PT_WORDS, 0, 1);
+        }
+        y = fp28::fp_select((ent >> 31) != 0, y, fp28::fp_neg<4>(y));
+        if (inf) {
+            acc.x = x; acc.y = y; acc.zz = fp28::fp_one(); acc.zzz = fp28::fp_one();
+            inf = false;
+        } else if (ec::xyzz_madd<F1>(acc, x, y)) {
+            break;  // exceptional pair at entry e: acc untouched
+        }
+        e++;
+    }
+    P1 out = ec::proj_inf<F1>();
+    if (!inf) out = ec::xyzz_to_proj<F1>(acc);
+    while (e < end) {  // cold path (never taken on random inputs): complete additions
+        uint32_t ent = sorted[e];
+        Fp x, y;
+        load_point(x, y, bases, ent);
+        y = fp28::fp_select((ent >> 31) != 0, y, fp28::fp_neg<4>(y));
+        P1 q = ec::proj_from_affine<F1>(x, y);
+        ec::proj_add<F1>(out, q);
+        e++;
+    }
+    store_bucket(partial + (size_t)i * G1_BK_WORDS, out);
+}
+
+// One binary-tree level of the per-bucket merge of split buckets: partial[i] += partial[i + d] for the items whose
+// chunk index is a multiple of 2d.  After ceil(log2(max items)) levels partial[woff[b]] is bucket b.  Launched only
+// when some bucket was split (meta[1] > 1).
+__global__ void __launch_bounds__(256, 2) k_merge_g1(uint32_t* __restrict__ partial, const uint32_t* __restrict__ item_k,
+                                                     const uint32_t* __restrict__ item_n, uint32_t nitems, uint32_t d) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nitems) return;
+    uint32_t n = item_n[i];
+    if (n <= d) return;
+    uint32_t k = item_k[i];
+    if ((k & (2 * d - 1)) != 0 || k + d >= n) return;
+    P1 a = load_bucket(partial + (size_t)i * G1_BK_WORDS);
+    P1 c = load_bucket(partial + (size_t)(i + d) * G1_BK_WORDS);
+    ec::proj_add<F1>(a, c);
+    store_bucket(partial + (size_t)i * G1_BK_WORDS, a);
 }
 
 // ---------------------------------------------------------------------------------------------- reduce
@@ -252,59 +331,64 @@ __device__ __forceinline__ Fp shfl_down_fp(const Fp& a, int d) {
     for (int k = 0; k < NL; k++) r.l[k] = __shfl_down(a.l[k], d, 64);
     return r;
 }
-__device__ __forceinline__ X1 shfl_down_pt(const X1& a, int d) {
-    X1 r;
-    r.x = shfl_down_fp(a.x, d); r.y = shfl_down_fp(a.y, d); r.zz = shfl_down_fp(a.zz, d); r.zzz = shfl_down_fp(a.zzz, d);
+__device__ __forceinline__ P1 shfl_down_pt(const P1& a, int d) {
+    P1 r;
+    r.x = shfl_down_fp(a.x, d); r.y = shfl_down_fp(a.y, d); r.z = shfl_down_fp(a.z, d);
     return r;
 }
 
-// XYZZ -> blst_p1 Jacobian words: (X*ZZ, Y*ZZZ, ZZ) is a Jacobian triple of the same point (Z := ZZ).
-__device__ __forceinline__ void store_jac_blst(uint32_t* out, const X1& p) {
+// projective (X : Y : Z) -> blst_p1 Jacobian words (X Z, Y Z^2, Z); infinity (Z == 0 mod p) -> all-zero
+__device__ __forceinline__ void store_jac_blst(uint32_t* out, const P1& p) {
     uint32_t w[12];
-    bool inf = ec::xyzz_is_inf<F1>(p);
-    fp28::fp_to_blst(w, fp28::fp_mul(p.x, p.zz));
+    fp28::fp_to_blst(w, p.z);
+    uint32_t any = 0;
 #pragma unroll
-    for (int k = 0; k < 12; k++) out[k] = inf ? 0u : w[k];
-    fp28::fp_to_blst(w, fp28::fp_mul(p.y, p.zzz));
+    for (int k = 0; k < 12; k++) { out[24 + k] = w[k]; any |= w[k]; }
+    Fp zz = fp28::fp_mul_call(p.z, p.z);
+    fp28::fp_to_blst(w, fp28::fp_mul_call(p.x, p.z));
 #pragma unroll
-    for (int k = 0; k < 12; k++) out[12 + k] = inf ? 0u : w[k];
-    fp28::fp_to_blst(w, p.zz);
+    for (int k = 0; k < 12; k++) out[k] = any ? w[k] : 0u;
+    fp28::fp_to_blst(w, fp28::fp_mul_call(p.y, zz));
 #pragma unroll
-    for (int k = 0; k < 12; k++) out[24 + k] = inf ? 0u : w[k];
+    for (int k = 0; k < 12; k++) out[12 + k] = any ? w[k] : 0u;
 }
 
 // One wave per chunk of 64*L consecutive buckets of one window (L = 2^logL).  Lane l owns buckets
 // [l*L, l*L+L) of the chunk.  Output per chunk: S = sum B, T = sum (rel+1) B with rel = index inside the chunk,
-// as two blst_p1 (36 words each).
-__global__ void __launch_bounds__(64) k_reduce_g1(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ pairs, uint32_t logL) {
+// as two blst_p1 (36 words each).  All additions are the complete projective formulas: no exceptional cases.
+__global__ void __launch_bounds__(64) k_reduce_g1(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ woff,
+                                                  uint32_t* __restrict__ pairs, uint32_t logL) {
     uint32_t chunk = blockIdx.x, lane = threadIdx.x;
     uint32_t L = 1u << logL;
-    const uint32_t* bp = buckets + ((size_t)chunk * 64 * L + (size_t)lane * L) * G1_BK_WORDS;
-    X1 run = ec::xyzz_inf<F1>(), acc = ec::xyzz_inf<F1>();
+    const uint32_t* wp = woff + (size_t)chunk * 64 * L + (size_t)lane * L;  // bucket b lives at partial[woff[b]]
+    P1 run = ec::proj_inf<F1>(), acc = ec::proj_inf<F1>();
+#pragma unroll 1
     for (int t = (int)L - 1; t >= 0; t--) {
-        X1 B = load_bucket(bp + (size_t)t * G1_BK_WORDS);
-        run = g1_add(run, B);
-        acc = g1_add(acc, run);
+        P1 B = load_bucket(partial + (size_t)wp[t] * G1_BK_WORDS);
+        ec::proj_add<F1>(run, B);
+        ec::proj_add<F1>(acc, run);
     }
     // suffix scan of the lane sums: P_l = sum_{j >= l} S_j
-    X1 P = run;
+#pragma unroll 1
     for (int d = 1; d < 64; d <<= 1) {
-        X1 Q = shfl_down_pt(P, d);
-        X1 Pn = g1_add(P, Q);
-        P = ec::xyzz_select<F1>(lane + d < 64, P, Pn);
+        P1 Q = shfl_down_pt(run, d);
+        Q = ec::proj_select<F1>(lane + d < 64, ec::proj_inf<F1>(), Q);
+        ec::proj_add<F1>(run, Q);
     }
     // V_l = T_l + L * P_l (l >= 1), V_0 = T_0 ; chunk T = sum_l V_l
-    X1 LP = ec::xyzz_dbl_n<F1>(P, (int)logL);
-    LP = ec::xyzz_select<F1>(lane == 0, LP, ec::xyzz_inf<F1>());
-    X1 V = g1_add(acc, LP);
+    P1 LP = run;
+    ec::proj_dbl_n<F1>(LP, (int)logL);
+    LP = ec::proj_select<F1>(lane == 0, LP, ec::proj_inf<F1>());
+    ec::proj_add<F1>(acc, LP);
+#pragma unroll 1
     for (int d = 32; d >= 1; d >>= 1) {
-        X1 Q = shfl_down_pt(V, d);
-        X1 Vn = g1_add(V, Q);
-        V = ec::xyzz_select<F1>((int)lane < d, V, Vn);
+        P1 Q = shfl_down_pt(acc, d);
+        Q = ec::proj_select<F1>((int)lane < d, ec::proj_inf<F1>(), Q);
+        ec::proj_add<F1>(acc, Q);
     }
     if (lane == 0) {
-        store_jac_blst(pairs + (size_t)chunk * 72, P);
-        store_jac_blst(pairs + (size_t)chunk * 72 + 36, V);
+        store_jac_blst(pairs + (size_t)chunk * 72, run);
+        store_jac_blst(pairs + (size_t)chunk * 72 + 36, acc);
     }
 }
 
@@ -317,10 +401,11 @@ __global__ void __launch_bounds__(256) k_test_fp_op(int op, const uint32_t* __re
 #pragma unroll
     for (int k = 0; k < 12; k++) { aw[k] = a[(size_t)i * 12 + k]; bw[k] = b[(size_t)i * 12 + k]; }
     Fp x = fp28::fp_from_blst(aw), y = fp28::fp_from_blst(bw), z;
-    if (op == 0) z = fp28::fp_mul(x, y);
+    if (op == 0) z = fp28::fp_mul_call(x, y);
     else if (op == 1) z = fp28::fp_sqr(x);
     else if (op == 2) z = fp28::fp_add(x, y);
     else z = fp28::fp_sub<4>(x, y);
+    
     fp28::fp_to_blst(ow, z);
 #pragma unroll
     for (int k = 0; k < 12; k++) out[(size_t)i * 12 + k] = ow[k];

@@ -63,7 +63,7 @@ typedef struct {
     double digits_ms;       /* signed-window digit extraction + histogram */
     double scan_ms;         /* bucket offsets (prefix sum) */
     double scatter_ms;      /* bucket scatter (sort by bucket) */
-    double accumulate_ms;   /* bucket accumulation: the dominant kernel */
+    double accumulate_ms;   /* bucket accumulation (dominant kernel) + merge of split buckets */
     double reduce_ms;       /* per-chunk weighted bucket reduction */
     double d2h_ms;          /* partial sums device->host */
     double host_fold_ms;    /* CPU tail: chunk combine + Horner fold over windows */
@@ -72,6 +72,8 @@ typedef struct {
     uint32_t num_windows;   /* ceil(256 / c) */
     uint64_t n;             /* points in the call */
     uint64_t accumulate_adds; /* mixed additions executed by the accumulate kernel */
+    uint32_t work_items;      /* lanes of the accumulate kernel: buckets, heavy ones split into chunks */
+    uint32_t max_items_per_bucket; /* 1 = no bucket was split */
 } mi_profile;
 
 /* Replaces Device::all()[0] + ec_gpu_gen::program! + SingleMultiexpKernel::create (src/gpu.rs:233-237,101-119),

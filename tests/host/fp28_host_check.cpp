@@ -7,6 +7,7 @@
 using namespace fp28;
 using F = ec::FpOps;
 using X = ec::Xyzz<F>;
+using Pj = ec::Proj<F>;
 
 static Fp load_blst(const uint8_t* p) {
     uint32_t w[12];
@@ -18,18 +19,32 @@ static void store_blst(uint8_t* p, const Fp& a) {
     fp_to_blst(w, a);
     memcpy(p, w, 48);
 }
+static bool is_zero96(const uint8_t* p) {
+    bool zero = true;
+    for (int k = 0; k < 96; k++) zero &= p[k] == 0;
+    return zero;
+}
+// projective -> blst Jacobian bytes (X Z, Y Z^2, Z); infinity -> zeros
+static void store_proj_as_jac(uint8_t* out, const Pj& p) {
+    uint8_t z[48];
+    store_blst(z, p.z);
+    bool any = false;
+    for (int k = 0; k < 48; k++) any |= z[k] != 0;
+    if (!any) { memset(out, 0, 144); return; }
+    Fp zz = fp_mul(p.z, p.z);
+    store_blst(out, fp_mul(p.x, p.z));
+    store_blst(out + 48, fp_mul(p.y, zz));
+    memcpy(out + 96, z, 48);
+}
 
 extern "C" {
 
-// out = a*b in blst Montgomery form (n elements)
 void h28_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int use_sqr) {
     for (size_t i = 0; i < n; i++) {
         Fp x = load_blst(a + 48 * i), y = load_blst(b + 48 * i);
-        Fp z = use_sqr ? fp_sqr(x) : fp_mul(x, y);
-        store_blst(out + 48 * i, z);
+        store_blst(out + 48 * i, use_sqr ? fp_sqr(x) : fp_mul(x, y));
     }
 }
-// out = a + b, a - b (mod p) canonical blst form
 void h28_fp_addsub(const uint8_t* a, const uint8_t* b, uint8_t* out_add, uint8_t* out_sub, size_t n) {
     for (size_t i = 0; i < n; i++) {
         Fp x = load_blst(a + 48 * i), y = load_blst(b + 48 * i);
@@ -37,58 +52,62 @@ void h28_fp_addsub(const uint8_t* a, const uint8_t* b, uint8_t* out_add, uint8_t
         store_blst(out_sub + 48 * i, fp_sub<4>(x, y));
     }
 }
-// pack/unpack round trip
+void h28_fp_mul_small(const uint8_t* a, uint8_t* out3, uint8_t* out12, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        Fp x = load_blst(a + 48 * i);
+        store_blst(out3 + 48 * i, fp_mul_small<3>(x));
+        store_blst(out12 + 48 * i, fp_mul_small<12>(x));
+    }
+}
 void h28_roundtrip(const uint8_t* a, uint8_t* out, size_t n) {
     for (size_t i = 0; i < n; i++) store_blst(out + 48 * i, load_blst(a + 48 * i));
 }
-static void store_xyzz_as_jac(uint8_t* out, const X& acc) {
-    if (ec::xyzz_is_inf(acc)) { memset(out, 0, 144); return; }
-    store_blst(out, fp_mul(acc.x, acc.zz));
-    store_blst(out + 48, fp_mul(acc.y, acc.zzz));
-    store_blst(out + 96, acc.zz);
-}
-// signed sum of affine points with the mixed-add path: out (Jacobian blst bytes) = sum (+/-) P_i
-void h28_g1_madd_chain(const uint8_t* bases, const uint8_t* neg, size_t n, uint8_t* out) {
-    X acc = ec::xyzz_inf<F>();
+// The accumulate kernel's per-bucket logic: XYZZ hot loop, then the complete cold path from the first
+// exceptional pair on.  *took_cold reports whether the cold path ran.
+void h28_g1_bucket(const uint8_t* bases, const uint8_t* neg, size_t n, uint8_t* out, int* took_cold) {
+    X acc;
+    acc.x = fp_zero(); acc.y = fp_zero(); acc.zz = fp_zero(); acc.zzz = fp_zero();
     bool inf = true;
-    for (size_t i = 0; i < n; i++) {
-        const uint8_t* p = bases + 96 * i;
-        bool zero = true;
-        for (int k = 0; k < 96; k++) zero &= p[k] == 0;
-        if (zero) continue;
+    size_t e = 0;
+    for (; e < n; e++) {
+        const uint8_t* p = bases + 96 * e;
         Fp x = load_blst(p), y = load_blst(p + 48);
-        if (neg && neg[i]) y = fp_neg<4>(y);
-        if (inf) { acc = ec::xyzz_from_affine<F>(x, y); inf = false; continue; }
-        bool pz;
-        X r = ec::xyzz_madd_core<F>(acc, x, y, pz);
-        if (pz) { r = ec::xyzz_madd_special<F>(acc, x, y); inf = ec::xyzz_is_inf(r); }
-        acc = r;
+        if (neg && neg[e]) y = fp_neg<4>(y);
+        if (inf) { acc.x = x; acc.y = y; acc.zz = fp_one(); acc.zzz = fp_one(); inf = false; }
+        else if (ec::xyzz_madd<F>(acc, x, y)) break;
     }
-    if (inf) acc = ec::xyzz_inf<F>();
-    store_xyzz_as_jac(out, acc);
+    Pj o = ec::proj_inf<F>();
+    if (!inf) o = ec::xyzz_to_proj<F>(acc);
+    *took_cold = e < n;
+    for (; e < n; e++) {
+        const uint8_t* p = bases + 96 * e;
+        Fp x = load_blst(p), y = load_blst(p + 48);
+        if (neg && neg[e]) y = fp_neg<4>(y);
+        Pj q = ec::proj_from_affine<F>(x, y);
+        ec::proj_add<F>(o, q);
+    }
+    store_proj_as_jac(out, o);
 }
-// tree sum with the complete XYZZ+XYZZ addition (exercises inf / doubling / cancellation)
+// tree sum with the complete projective addition (infinity inputs = all-zero affine)
 void h28_g1_add_tree(const uint8_t* bases, size_t n, uint8_t* out) {
-    X* v = new X[n + 1];
+    Pj* v = new Pj[n + 1];
     for (size_t i = 0; i < n; i++) {
         const uint8_t* p = bases + 96 * i;
-        bool zero = true;
-        for (int k = 0; k < 96; k++) zero &= p[k] == 0;
-        v[i] = zero ? ec::xyzz_inf<F>() : ec::xyzz_from_affine<F>(load_blst(p), load_blst(p + 48));
+        v[i] = is_zero96(p) ? ec::proj_inf<F>() : ec::proj_from_affine<F>(load_blst(p), load_blst(p + 48));
     }
     size_t m = n;
     while (m > 1) {
         size_t h = (m + 1) / 2;
-        for (size_t i = 0; i + h < m; i++) v[i] = ec::xyzz_add<F>(v[i], v[i + h]);
+        for (size_t i = 0; i + h < m; i++) ec::proj_add<F>(v[i], v[i + h]);
         m = h;
     }
-    X r = n ? v[0] : ec::xyzz_inf<F>();
-    store_xyzz_as_jac(out, r);
+    Pj r = n ? v[0] : ec::proj_inf<F>();
+    store_proj_as_jac(out, r);
     delete[] v;
 }
-// out = 2^k * P via xyzz_dbl_n
 void h28_g1_dbl_n(const uint8_t* base, int k, uint8_t* out) {
-    X a = ec::xyzz_from_affine<F>(load_blst(base), load_blst(base + 48));
-    store_xyzz_as_jac(out, ec::xyzz_dbl_n<F>(a, k));
+    Pj a = is_zero96(base) ? ec::proj_inf<F>() : ec::proj_from_affine<F>(load_blst(base), load_blst(base + 48));
+    ec::proj_dbl_n<F>(a, k);
+    store_proj_as_jac(out, a);
 }
 }

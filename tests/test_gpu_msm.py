@@ -92,6 +92,29 @@ def test_g1_msm_edge_cases(ctx, co, o, pkg):
     assert _canon(co, "g1", got) == bytes(96)
 
 
+@pytest.mark.parametrize("kind", ["all_equal", "zero_one", "small64", "two_values"])
+def test_g1_msm_skewed_scalars(ctx, co, o, pkg, kind):
+    """Non-uniform scalar distributions (R1CS-like witnesses): heavy buckets are split into work items and merged."""
+    n = 6000
+    rnd = random.Random(5)
+    bases = co.gen_bases("g1", SEED_B + 4, n, 4)
+    if kind == "all_equal":
+        sc = [rnd.randrange(o.R_ORDER)] * n
+    elif kind == "zero_one":
+        sc = [rnd.randrange(2) for _ in range(n)]
+    elif kind == "small64":
+        sc = [rnd.randrange(1 << 64) for _ in range(n)]
+    else:
+        a, b = rnd.randrange(o.R_ORDER), o.R_ORDER - 1
+        sc = [a if rnd.randrange(2) else b for _ in range(n)]
+    ss = b"".join(o.fr_to_canon_bytes(x) for x in sc)
+    got = ctx.msm("g1", bases, ss, n, pkg.SCALAR_CANONICAL)
+    assert _canon(co, "g1", got) == co.dlog_expected("g1", ss, SEED_B + 4, n)
+    prof = ctx.profile()
+    if kind != "small64":
+        assert prof["max_items_per_bucket"] > 1  # the split/merge path really ran
+
+
 def test_g1_resident_bases_and_prefix(ctx, co, pkg):
     n = 4096
     bases = co.gen_bases("g1", SEED_B, n, 4)

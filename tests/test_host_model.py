@@ -1,0 +1,96 @@
+"""CPU-only check of the DEVICE arithmetic: ark-blst_amd/csrc/{fp28,ec}.cuh compile as plain C++ (g++), so the
+radix-2^28 lazy field and the XYZZ / complete-projective formulas are pinned against the oracle without a GPU."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def h28():
+    src = os.path.join(HERE, "host", "fp28_host_check.cpp")
+    so = os.path.join(HERE, "host", "libfp28_host.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    return C.CDLL(so)
+
+
+def test_bounds_checker():
+    subprocess.check_call(["python3", os.path.join(HERE, "..", "tools", "bounds_check.py")])
+
+
+def test_field_ops(h28, co, o):
+    rnd = random.Random(1)
+    n = 3000
+    va = [rnd.randrange(o.P) for _ in range(n)]
+    vb = [rnd.randrange(o.P) for _ in range(n)]
+    edge = [0, 1, o.P - 1, (o.P - 1) // 2, 2, o.P - 2]
+    va[:6] = edge
+    vb[:6] = edge[::-1]
+    a = b"".join(o.fp_to_mont_bytes(v) for v in va)
+    b = b"".join(o.fp_to_mont_bytes(v) for v in vb)
+    out = C.create_string_buffer(48 * n)
+    h28.h28_roundtrip(a, out, C.c_size_t(n))
+    assert out.raw == a
+    h28.h28_fp_mul(a, b, out, C.c_size_t(n), 0)
+    assert out.raw == co.fp_mul(a, b)
+    h28.h28_fp_mul(a, b, out, C.c_size_t(n), 1)
+    assert out.raw == co.fp_mul(a, a)
+    oa, os_ = C.create_string_buffer(48 * n), C.create_string_buffer(48 * n)
+    h28.h28_fp_addsub(a, b, oa, os_, C.c_size_t(n))
+    assert oa.raw == b"".join(o.fp_to_mont_bytes((x + y) % o.P) for x, y in zip(va, vb))
+    assert os_.raw == b"".join(o.fp_to_mont_bytes((x - y) % o.P) for x, y in zip(va, vb))
+    h28.h28_fp_mul_small(a, oa, os_, C.c_size_t(n))
+    assert oa.raw == b"".join(o.fp_to_mont_bytes(3 * x % o.P) for x in va)
+    assert os_.raw == b"".join(o.fp_to_mont_bytes(12 * x % o.P) for x in va)
+
+
+def _sum(o, pts):
+    acc = None
+    for p in pts:
+        acc = o.aff_add(o.F1, acc, p)
+    return acc
+
+
+def test_bucket_hot_and_cold_paths(h28, co, o):
+    rnd = random.Random(2)
+    m = 40
+    bases = co.gen_bases("g1", 7, m)
+    pts = [o.affine_from_bytes(o.F1, bases[96 * i:96 * i + 96]) for i in range(m)]
+    neg = bytes(rnd.randrange(2) for _ in range(m))
+    oj = C.create_string_buffer(144)
+    cold = C.c_int(0)
+    h28.h28_g1_bucket(bases, neg, C.c_size_t(m), oj, C.byref(cold))
+    want = _sum(o, [o.aff_neg(o.F1, p) if s else p for p, s in zip(pts, neg)])
+    assert cold.value == 0
+    assert co.to_affine("g1", oj.raw) == o.affine_to_bytes(o.F1, want)
+    # exceptional pairs: duplicate (doubling), opposite (cancellation), repeated after cancellation
+    P_, Q = pts[0], pts[1]
+    nP, nQ = o.aff_neg(o.F1, P_), o.aff_neg(o.F1, Q)
+    for seq in ([P_, P_], [P_, nP], [P_, Q, P_, P_, nQ, nP, nP, nP, Q, Q, Q], [P_, P_, P_, P_], [Q, P_, nP, nQ]):
+        sb = b"".join(o.affine_to_bytes(o.F1, x) for x in seq)
+        h28.h28_g1_bucket(sb, None, C.c_size_t(len(seq)), oj, C.byref(cold))
+        assert co.to_affine("g1", oj.raw) == o.affine_to_bytes(o.F1, _sum(o, seq)), seq
+    assert cold.value == 1
+
+
+def test_complete_addition_tree_and_doubling(h28, co, o):
+    m = 37
+    bases = co.gen_bases("g1", 9, m)
+    pts = [o.affine_from_bytes(o.F1, bases[96 * i:96 * i + 96]) for i in range(m)]
+    oj = C.create_string_buffer(144)
+    h28.h28_g1_add_tree(bases, C.c_size_t(m), oj)
+    assert co.to_affine("g1", oj.raw) == o.affine_to_bytes(o.F1, _sum(o, pts))
+    P_, Q = pts[0], pts[1]
+    seq = [P_, P_, P_, P_, None, None, Q, o.aff_neg(o.F1, Q), P_, o.aff_neg(o.F1, P_), Q, None]
+    sb = b"".join(o.affine_to_bytes(o.F1, x) for x in seq)
+    h28.h28_g1_add_tree(sb, C.c_size_t(len(seq)), oj)
+    assert co.to_affine("g1", oj.raw) == o.affine_to_bytes(o.F1, _sum(o, seq))
+    for k in (0, 1, 5, 9):
+        h28.h28_g1_dbl_n(o.affine_to_bytes(o.F1, P_), k, oj)
+        assert co.to_affine("g1", oj.raw) == o.affine_to_bytes(o.F1, o.scalar_mul(o.F1, P_, 1 << k))
+    h28.h28_g1_dbl_n(bytes(96), 3, oj)
+    assert oj.raw == bytes(144)

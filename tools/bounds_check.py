@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Static bound check of the lazily reduced device formulas (ark-blst_amd/csrc/ec.cuh).
+
+Every device field value is kept in N-form (14 limbs <= 2^28+15 after fp_norm1) and only its VALUE is lazy.
+This script replays each formula with value bounds (in units of p) and asserts the two preconditions:
+  mul(a, b):  a*b < 2^392 * p   (Montgomery reduction then returns < 2p)
+  sub<K>(a, b):  b <= (K-1) p   (the spread constant S_K dominates b limb-wise)
+Run:  python tools/bounds_check.py
+"""
+P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+LIM = (1 << 392) / P  # ~2521
+
+
+class V:
+    def __init__(self, v, name=""):
+        self.v = v
+        self.name = name
+
+
+def mul(a, b):
+    assert a.v * b.v < LIM, f"mul overflow: {a.v} * {b.v} >= {LIM:.0f}"
+    return V(2)
+
+
+def add(a, b):
+    r = V(a.v + b.v)
+    assert r.v < LIM
+    return r
+
+
+def sub(K, a, b):
+    assert b.v <= K - 1, f"sub<{K}>: subtrahend bound {b.v} > {K - 1}"
+    return V(a.v + K)
+
+
+def scale(k, a):
+    r = V(k * a.v)
+    assert r.v < LIM
+    return r
+
+
+def check_madd(X=10, Y=6, x2=4, y2=4):
+    """xyzz_madd state machine; returns output bounds."""
+    X, Y, ZZ, ZZZ, x2, y2 = V(X), V(Y), V(2), V(2), V(x2), V(y2)
+    t0 = sub(16, mul(x2, ZZ), X)      # P
+    t1 = sub(8, mul(y2, ZZZ), Y)      # R
+    t2 = mul(t0, t0)                  # PP
+    t0 = mul(t0, t2)                  # PPP
+    ZZ = mul(ZZ, t2)
+    t2 = mul(X, t2)                   # Q
+    ZZZ = mul(ZZZ, t0)
+    Y = mul(Y, t0)
+    t0 = add(add(t0, t2), t2)         # PPP + 2Q
+    X = sub(8, mul(t1, t1), t0)       # X3
+    t2 = sub(16, t2, X)               # Q - X3
+    Y = sub(4, mul(t1, t2), Y)        # Y3
+    assert X.v <= 10 and Y.v <= 6 and ZZ.v <= 2 and ZZZ.v <= 2, (X.v, Y.v)
+    return X.v, Y.v
+
+
+def check_mdbl(x=4, y=4):
+    x, y = V(x), V(y)
+    U = add(y, y)
+    Vv = mul(U, U)
+    W = mul(U, Vv)
+    S = mul(x, Vv)
+    xx = mul(x, x)
+    M = add(add(xx, xx), xx)
+    X3 = sub(8, mul(M, M), add(S, S))
+    v = sub(16, S, X3)
+    Y3 = sub(4, mul(M, v), mul(W, y))
+    assert X3.v <= 10 and Y3.v <= 6
+
+
+def check_xyzz_to_proj(X=10, Y=6):
+    X, Y, ZZ, ZZZ = V(X), V(Y), V(2), V(2)
+    return mul(X, ZZZ).v, mul(Y, ZZ).v, mul(ZZ, ZZZ).v
+
+
+def check_rcb_add(B=8):
+    """Renes-Costello-Batina 2016 Alg. 7 (a = 0, b3 = 12), scheduled as 12 multiplications."""
+    X1, Y1, Z1, X2, Y2, Z2 = (V(B) for _ in range(6))
+    t0 = mul(X1, X2)
+    t1 = mul(Y1, Y2)
+    t2 = mul(Z1, Z2)
+    t3 = mul(add(X1, Y1), add(X2, Y2))
+    t4 = mul(add(Y1, Z1), add(Y2, Z2))
+    t5 = mul(add(X1, Z1), add(X2, Z2))
+    t3 = sub(8, t3, add(t0, t1))
+    t4 = sub(8, t4, add(t1, t2))
+    t5 = sub(8, t5, add(t0, t2))
+    t0 = scale(3, t0)
+    t2 = scale(12, t2)
+    Z3 = add(t1, t2)
+    t1 = sub(32, t1, t2)
+    t5 = scale(12, t5)
+    X3 = mul(t4, t5)
+    t2 = mul(t3, t1)
+    Y3 = mul(t5, t0)
+    t1 = mul(t1, Z3)
+    t0 = mul(t0, t3)
+    Z3 = mul(Z3, t4)
+    X3 = sub(4, t2, X3)
+    Y3 = add(t1, Y3)
+    Z3 = add(Z3, t0)
+    assert max(X3.v, Y3.v, Z3.v) <= B, (X3.v, Y3.v, Z3.v)
+    return X3.v, Y3.v, Z3.v
+
+
+if __name__ == "__main__":
+    print("limit a*b <", LIM)
+    print("madd out bounds", check_madd())
+    check_mdbl()
+    print("xyzz->proj", check_xyzz_to_proj())
+    print("rcb add out bounds", check_rcb_add())
+    print("all bounds OK")
