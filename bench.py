@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — G1 MSM points/sec on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 20] [--group g1]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+              bench.py --gpus N --steps K --warmup W
+
+A "step" is one full MSM over one batch of 2^log_n synthetic (base, scalar) pairs PER GPU through the C ABI
+(mi_msm_g1_device): digit extraction, bucket sort, bucket accumulation, bucket reduction, host fold — nothing is
+cached between steps.  Inputs are resident in HBM when the timed region starts (bases as the resident SRS,
+scalars in a device buffer).  With N ranks the base set is N * 2^log_n points sharded contiguously (weak scaling,
+no data-path collective); each step ends with the RCCL all-gather of the N 144-byte partial sums and the
+deterministic fold on every rank.  The result of the last step is checked bit-exact (canonical affine bytes)
+against the closed form (sum s_i k_i) G.
+
+The oracle (oracle/) is used ONLY to generate the synthetic inputs, as the checker, and as the timed CPU baseline
+(`cpu_baseline`, kind "port": the reference's blst path cannot be built in this image).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED_B, SEED_S = 0xA55E7 + 2, 0x5CA1A5 + 2
+ALG_BYTES_PER_POINT = {"g1": 128, "g2": 224}   # base + scalar, each read once
+MADS_PER_POINT = {"g1": 48_000, "g2": 144_000} # SURVEY.md §8(d) canonical integer-op model
+HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8 TB/s spec
+MAD_PEAK_TLOPS = 39.3                          # 1024 SIMD x 64 lanes x 2.4 GHz / 4 cyc (v_mad_u64_u32 is half rate:
+                                               # tools/ubench_valu.hip measured 33.4 T/s incl. loop overhead)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=20, help="log2 of points PER GPU")
+    ap.add_argument("--group", default="g1", choices=["g1"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--window-bits", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch  # plumbing only: device buffers, synchronize, torch.distributed (RCCL)
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the MSM path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    from oracle import coracle as co   # input generation, checker, cpu_baseline only
+
+    pkg = ge.load_package()
+    g = args.group
+    n = 1 << args.log_n
+    ncpu = _host_threads()
+    aff = 96 if g == "g1" else 192
+
+    # ---- synthetic inputs (seeded): rank r owns global indices [r*n, (r+1)*n)
+    t0 = time.time()
+    seed_b, seed_s = SEED_B + 1000 * rank, SEED_S + 1000 * rank
+    bases = co.gen_bases(g, seed_b, n, ncpu)
+    scalars = co.gen_scalars(seed_s, n)
+    gen_s = time.time() - t0
+
+    ctx = pkg.Context([local_rank])
+    if args.window_bits:
+        ctx.set_window_bits(args.window_bits)
+    ctx.set_bases(g, bases, n)
+    d_scalars = torch.frombuffer(bytearray(scalars), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+
+    gather = [torch.empty(144, dtype=torch.uint8, device="cuda") for _ in range(world)] if world > 1 else None
+
+    def step() -> bytes:
+        part = ctx.msm_device(g, d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)
+        if world == 1:
+            return part
+        mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).cuda()
+        dist.all_gather(gather, mine)                       # RCCL over xGMI: N x 144 B
+        return pkg.g1_sum([t.cpu().numpy().tobytes() for t in gather])   # fold in rank order on every rank
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prof_acc = []
+    fence()
+    t0 = time.perf_counter()
+    result = b""
+    for _ in range(args.steps):
+        result = step()
+        prof_acc.append(ctx.profile())
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- parity: closed form over ALL ranks' inputs
+    expected_parts = []
+    mine_expected = co.dlog_expected(g, scalars, seed_b, n)          # affine bytes of this rank's shard
+    if world > 1:
+        buf = [torch.empty(aff, dtype=torch.uint8, device="cuda") for _ in range(world)]
+        dist.all_gather(buf, torch.frombuffer(bytearray(mine_expected), dtype=torch.uint8).cuda())
+        expected_parts = [t.cpu().numpy().tobytes() for t in buf]
+    else:
+        expected_parts = [mine_expected]
+    bit_exact = None
+    if rank == 0:
+        # lift each shard's expected affine point to Jacobian (x, y, 1) and add them up
+        jac = b"".join((e + _mont_one()) if e != bytes(aff) else bytes(aff + 48) for e in expected_parts)
+        want = co.to_affine(g, co.sum_jac(g, jac, world))
+        bit_exact = co.to_affine(g, result) == want
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        total_points = n * world
+        value = total_points / (elapsed / args.steps)
+        acc_ms = sum(p["accumulate_ms"] for p in prof_acc) / len(prof_acc)
+        p0 = prof_acc[-1]
+        alg_bytes = ALG_BYTES_PER_POINT[g] * n
+        achieved_gbs = alg_bytes / (acc_ms * 1e-3) / 1e9
+        out = {
+            "metric": "G1 MSM points/sec",
+            "value": value,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 (14 x 28-bit limbs, 64-bit MAD accumulation)",
+            "data": "synthetic",
+            "bit_exact": bit_exact,
+            "config": {"workload": f"G1 MSM, 2^{args.log_n} random bases+scalars per GPU, bases resident, scalars in HBM",
+                       "points_per_gpu": n, "total_points": total_points, "window_bits": p0["window_bits"],
+                       "num_windows": p0["num_windows"], "parallelism": f"base-set sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_accumulate_g1", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms},
+            "valu_roofline": {"model_mads_per_point": MADS_PER_POINT[g],
+                              "achieved_Tmad_s": MADS_PER_POINT[g] * n / (acc_ms * 1e-3) / 1e12,
+                              "peak_Tmad_s": MAD_PEAK_TLOPS,
+                              "frac": MADS_PER_POINT[g] * n / (acc_ms * 1e-3) / 1e12 / MAD_PEAK_TLOPS,
+                              "note": "integer VALU (v_mad_u64_u32) is the real bound of this path; HBM frac is low by construction"},
+            "phases_ms": {k: sum(p[k] for p in prof_acc) / len(prof_acc) for k in
+                          ("digits_ms", "scan_ms", "scatter_ms", "accumulate_ms", "reduce_ms", "d2h_ms", "host_fold_ms", "total_ms")},
+            "input_gen_s": gen_s,
+        }
+        if not args.no_cpu_baseline:
+            best = 1e30
+            runs = 3 if args.log_n <= 20 else 1
+            for _ in range(runs):
+                t0 = time.perf_counter()
+                cpu = co.msm(g, bases, scalars, n, 0, ncpu)
+                best = min(best, time.perf_counter() - t0)
+            assert co.to_affine(g, cpu) == co.dlog_expected(g, scalars, seed_b, n)
+            out["cpu_baseline"] = {"value": n / best, "unit": "points/s", "cores": ncpu, "kind": "port",
+                                   "sample": f"full workload of one GPU (2^{args.log_n} points), best of {runs} runs, "
+                                             "blst-style Pippenger restatement in portable C (oracle/msm_oracle.c), not blst assembly",
+                                   "seconds": best}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def _host_threads() -> int:
+    """Threads for the CPU legs: the cgroup CPU quota when there is one (a 1-GPU box is given ~16 cores of a
+    256-thread host), else the affinity mask."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return max(1, int(int(quota) / int(period)))
+    except Exception:
+        pass
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    return min(n, 16)
+
+
+def _mont_one() -> bytes:
+    """Montgomery form of 1 (R mod p), /root/reference/src/fp.rs:532 — Z coordinate of an affine point lifted to Jacobian."""
+    limbs = [0x760900000002FFFD, 0xEBF4000BC40C0002, 0x5F48985753C758BA, 0x77CE585370525745, 0x5C071A97A256EC6D, 0x15F65EC3FA80E493]
+    return b"".join(l.to_bytes(8, "little") for l in limbs)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,53 @@
+"""The N>1 path on CPU: world_size-2 `gloo` run of the exchange step bench.py uses (all-gather of the per-rank
+partial sums + deterministic fold in rank order via the C ABI's mi_g1_sum).  The per-rank partials come from the
+oracle here (no GPU); on the GPU box the same code path gathers the partials the HIP pipeline produced."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    import __graft_entry__ as ge
+    from oracle import coracle as co
+    pkg = ge.load_package()
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n = 300
+    seed_b, seed_s = 11 + 1000 * rank, 22 + 1000 * rank
+    bases = co.gen_bases("g1", seed_b, n, 1)
+    sc = co.gen_scalars(seed_s, n)
+    part = co.msm("g1", bases, sc, n, 0, 1)                      # stands in for the per-GPU HIP partial sum
+    mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
+    gather = [torch.empty(144, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(gather, mine)
+    total = pkg.g1_sum([t.numpy().tobytes() for t in gather])    # identical on every rank
+    # expected: closed form of every rank's shard, folded by the oracle
+    exp = torch.frombuffer(bytearray(co.dlog_expected("g1", sc, seed_b, n)), dtype=torch.uint8)
+    eg = [torch.empty(96, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(eg, exp)
+    one = bytes.fromhex("fdff02000000097602000cc40b00f4ebba58c7535798485f455752705358ce776dec56a2971a075c93e480fac35ef615")
+    want = co.sum_jac("g1", b"".join(t.numpy().tobytes() + one for t in eg), world)
+    assert co.to_affine("g1", total) == co.to_affine("g1", want), "fold mismatch"
+    chk = [None] * world
+    dist.all_gather_object(chk, total)
+    assert all(c == chk[0] for c in chk), "ranks disagree"
+    dist.barrier()
+    if rank == 0:
+        print("GLOO_FOLD_OK")
+""") % ROOT
+
+
+def test_two_rank_gloo_allgather_and_fold(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "GLOO_FOLD_OK" in out.stdout

@@ -1,0 +1,75 @@
+"""CPU tests (-m "not gpu"): the oracle against the reference's embedded known-answer constants and against the
+committed golden vectors; the C restatement against the independent Python big-int restatement."""
+import json
+import os
+import random
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(HERE, "golden", "msm_vectors.json")) as f:
+        return json.load(f)
+
+
+def test_python_oracle_selfcheck(o):
+    o.selfcheck()  # reference KATs: src/fp.rs:25-32,714-721; src/scalar.rs:476-481; src/g1.rs:42-51; src/g2.rs:45-63
+
+
+def test_c_oracle_selfcheck(co):
+    assert co.selfcheck() == 0
+
+
+def test_c_oracle_fp_and_fr_golden(co, golden):
+    a = bytes.fromhex("".join(v["a"] for v in golden["fp_mul"]))
+    b = bytes.fromhex("".join(v["b"] for v in golden["fp_mul"]))
+    assert co.fp_mul(a, b) == bytes.fromhex("".join(v["ab"] for v in golden["fp_mul"]))
+    canon = bytes.fromhex("".join(v["canon"] for v in golden["fr_mont"]))
+    mont = bytes.fromhex("".join(v["mont"] for v in golden["fr_mont"]))
+    assert co.fr_from_mont(mont) == canon       # Scalar::into_bigint, src/scalar.rs:503-505
+    assert co.fr_to_mont(canon) == mont
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_c_oracle_msm_golden(co, golden, group):
+    for case in golden[group]:
+        n = case["n"]
+        bases, sc, scm = bytes.fromhex(case["bases"]), bytes.fromhex(case["scalars"]), bytes.fromhex(case["scalars_mont"])
+        want = bytes.fromhex(case["expected_affine"])
+        assert co.to_affine(group, co.msm(group, bases, sc, n, 0, 1)) == want, case["name"]
+        assert co.to_affine(group, co.msm(group, bases, scm, n, 1, 3)) == want, case["name"]
+        assert co.to_affine(group, co.msm_naive(group, bases, sc, n)) == want, case["name"]
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_c_oracle_generators_match_python(co, o, group):
+    F, gen = (o.F1, o.G1_GEN) if group == "g1" else (o.F2, o.G2_GEN)
+    aff = 96 if group == "g1" else 192
+    n = 6
+    bases = co.gen_bases(group, 0xA55E7, n, 2)
+    for i in range(n):
+        k = o.gen_dlog(0xA55E7, i)
+        assert bases[aff * i:aff * (i + 1)] == o.affine_to_bytes(F, o.scalar_mul(F, gen, k))
+    assert co.gen_scalars(0x5CA1A5, 50) == b"".join(o.fr_to_canon_bytes(s) for s in o.rand_scalars(50, 0x5CA1A5))
+
+
+@pytest.mark.parametrize("group,n", [("g1", 1000), ("g1", 1 << 14), ("g2", 300)])
+def test_c_oracle_pippenger_vs_closed_form(co, group, n):
+    """Closed form (sum s_i k_i) G for known-discrete-log bases: independent of the Pippenger code."""
+    bases = co.gen_bases(group, 77, n, 8)
+    sc = co.gen_scalars(78, n)
+    assert co.to_affine(group, co.msm(group, bases, sc, n, 0, 8)) == co.dlog_expected(group, sc, 77, n)
+
+
+def test_c_oracle_fold_and_sum(co, o):
+    rnd = random.Random(3)
+    ks = [rnd.randrange(1, 1 << 40) for _ in range(5)]
+    wins = b"".join(o.jac_to_bytes(o.F1, o.scalar_mul(o.F1, o.G1_GEN, k)) for k in ks)
+    c = 13
+    want = o.scalar_mul(o.F1, o.G1_GEN, sum(k << (c * i) for i, k in enumerate(ks)) % o.R_ORDER)
+    assert co.to_affine("g1", co.fold_windows("g1", wins, 5, c)) == o.affine_to_bytes(o.F1, want)
+    want = o.scalar_mul(o.F1, o.G1_GEN, sum(ks) % o.R_ORDER)
+    assert co.to_affine("g1", co.sum_jac("g1", wins, 5)) == o.affine_to_bytes(o.F1, want)
