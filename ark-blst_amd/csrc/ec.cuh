@@ -32,6 +32,7 @@ struct FpOps {
     static FP_HD E zero() { return fp28::fp_zero(); }
     static FP_HD E one() { return fp28::fp_one(); }
     static FP_HD E mul(const E& a, const E& b) { return fp28::fp_mul_call(a, b); }
+    static FP_HD E sqr(const E& a) { return fp28::fp_sqr_call(a); }
     static FP_HD E add(const E& a, const E& b) { return fp28::fp_add(a, b); }
     template <int K>
     static FP_HD E sub(const E& a, const E& b) { return fp28::fp_sub<K>(a, b); }
@@ -122,7 +123,7 @@ template <class F>
 FP_HD bool xyzz_madd(Xyzz<F>& acc, const typename F::E& x2, const typename F::E& y2) {
     using E = typename F::E;
     E t0 = F::template sub<16>(F::mul(x2, acc.zz), acc.x);    // P = U2 - X1          < 18p
-    E t2 = F::mul(t0, t0);                                     // PP
+    E t2 = F::sqr(t0);                                         // PP
     if (F::is_zero_2p(t2)) return true;
     E t1 = F::template sub<8>(F::mul(y2, acc.zzz), acc.y);    // R = S2 - Y1          < 10p
     t0 = F::mul(t0, t2);                                       // PPP
@@ -131,7 +132,7 @@ FP_HD bool xyzz_madd(Xyzz<F>& acc, const typename F::E& x2, const typename F::E&
     acc.zzz = F::mul(acc.zzz, t0);                             // ZZZ3 = ZZZ1 PPP
     acc.y = F::mul(acc.y, t0);                                 // Y1 PPP
     t0 = F::add(F::add(t0, t2), t2);                           // PPP + 2Q             < 6p
-    acc.x = F::template sub<8>(F::mul(t1, t1), t0);            // X3 = R^2 - PPP - 2Q  < 10p
+    acc.x = F::template sub<8>(F::sqr(t1), t0);                // X3 = R^2 - PPP - 2Q  < 10p
     t2 = F::template sub<16>(t2, acc.x);                       // Q - X3               < 18p
     acc.y = F::template sub<4>(F::mul(t1, t2), acc.y);         // Y3 = R (Q - X3) - Y1 PPP  < 6p
     return false;

@@ -175,6 +175,13 @@ FP_HD Fp fp_sqr(const Fp& a) {
     return fp_mont_reduce(c);
 }
 
+// shared squaring instance (see fp_mul_call)
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __noinline__ Fp fp_sqr_call(Fp a) { return fp_sqr(a); }
+#else
+FP_HD Fp fp_sqr_call(const Fp& a) { return fp_sqr(a); }
+#endif
+
 // Exact carry propagation of an N-form value that fits 392 bits: limbs -> [0, 2^28), l[13] holds the rest.
 FP_HD void fp_carry_exact(Fp& r) {
     uint32_t carry = 0;

@@ -98,7 +98,7 @@ struct DevState {
     size_t g1_resident = 0;      // points resident on this device
     size_t g1_shard_lo = 0;      // global index of the first resident point
     // scratch
-    DevBuf raw, call_bases, scalars, hist, offsets, cursor, woff, meta, sorted, partial, item_k, item_n, pairs;
+    DevBuf raw, call_bases, scalars, hist, offsets, cursor, woff, meta, sched, sorted, partial, order, item_bucket, pairs;
     void* h_pairs = nullptr;
     size_t h_pairs_cap = 0;
     mi_profile prof{};
@@ -199,8 +199,26 @@ G1 run_g1(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_s
     hipLaunchKernelGGL(msmk::k_digits_hist, dim3(grid_n), dim3(256), 0, s, d_scalars, d_bases, (uint32_t)msmk::G1_PT_WORDS,
                        (uint32_t)n, fmt, pl.c, pl.nwin, (uint32_t*)d.hist.p);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 1], s));
-    hipLaunchKernelGGL(msmk::k_scan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, pl.logT,
-                       (uint32_t*)d.offsets.p, (uint32_t*)d.cursor.p, (uint32_t*)d.woff.p, (uint32_t*)d.meta.p);
+    // schedule: <= 256 blocks of 1024 lanes, each lane owning per_blk/1024 consecutive buckets
+    uint32_t per_blk = 4096;
+    while ((pl.nbuckets + per_blk - 1) / per_blk > 256) per_blk <<= 1;
+    uint32_t nblk = (uint32_t)((pl.nbuckets + per_blk - 1) / per_blk);
+    // upper bound on items: one per bucket plus one per T entries
+    size_t items_cap = pl.nbuckets + (((size_t)n * pl.nwin) >> pl.logT) + 1;
+    d.sched.ensure((size_t)(3 + msmk::SCHED_CLASSES) * nblk * 4);
+    d.order.ensure(items_cap * 4);
+    d.item_bucket.ensure(items_cap * 4);
+    uint32_t* blk_e = (uint32_t*)d.sched.p;
+    uint32_t* blk_i = blk_e + nblk;
+    uint32_t* blk_max = blk_i + nblk;
+    uint32_t* blk_cls = blk_max + nblk;
+    hipLaunchKernelGGL(msmk::k_sched1, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT,
+                       nblk, blk_e, blk_i, blk_cls, blk_max);
+    hipLaunchKernelGGL(msmk::k_sched2, dim3(1), dim3(1024), 0, s, nblk, blk_e, blk_i, blk_cls, (const uint32_t*)blk_max,
+                       (uint32_t*)d.meta.p);
+    hipLaunchKernelGGL(msmk::k_sched3, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT,
+                       nblk, (const uint32_t*)blk_e, (const uint32_t*)blk_i, (const uint32_t*)blk_cls, (uint32_t*)d.offsets.p,
+                       (uint32_t*)d.cursor.p, (uint32_t*)d.woff.p, (uint32_t*)d.order.p, (uint32_t*)d.item_bucket.p);
     // the item count sizes the next launches: one small read-back (the only mid-pipeline sync)
     uint32_t meta[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(meta, d.meta.p, 12, hipMemcpyDeviceToHost, s));
@@ -211,15 +229,13 @@ G1 run_g1(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_s
     HIP_TRY(hipStreamSynchronize(s));
     uint32_t nitems = meta[0], max_items = meta[1];
     d.partial.ensure((size_t)nitems * msmk::G1_BK_WORDS * 4);
-    d.item_k.ensure((size_t)nitems * 4);
-    d.item_n.ensure((size_t)nitems * 4);
     uint32_t grid_items = (nitems + 255) / 256;
     hipLaunchKernelGGL(msmk::k_accumulate_g1, dim3(grid_items), dim3(256), 0, s, d_bases, (const uint32_t*)d.sorted.p,
-                       (const uint32_t*)d.offsets.p, (const uint32_t*)d.woff.p, (uint32_t)pl.nbuckets, pl.logT, (uint32_t*)d.partial.p,
-                       (uint32_t*)d.item_k.p, (uint32_t*)d.item_n.p);
+                       (const uint32_t*)d.offsets.p, (const uint32_t*)d.woff.p, (const uint32_t*)d.order.p,
+                       (const uint32_t*)d.item_bucket.p, nitems, pl.logT, (uint32_t*)d.partial.p);
     for (uint32_t dd = 1; dd < max_items; dd <<= 1)
-        hipLaunchKernelGGL(msmk::k_merge_g1, dim3(grid_items), dim3(256), 0, s, (uint32_t*)d.partial.p, (const uint32_t*)d.item_k.p,
-                           (const uint32_t*)d.item_n.p, nitems, dd);
+        hipLaunchKernelGGL(msmk::k_merge_g1, dim3(grid_items), dim3(256), 0, s, (uint32_t*)d.partial.p, (const uint32_t*)d.item_bucket.p,
+                           (const uint32_t*)d.woff.p, nitems, dd);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 4], s));
     hipLaunchKernelGGL(msmk::k_reduce_g1, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
                        (const uint32_t*)d.woff.p, (uint32_t*)d.pairs.p, pl.logL);
@@ -402,8 +418,8 @@ void mi_msm_destroy(mi_ctx* ctx) {
     for (auto& d : ctx->devs) {
         (void)hipSetDevice(d.dev);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
-        for (DevBuf* b : {&d.g1_bases, &d.raw, &d.call_bases, &d.scalars, &d.hist, &d.offsets, &d.cursor, &d.woff, &d.meta, &d.sorted,
-                          &d.partial, &d.item_k, &d.item_n, &d.pairs})
+        for (DevBuf* b : {&d.g1_bases, &d.raw, &d.call_bases, &d.scalars, &d.hist, &d.offsets, &d.cursor, &d.woff, &d.meta, &d.sched, &d.sorted,
+                          &d.partial, &d.order, &d.item_bucket, &d.pairs})
             b->release();
         if (d.h_pairs) (void)hipHostFree(d.h_pairs);
         for (auto& e : d.ev)

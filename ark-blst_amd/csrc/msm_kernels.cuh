@@ -182,58 +182,151 @@ __global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ sc
     });
 }
 
-// Exclusive prefix sums over the `m` bucket counters by ONE workgroup of 1024 lanes (m <= a few 10^5; ~tens of us):
-//   offsets[m+1] / cursor[m] : entry offsets (scatter destinations)
-//   woff[m+1]                : WORK-ITEM offsets.  A bucket with cnt entries becomes max(1, ceil(cnt / T)) items of at
-//                              most T = 2^logT entries each, so a heavy bucket (skewed scalars, or the short top window)
-//                              is spread over many lanes instead of serialising one lane for its whole length.
-//   meta[0] = total items, meta[1] = max items of any bucket, meta[2] = total entries.
-__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ hist, uint32_t m, uint32_t logT,
-                                               uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
-                                               uint32_t* __restrict__ woff, uint32_t* __restrict__ meta) {
-    __shared__ uint32_t part_e[1024];
-    __shared__ uint32_t part_i[1024];
-    __shared__ uint32_t max_items;
-    uint32_t t = threadIdx.x;
-    if (t == 0) max_items = 1;
-    uint32_t per = (m + 1023) / 1024;
-    uint32_t lo = t * per, hi = lo + per < m ? lo + per : m;
-    uint32_t T1 = (1u << logT) - 1u;
-    uint32_t sum_e = 0, sum_i = 0, mx = 1;
+// ---------------------------------------------------------------------------------------------- scan / schedule
+// Three small launches turn the histogram into (a) entry offsets for the scatter, (b) WORK ITEMS and (c) a
+// length-sorted processing order for them:
+//   * a bucket with cnt entries becomes max(1, ceil(cnt / T)) items of at most T = 2^logT entries, so a heavy
+//     bucket (skewed scalars, or the short top window) is spread over many lanes instead of serialising one;
+//   * order[] lists item ids by DESCENDING length class (65 classes): the 64 lanes of a wave then run the same
+//     number of additions (bucket loads are Poisson distributed: unsorted, a wave waits for its longest lane,
+//     ~70 % lane efficiency at a mean of 32) and the longest items start first.
+// Layout: nblk <= 256 blocks of 1024 lanes; block k owns `per_blk` consecutive buckets, lane t owns
+// per_blk/1024 consecutive ones.  item id of (bucket b, chunk k) = woff[b] + k.
+constexpr int SCHED_CLASSES = 65;
+
+__device__ __forceinline__ uint32_t items_of(uint32_t cnt, uint32_t logT) {
+    return cnt == 0 ? 1u : (cnt + (1u << logT) - 1u) >> logT;
+}
+__device__ __forceinline__ uint32_t class_of(uint32_t len, uint32_t logT) { return (len << 6) >> logT; }  // 0..64
+
+__global__ void __launch_bounds__(1024) k_sched1(const uint32_t* __restrict__ hist, uint32_t m, uint32_t per_blk, uint32_t logT,
+                                                 uint32_t nblk, uint32_t* __restrict__ blk_e, uint32_t* __restrict__ blk_i,
+                                                 uint32_t* __restrict__ blk_cls, uint32_t* __restrict__ blk_max) {
+    __shared__ uint32_t cls[SCHED_CLASSES];
+    __shared__ uint32_t se, si, smax;
+    uint32_t t = threadIdx.x, blk = blockIdx.x;
+    if (t < SCHED_CLASSES) cls[t] = 0;
+    if (t == 0) { se = 0; si = 0; smax = 1; }
+    __syncthreads();
+    uint32_t per_t = per_blk >> 10;
+    uint32_t lo = blk * per_blk + t * per_t, hi = lo + per_t < m ? lo + per_t : m;
+    uint32_t sum_e = 0, sum_i = 0, mx = 1, T = 1u << logT;
     for (uint32_t k = lo; k < hi; k++) {
-        uint32_t h = hist[k];
-        uint32_t it = h == 0 ? 1u : (h + T1) >> logT;
+        uint32_t h = hist[k], it = items_of(h, logT);
         sum_e += h;
         sum_i += it;
         mx = it > mx ? it : mx;
+        if (it > 1) atomicAdd(&cls[64], it - 1);
+        atomicAdd(&cls[class_of(h - (it - 1) * T, logT)], 1u);
     }
-    part_e[t] = sum_e;
-    part_i[t] = sum_i;
+    atomicAdd(&se, sum_e);
+    atomicAdd(&si, sum_i);
+    atomicMax(&smax, mx);
     __syncthreads();
-    atomicMax(&max_items, mx);
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t ve = t >= d ? part_e[t - d] : 0, vi = t >= d ? part_i[t - d] : 0;
+    if (t < SCHED_CLASSES) blk_cls[t * nblk + blk] = cls[t];
+    if (t == 0) { blk_e[blk] = se; blk_i[blk] = si; blk_max[blk] = smax; }
+}
+
+// one workgroup: exclusive scans over the <= 256 block sums, and per (class, block) the base position in order[]
+__global__ void __launch_bounds__(1024) k_sched2(uint32_t nblk, uint32_t* __restrict__ blk_e, uint32_t* __restrict__ blk_i,
+                                                 uint32_t* __restrict__ blk_cls, const uint32_t* __restrict__ blk_max,
+                                                 uint32_t* __restrict__ meta) {
+    __shared__ uint32_t a[256], b[256], ctot[SCHED_CLASSES], cbase[SCHED_CLASSES];
+    uint32_t t = threadIdx.x;
+    uint32_t ve = 0, vi = 0;
+    if (t < 256) {
+        ve = t < nblk ? blk_e[t] : 0;
+        vi = t < nblk ? blk_i[t] : 0;
+        a[t] = ve;
+        b[t] = vi;
+    }
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        uint32_t xa = 0, xb = 0;
+        if (t < 256 && t >= d) { xa = a[t - d]; xb = b[t - d]; }
         __syncthreads();
-        part_e[t] += ve;
-        part_i[t] += vi;
+        if (t < 256) { a[t] += xa; b[t] += xb; }
         __syncthreads();
     }
-    uint32_t run_e = part_e[t] - sum_e, run_i = part_i[t] - sum_i;  // exclusive
+    if (t < nblk) { blk_e[t] = a[t] - ve; blk_i[t] = b[t] - vi; }
+    // class rows: wave w handles classes w, w+16, ...; exclusive scan of each row in chunks of 64 lanes
+    uint32_t wave = t >> 6, lane = t & 63;
+    for (uint32_t c = wave; c < SCHED_CLASSES; c += 16) {
+        uint32_t run = 0;
+        for (uint32_t base = 0; base < nblk; base += 64) {
+            uint32_t idx = base + lane;
+            uint32_t v = idx < nblk ? blk_cls[c * nblk + idx] : 0, incl = v;
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t u = __shfl_up(incl, d, 64);
+                if ((int)lane >= d) incl += u;
+            }
+            if (idx < nblk) blk_cls[c * nblk + idx] = run + incl - v;
+            run += __shfl(incl, 63, 64);
+        }
+        if (lane == 0) ctot[c] = run;
+    }
+    __syncthreads();
+    if (t < SCHED_CLASSES) {  // descending class order: class c starts after all longer classes
+        uint32_t above = 0;
+        for (uint32_t c = t + 1; c < SCHED_CLASSES; c++) above += ctot[c];
+        cbase[t] = above;
+    }
+    __syncthreads();
+    for (uint32_t idx = t; idx < SCHED_CLASSES * nblk; idx += 1024) blk_cls[idx] += cbase[idx / nblk];
+    if (t == 0) {
+        uint32_t mx = 1;
+        for (uint32_t k = 0; k < nblk; k++) mx = blk_max[k] > mx ? blk_max[k] : mx;
+        meta[0] = b[255];  // total items   (a[], b[] are inclusive scans; entries past nblk are zero)
+        meta[1] = mx;      // max items of any bucket
+        meta[2] = a[255];  // total entries
+    }
+}
+
+// per block: bucket-level exclusive scans -> offsets / cursor / woff; every item gets its slot in order[]
+__global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hist, uint32_t m, uint32_t per_blk, uint32_t logT,
+                                                 uint32_t nblk, const uint32_t* __restrict__ blk_e, const uint32_t* __restrict__ blk_i,
+                                                 const uint32_t* __restrict__ blk_cls, uint32_t* __restrict__ offsets,
+                                                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ woff,
+                                                 uint32_t* __restrict__ order, uint32_t* __restrict__ item_bucket) {
+    __shared__ uint32_t pe[1024], pi[1024], cur[SCHED_CLASSES];
+    uint32_t t = threadIdx.x, blk = blockIdx.x;
+    if (t < SCHED_CLASSES) cur[t] = blk_cls[t * nblk + blk];
+    uint32_t per_t = per_blk >> 10;
+    uint32_t lo = blk * per_blk + t * per_t, hi = lo + per_t < m ? lo + per_t : m;
+    uint32_t sum_e = 0, sum_i = 0, T = 1u << logT;
     for (uint32_t k = lo; k < hi; k++) {
         uint32_t h = hist[k];
+        sum_e += h;
+        sum_i += items_of(h, logT);
+    }
+    pe[t] = sum_e;
+    pi[t] = sum_i;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t xe = t >= d ? pe[t - d] : 0, xi = t >= d ? pi[t - d] : 0;
+        __syncthreads();
+        pe[t] += xe;
+        pi[t] += xi;
+        __syncthreads();
+    }
+    uint32_t run_e = blk_e[blk] + pe[t] - sum_e, run_i = blk_i[blk] + pi[t] - sum_i;
+    for (uint32_t k = lo; k < hi; k++) {
+        uint32_t h = hist[k], it = items_of(h, logT);
         offsets[k] = run_e;
         cursor[k] = run_e;
         woff[k] = run_i;
+        if (it > 1) {  // full-length chunks of a split bucket: one reservation in the longest class
+            uint32_t pos = atomicAdd(&cur[64], it - 1);
+            for (uint32_t j = 0; j + 1 < it; j++) { order[pos + j] = run_i + j; item_bucket[run_i + j] = k; }
+        }
+        uint32_t last = run_i + it - 1;
+        uint32_t pos = atomicAdd(&cur[class_of(h - (it - 1) * T, logT)], 1u);
+        order[pos] = last;
+        item_bucket[last] = k;
         run_e += h;
-        run_i += h == 0 ? 1u : (h + T1) >> logT;
+        run_i += it;
     }
-    if (t == 1023) {
-        offsets[m] = part_e[1023];
-        woff[m] = part_i[1023];
-        meta[0] = part_i[1023];
-        meta[1] = max_items;
-        meta[2] = part_e[1023];
-    }
+    if (blk == nblk - 1 && t == 1023) { offsets[m] = run_e; woff[m] = run_i; }
 }
 
 // ---------------------------------------------------------------------------------------------- accumulate
@@ -249,29 +342,18 @@ __device__ __forceinline__ void load_point(Fp& x, Fp& y, const uint32_t* bases, 
 // point is not staged in registers: its index is fetched one iteration ahead and its 128-byte line is touched
 // early so the real load hits L2; the other resident wave covers what latency is left.
 // A lane that meets an exceptional pair (same x) leaves the hot loop and finishes on the complete formulas.
-// Output: partial[i] (projective), item_k[i] = k, item_n[i] = items of the bucket (for the merge passes).
+// Output: partial[i] (projective), i = natural item id.
 __global__ void __launch_bounds__(256, 2) k_accumulate_g1(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                           const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ woff,
-                                                          uint32_t nbuckets, uint32_t logT, uint32_t* __restrict__ partial,
-                                                          uint32_t* __restrict__ item_k, uint32_t* __restrict__ item_n) {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    uint32_t nitems = woff[nbuckets];
-    if (i >= nitems) return;
-    // item -> bucket: identity when nothing before it was split, else binary search (largest b with woff[b] <= i)
-    uint32_t b = i < nbuckets ? i : nbuckets - 1;
-    if (!(woff[b] <= i && i < woff[b + 1])) {
-        uint32_t lo = 0, hi = b;  // woff[b] > i here is impossible to the right: items >= buckets, so woff[b] >= b
-        while (lo < hi) {
-            uint32_t mid = (lo + hi + 1) >> 1;
-            if (woff[mid] <= i) lo = mid; else hi = mid - 1;
-        }
-        b = lo;
-    }
+                                                          const uint32_t* __restrict__ order, const uint32_t* __restrict__ item_bucket,
+                                                          uint32_t nitems, uint32_t logT, uint32_t* __restrict__ partial) {
+    uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nitems) return;
+    uint32_t i = order[j];          // items are processed longest class first; partial[] keeps natural item order
+    uint32_t b = item_bucket[i];
     uint32_t k = i - woff[b];
     uint32_t e = offsets[b] + (k << logT), bend = offsets[b + 1];
     uint32_t end = e + (1u << logT) < bend ? e + (1u << logT) : bend;
-    item_k[i] = k;
-    item_n[i] = woff[b + 1] - woff[b];
     X1 acc;
     acc.x = fp28::fp_zero(); acc.y = fp28::fp_zero(); acc.zz = fp28::fp_zero(); acc.zzz = fp28::fp_zero();
     bool inf = true;
@@ -310,13 +392,14 @@ __global__ void __launch_bounds__(256, 2) k_accumulate_g1(const uint32_t* __rest
 // One binary-tree level of the per-bucket merge of split buckets: partial[i] += partial[i + d] for the items whose
 // chunk index is a multiple of 2d.  After ceil(log2(max items)) levels partial[woff[b]] is bucket b.  Launched only
 // when some bucket was split (meta[1] > 1).
-__global__ void __launch_bounds__(256, 2) k_merge_g1(uint32_t* __restrict__ partial, const uint32_t* __restrict__ item_k,
-                                                     const uint32_t* __restrict__ item_n, uint32_t nitems, uint32_t d) {
+__global__ void __launch_bounds__(256, 2) k_merge_g1(uint32_t* __restrict__ partial, const uint32_t* __restrict__ item_bucket,
+                                                     const uint32_t* __restrict__ woff, uint32_t nitems, uint32_t d) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nitems) return;
-    uint32_t n = item_n[i];
+    uint32_t b = item_bucket[i];
+    uint32_t n = woff[b + 1] - woff[b];
     if (n <= d) return;
-    uint32_t k = item_k[i];
+    uint32_t k = i - woff[b];
     if ((k & (2 * d - 1)) != 0 || k + d >= n) return;
     P1 a = load_bucket(partial + (size_t)i * G1_BK_WORDS);
     P1 c = load_bucket(partial + (size_t)(i + d) * G1_BK_WORDS);
