@@ -11,7 +11,9 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -19,6 +21,7 @@
 
 #include "../../include/arkblst_amd.h"
 #include "host_curve.hpp"
+#include "host_pool.hpp"
 #include "msm_kernels.cuh"
 
 namespace {
@@ -60,6 +63,7 @@ Plan make_plan(size_t n, unsigned forced_c) {
         }
     }
     best.nb = 1u << (best.c - 1);
+    // 8 buckets per lane, one reduce wave per SIMD: measured best of L in {2,4,8} x {1,2} waves/SIMD (tools/ab_reduce.sh)
     best.logL = std::min<uint32_t>(3, best.c - 7);
     best.chunks_per_win = best.nb >> (6 + best.logL);
     best.nbuckets = (uint64_t)best.nb * best.nwin;
@@ -108,6 +112,7 @@ struct DevState {
 
 struct mi_ctx {
     std::vector<DevState> devs;
+    std::unique_ptr<hostpool::Pool> pool;
     std::mutex mu;
     unsigned forced_c = 0;
     mi_profile prof{};
@@ -145,9 +150,9 @@ void ingest_g1(DevState& d, const void* bases, bool bases_on_device, size_t n, D
 }
 
 // Host tail: combine chunk sums per window and Horner-fold the windows (cf. /root/reference/src/gpu.rs:193-209).
-G1 host_fold_g1(const G1* pairs, const Plan& pl) {
+G1 host_fold_g1(mi_ctx* ctx, const G1* pairs, const Plan& pl) {
     std::vector<G1> win(pl.nwin);
-    auto do_window = [&](uint32_t w) {
+    auto do_window = [&](unsigned w) {
         const G1* p = pairs + (size_t)w * pl.chunks_per_win * 2;
         G1 run = G1::inf(), acc = G1::inf(), tsum = G1::inf();
         for (int j = (int)pl.chunks_per_win - 1; j >= 0; j--) {
@@ -160,17 +165,10 @@ G1 host_fold_g1(const G1* pairs, const Plan& pl) {
         win[w] = acc.dbl_n(6 + pl.logL).add(tsum);
     };
     size_t work = (size_t)pl.nwin * pl.chunks_per_win;
-    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    unsigned nt = work >= 256 ? std::min<unsigned>(hw, pl.nwin) : 1;
-    if (nt <= 1) {
-        for (uint32_t w = 0; w < pl.nwin; w++) do_window(w);
+    if (work >= 128 && ctx->pool && ctx->devs.size() == 1) {
+        ctx->pool->parallel_for(pl.nwin, do_window);
     } else {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; t++)
-            th.emplace_back([&, t] {
-                for (uint32_t w = t; w < pl.nwin; w += nt) do_window(w);
-            });
-        for (auto& x : th) x.join();
+        for (uint32_t w = 0; w < pl.nwin; w++) do_window(w);
     }
     G1 r = G1::inf();
     for (int w = (int)pl.nwin - 1; w >= 0; w--) r = r.dbl_n(pl.c).add(win[w]);
@@ -237,7 +235,7 @@ G1 run_g1(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_s
         hipLaunchKernelGGL(msmk::k_merge_g1, dim3(grid_items), dim3(256), 0, s, (uint32_t*)d.partial.p, (const uint32_t*)d.item_bucket.p,
                            (const uint32_t*)d.woff.p, nitems, dd);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 4], s));
-    hipLaunchKernelGGL(msmk::k_reduce_g1, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
+    hipLaunchKernelGGL(msmk::k_reduce_g1<1>, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
                        (const uint32_t*)d.woff.p, (uint32_t*)d.pairs.p, pl.logL);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 5], s));
     HIP_TRY(hipMemcpyAsync(d.h_pairs, d.pairs.p, pl.nchunks * 2 * 144, hipMemcpyDeviceToHost, s));
@@ -256,7 +254,7 @@ G1 run_g1(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_s
     d.prof.max_items_per_bucket = max_items;
 
     auto t0 = std::chrono::steady_clock::now();
-    G1 r = host_fold_g1(reinterpret_cast<const G1*>(d.h_pairs), pl);
+    G1 r = host_fold_g1(ctx, reinterpret_cast<const G1*>(d.h_pairs), pl);
     d.prof.host_fold_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return r;
 }
@@ -403,6 +401,8 @@ int mi_msm_init(mi_ctx** out, const int* device_ids, int n_devices) {
             HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
             for (auto& e : d.ev) HIP_TRY(hipEventCreate(&e));
         }
+        unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        ctx->pool.reset(new hostpool::Pool(std::min(hw, 16u) - 1));
         return MI_OK;
     });
     if (rc != MI_OK) {

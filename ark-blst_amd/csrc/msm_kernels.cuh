@@ -439,7 +439,8 @@ __device__ __forceinline__ void store_jac_blst(uint32_t* out, const P1& p) {
 // One wave per chunk of 64*L consecutive buckets of one window (L = 2^logL).  Lane l owns buckets
 // [l*L, l*L+L) of the chunk.  Output per chunk: S = sum B, T = sum (rel+1) B with rel = index inside the chunk,
 // as two blst_p1 (36 words each).  All additions are the complete projective formulas: no exceptional cases.
-__global__ void __launch_bounds__(64) k_reduce_g1(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ woff,
+template <int WPS>
+__global__ void __launch_bounds__(64, WPS) k_reduce_g1(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ woff,
                                                   uint32_t* __restrict__ pairs, uint32_t logL) {
     uint32_t chunk = blockIdx.x, lane = threadIdx.x;
     uint32_t L = 1u << logL;
