@@ -42,7 +42,7 @@ struct HipFail {
     } while (0)
 
 struct Plan {
-    uint32_t c, nwin, nb, logL, chunks_per_win, logT;
+    uint32_t c, nwin, nb, logL, chunks_per_win, logT, lo_bits;
     uint64_t nbuckets, nchunks;
 };
 
@@ -51,8 +51,14 @@ struct Plan {
 Plan make_plan(size_t n, unsigned forced_c) {
     Plan best{};
     double best_cost = 1e300;
+    uint32_t idx_bits = 1;
+    while ((1ull << idx_bits) < n) idx_bits++;
     for (unsigned c = 7; c <= 22; c++) {
         if (forced_c && c != forced_c) continue;
+        // sort geometry: lo bits share a 32-bit entry with the point index and the sign; the coarse bins of one
+        // window must fit the LDS counter array
+        uint32_t lo_bits = std::min<uint32_t>(std::min<uint32_t>(8, c - 1), 31 - idx_bits);
+        if (((1u << (c - 1)) >> lo_bits) > msmk::SORT_MAX_COUNTERS) continue;
         uint32_t nwin = (256 + c - 1) / c;
         double nb = (double)(1u << (c - 1));
         double cost = (double)n * nwin + 6.0 * nb * nwin;
@@ -60,6 +66,7 @@ Plan make_plan(size_t n, unsigned forced_c) {
             best_cost = cost;
             best.c = c;
             best.nwin = nwin;
+            best.lo_bits = lo_bits;
         }
     }
     best.nb = 1u << (best.c - 1);
@@ -103,6 +110,7 @@ struct DevState {
     size_t g1_shard_lo = 0;      // global index of the first resident point
     // scratch
     DevBuf raw, call_bases, scalars, hist, offsets, cursor, woff, meta, sched, sorted, partial, order, item_bucket, pairs;
+    DevBuf tilecnt, bin_tot, bin_base, coarse;
     void* h_pairs = nullptr;
     size_t h_pairs_cap = 0;
     mi_profile prof{};
@@ -178,6 +186,7 @@ G1 host_fold_g1(mi_ctx* ctx, const G1* pairs, const Plan& pl) {
 // The pipeline on one device.  d_bases: device-form points for indices [0, n); d_scalars: n x 32 B on device.
 G1 run_g1(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, unsigned fmt, int ev0) {
     Plan pl = make_plan(n, ctx->forced_c);
+    if (pl.c == 0) throw HipFail{"window_bits not usable for this n (sort geometry)"};
     d.prof.window_bits = pl.c;
     d.prof.num_windows = pl.nwin;
     d.prof.n = n;
@@ -191,12 +200,33 @@ G1 run_g1(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_s
     ensure_host(d, pl.nchunks * 2 * 144 + 16);
 
     hipStream_t s = d.stream;
-    uint32_t grid_n = (uint32_t)((n + 255) / 256);
     HIP_TRY(hipEventRecord(d.ev[ev0], s));
-    HIP_TRY(hipMemsetAsync(d.hist.p, 0, pl.nbuckets * 4, s));
-    hipLaunchKernelGGL(msmk::k_digits_hist, dim3(grid_n), dim3(256), 0, s, d_scalars, d_bases, (uint32_t)msmk::G1_PT_WORDS,
-                       (uint32_t)n, fmt, pl.c, pl.nwin, (uint32_t*)d.hist.p);
+    // ---- two-level LDS-staged bucket sort (geometry in msmk::SortGeom)
+    msmk::SortGeom g{};
+    g.n = (uint32_t)n; g.fmt = fmt; g.c = pl.c; g.nwin = pl.nwin; g.pt_words = msmk::G1_PT_WORDS;
+    g.lo_bits = pl.lo_bits;
+    g.H = pl.nb >> g.lo_bits;
+    g.tiles = (uint32_t)std::min<size_t>(512, std::max<size_t>(1, n / 4096));
+    g.tile_pts = (uint32_t)(((n + g.tiles - 1) / g.tiles + 255) / 256 * 256);
+    g.tiles = (uint32_t)((n + g.tile_pts - 1) / g.tile_pts);
+    g.wgroup = std::max<uint32_t>(1, std::min<uint32_t>(pl.nwin, msmk::SORT_MAX_COUNTERS / g.H));
+    g.ngroups = (pl.nwin + g.wgroup - 1) / g.wgroup;
+    g.nbins = pl.nwin * g.H;
+    d.tilecnt.ensure((size_t)g.tiles * g.nbins * 4);
+    d.bin_tot.ensure((size_t)g.nbins * 4);
+    d.bin_base.ensure((size_t)(g.nbins + 1) * 4);
+    d.coarse.ensure((size_t)n * pl.nwin * 4);
+    hipLaunchKernelGGL(msmk::k_coarse<false>, dim3(g.tiles, g.ngroups), dim3(256), 0, s, d_scalars, d_bases, g, (uint32_t*)d.tilecnt.p,
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(msmk::k_colscan, dim3((g.nbins + 255) / 256), dim3(256), 0, s, (uint32_t*)d.tilecnt.p, g.nbins, g.tiles,
+                       (uint32_t*)d.bin_tot.p);
+    hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.bin_tot.p, g.nbins, (uint32_t*)d.bin_base.p);
+    hipLaunchKernelGGL(msmk::k_coarse<true>, dim3(g.tiles, g.ngroups), dim3(256), 0, s, d_scalars, d_bases, g, (uint32_t*)d.tilecnt.p,
+                       (const uint32_t*)d.bin_base.p, (uint32_t*)d.coarse.p);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 1], s));
+    hipLaunchKernelGGL(msmk::k_fine_sort, dim3(g.nbins), dim3(256), 0, s, (const uint32_t*)d.coarse.p, (const uint32_t*)d.bin_base.p, g,
+                       (uint32_t*)d.sorted.p, (uint32_t*)d.hist.p);
+    HIP_TRY(hipEventRecord(d.ev[ev0 + 2], s));
     // schedule: <= 256 blocks of 1024 lanes, each lane owning per_blk/1024 consecutive buckets
     uint32_t per_blk = 4096;
     while ((pl.nbuckets + per_blk - 1) / per_blk > 256) per_blk <<= 1;
@@ -220,9 +250,6 @@ G1 run_g1(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_s
     // the item count sizes the next launches: one small read-back (the only mid-pipeline sync)
     uint32_t meta[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(meta, d.meta.p, 12, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(d.ev[ev0 + 2], s));
-    hipLaunchKernelGGL(msmk::k_scatter, dim3(grid_n), dim3(256), 0, s, d_scalars, d_bases, (uint32_t)msmk::G1_PT_WORDS, (uint32_t)n,
-                       fmt, pl.c, pl.nwin, (uint32_t*)d.cursor.p, (uint32_t*)d.sorted.p);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 3], s));
     HIP_TRY(hipStreamSynchronize(s));
     uint32_t nitems = meta[0], max_items = meta[1];
@@ -243,9 +270,9 @@ G1 run_g1(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_s
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipGetLastError());
 
-    d.prof.digits_ms = ev_ms(d.ev[ev0], d.ev[ev0 + 1]);
-    d.prof.scan_ms = ev_ms(d.ev[ev0 + 1], d.ev[ev0 + 2]);
-    d.prof.scatter_ms = ev_ms(d.ev[ev0 + 2], d.ev[ev0 + 3]);
+    d.prof.digits_ms = ev_ms(d.ev[ev0], d.ev[ev0 + 1]);      // digits + coarse partition (4 kernels)
+    d.prof.scatter_ms = ev_ms(d.ev[ev0 + 1], d.ev[ev0 + 2]);  // fine sort in LDS
+    d.prof.scan_ms = ev_ms(d.ev[ev0 + 2], d.ev[ev0 + 3]);     // schedule (3 kernels)
     d.prof.accumulate_ms = ev_ms(d.ev[ev0 + 3], d.ev[ev0 + 4]);
     d.prof.reduce_ms = ev_ms(d.ev[ev0 + 4], d.ev[ev0 + 5]);
     d.prof.d2h_ms = ev_ms(d.ev[ev0 + 5], d.ev[ev0 + 6]);
@@ -419,7 +446,7 @@ void mi_msm_destroy(mi_ctx* ctx) {
         (void)hipSetDevice(d.dev);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         for (DevBuf* b : {&d.g1_bases, &d.raw, &d.call_bases, &d.scalars, &d.hist, &d.offsets, &d.cursor, &d.woff, &d.meta, &d.sched, &d.sorted,
-                          &d.partial, &d.order, &d.item_bucket, &d.pairs})
+                          &d.partial, &d.order, &d.item_bucket, &d.pairs, &d.tilecnt, &d.bin_tot, &d.bin_base, &d.coarse})
             b->release();
         if (d.h_pairs) (void)hipHostFree(d.h_pairs);
         for (auto& e : d.ev)

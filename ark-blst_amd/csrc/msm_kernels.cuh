@@ -6,9 +6,9 @@
 // host-side fold of ~32k partials at gpu.rs:193-209) with a sort-based pipeline:
 //
 //   k_ingest      bases: blst_p1_affine (96 B, R = 2^384)  ->  device form (2 x 14 x 28-bit limbs, R' = 2^392)
-//   k_digits_hist scalars -> signed c-bit digits (NEGATION_IS_CHEAP, src/g1.rs:595), per-(window,bucket) histogram
-//   k_scan        exclusive prefix sums of the histogram -> bucket offsets + work-item offsets (heavy buckets split)
-//   k_scatter     (point index | sign) scattered into bucket order
+//   k_coarse<0/1>, k_colscan, k_binscan, k_fine_sort: scalars -> signed c-bit digits (NEGATION_IS_CHEAP,
+//                 src/g1.rs:595) -> two-level LDS-staged bucket sort -> sorted (index|sign) entries + histogram
+//   k_sched1-3    prefix sums of the histogram -> bucket offsets, work items (heavy buckets split), length-sorted order
 //   k_accumulate  one lane per work item (bucket, chunk<=T): XYZZ mixed additions over its run   <- dominant kernel
 //                 (exceptional pairs finish on the complete projective formulas); bucket stored projective
 //   k_merge       (only if a bucket was split) binary-tree merge of a bucket's partial sums
@@ -154,32 +154,133 @@ __device__ __forceinline__ void for_each_digit(const uint32_t (&s)[8], uint32_t 
     }
 }
 
-// pt_flags: word 31 of each device point (1 = infinity base: contributes nothing)
-__global__ void __launch_bounds__(256) k_digits_hist(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ bases,
-                                                     uint32_t pt_words, uint32_t n, unsigned fmt, uint32_t c, uint32_t nwin,
-                                                     uint32_t* __restrict__ hist) {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    if (bases[(size_t)i * pt_words + pt_words - 1] != 0) return;
-    uint32_t s[8];
-    load_scalar(s, scalars, i, fmt);
-    uint32_t nb = 1u << (c - 1);
-    for_each_digit(s, c, nwin, [&](uint32_t w, uint32_t b, bool) { atomicAdd(&hist[w * nb + b], 1u); });
+// ---------------------------------------------------------------------------------------------- bucket sort
+// Two-level sort of the N*W (window, bucket) keys, staged through LDS — replaces one global atomic per key in the
+// histogram pass and one returning global atomic + 4-byte scatter per key in the scatter pass.
+//   bucket id = (hi, lo): lo = low `lo_bits` (<= 8) bits -> F = 2^lo_bits fine buckets, H = 2^(c-1) / F coarse bins
+//   level 1 (global, coarse):  k_coarse_count   per tile of points: LDS histogram over (window, hi)  -> tilecnt[tile][bin]
+//                              k_colscan        per bin: exclusive scan over tiles, bin totals
+//                              k_binscan        exclusive scan of the bin totals                     -> bin_base[bin]
+//                              k_coarse_scatter per tile: LDS cursors seeded with the scanned bases; entries
+//                                               (index | sign | lo) land in their coarse bin of `coarse`
+//   level 2 (LDS, fine):       k_fine_sort      one workgroup per coarse bin: LDS histogram of lo, scan, scatter
+//                                               -> sorted[] in (window, bucket) order and hist[window][bucket]
+// Windows are processed in groups of `wgroup` so that wgroup * H counters fit LDS (<= 8192 counters, 32 KB).
+struct SortGeom {
+    uint32_t n, fmt, c, nwin, pt_words;
+    uint32_t lo_bits, H;          // fine bits, coarse bins per window
+    uint32_t tiles, tile_pts;     // point tiles (grid.x) and points per tile (multiple of 256)
+    uint32_t wgroup, ngroups;     // windows per group, groups (grid.y)
+    uint32_t nbins;               // nwin * H
+};
+constexpr uint32_t SORT_MAX_COUNTERS = 8192;
+
+// entry in `coarse`: (point index << (lo_bits+1)) | (negative << lo_bits) | lo
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) k_coarse(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ bases, SortGeom g,
+                                                uint32_t* __restrict__ tilecnt, const uint32_t* __restrict__ bin_base,
+                                                uint32_t* __restrict__ coarse) {
+    __shared__ uint32_t cnt[SORT_MAX_COUNTERS];
+    uint32_t tile = blockIdx.x, grp = blockIdx.y, t = threadIdx.x;
+    uint32_t w0 = grp * g.wgroup, w1 = w0 + g.wgroup < g.nwin ? w0 + g.wgroup : g.nwin;
+    uint32_t ncnt = (w1 - w0) * g.H;
+    for (uint32_t k = t; k < ncnt; k += 256) {
+        if (SCATTER) {
+            uint32_t bin = w0 * g.H + k;
+            cnt[k] = bin_base[bin] + tilecnt[(size_t)tile * g.nbins + bin];  // where this tile's run of the bin starts
+        } else {
+            cnt[k] = 0;
+        }
+    }
+    __syncthreads();
+    uint32_t lo_mask = (1u << g.lo_bits) - 1u;
+    uint32_t p0 = tile * g.tile_pts, p1 = p0 + g.tile_pts < g.n ? p0 + g.tile_pts : g.n;
+    for (uint32_t i = p0 + t; i < p1; i += 256) {
+        if (bases[(size_t)i * g.pt_words + g.pt_words - 1] != 0) continue;  // infinity base
+        uint32_t s[8];
+        load_scalar(s, scalars, i, g.fmt);
+        for_each_digit(s, g.c, w1, [&](uint32_t w, uint32_t b, bool neg) {
+            if (w < w0) return;
+            uint32_t k = (w - w0) * g.H + (b >> g.lo_bits);
+            uint32_t pos = atomicAdd(&cnt[k], 1u);
+            if (SCATTER) coarse[pos] = (i << (g.lo_bits + 1)) | ((neg ? 1u : 0u) << g.lo_bits) | (b & lo_mask);
+        });
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t k = t; k < ncnt; k += 256) tilecnt[(size_t)tile * g.nbins + w0 * g.H + k] = cnt[k];
+    }
 }
 
-__global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ bases,
-                                                 uint32_t pt_words, uint32_t n, unsigned fmt, uint32_t c, uint32_t nwin,
-                                                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    if (bases[(size_t)i * pt_words + pt_words - 1] != 0) return;
-    uint32_t s[8];
-    load_scalar(s, scalars, i, fmt);
-    uint32_t nb = 1u << (c - 1);
-    for_each_digit(s, c, nwin, [&](uint32_t w, uint32_t b, bool neg) {
-        uint32_t pos = atomicAdd(&cursor[w * nb + b], 1u);
-        sorted[pos] = i | (neg ? 0x80000000u : 0u);
-    });
+// per bin: exclusive scan over the tiles (in place) and the bin total.  One lane per bin: coalesced across bins.
+__global__ void __launch_bounds__(256) k_colscan(uint32_t* __restrict__ tilecnt, uint32_t nbins, uint32_t tiles,
+                                                 uint32_t* __restrict__ bin_tot) {
+    uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nbins) return;
+    uint32_t run = 0;
+    for (uint32_t k = 0; k < tiles; k++) {
+        uint32_t v = tilecnt[(size_t)k * nbins + b];
+        tilecnt[(size_t)k * nbins + b] = run;
+        run += v;
+    }
+    bin_tot[b] = run;
+}
+
+// exclusive scan of m <= ~100k values by one workgroup; out[m] = total
+__global__ void __launch_bounds__(1024) k_binscan(const uint32_t* __restrict__ in, uint32_t m, uint32_t* __restrict__ out) {
+    __shared__ uint32_t part[1024];
+    uint32_t t = threadIdx.x;
+    uint32_t per = (m + 1023) / 1024;
+    uint32_t lo = t * per, hi = lo + per < m ? lo + per : m;
+    uint32_t sum = 0;
+    for (uint32_t k = lo; k < hi; k++) sum += in[k];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (uint32_t k = lo; k < hi; k++) {
+        uint32_t v = in[k];
+        out[k] = run;
+        run += v;
+    }
+    if (t == 1023) out[m] = part[1023];
+}
+
+// one workgroup per coarse bin: sort its entries by lo in LDS-counter space, emit sorted[] and the bucket histogram
+__global__ void __launch_bounds__(256) k_fine_sort(const uint32_t* __restrict__ coarse, const uint32_t* __restrict__ bin_base,
+                                                   SortGeom g, uint32_t* __restrict__ sorted, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t cnt[256], scan[256];
+    uint32_t bin = blockIdx.x, t = threadIdx.x;
+    uint32_t beg = bin_base[bin], end = bin_base[bin + 1];
+    uint32_t F = 1u << g.lo_bits, lo_mask = F - 1u;
+    cnt[t] = 0;
+    __syncthreads();
+    for (uint32_t i = beg + t; i < end; i += 256) atomicAdd(&cnt[coarse[i] & lo_mask], 1u);
+    __syncthreads();
+    uint32_t own = cnt[t];
+    scan[t] = own;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        uint32_t v = t >= d ? scan[t - d] : 0;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    if (t < F) hist[(size_t)bin * F + t] = own;      // bucket (window, hi, lo) has index bin * F + lo
+    __syncthreads();
+    cnt[t] = beg + scan[t] - own;                    // cursor: start of this fine bucket in sorted[]
+    __syncthreads();
+    uint32_t sh = g.lo_bits + 1;
+    for (uint32_t i = beg + t; i < end; i += 256) {
+        uint32_t e = coarse[i];
+        uint32_t pos = atomicAdd(&cnt[e & lo_mask], 1u);
+        sorted[pos] = (e >> sh) | (((e >> g.lo_bits) & 1u) << 31);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- scan / schedule
