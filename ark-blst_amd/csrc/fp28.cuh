@@ -149,6 +149,25 @@ FP_HD Fp fp_mul(const Fp& a, const Fp& b) {
     return fp_mont_reduce(c);
 }
 
+// r = (a*b + c*d) / 2^392 mod p with ONE Montgomery reduction (the two products share the 64-bit columns:
+// 28 + 14 terms of < 2^56 stay below 2^62).  Needs a*b + c*d < 2^392 p.  Saves a 210-MAD reduction per use.
+FP_HD Fp fp_mul2add(const Fp& a, const Fp& b, const Fp& c2, const Fp& d) {
+    uint64_t c[2 * NL];
+#pragma unroll
+    for (int k = 0; k < 2 * NL; k++) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+#pragma unroll
+        for (int j = 0; j < NL; j++) c[i + j] += (uint64_t)a.l[i] * b.l[j];
+    }
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+#pragma unroll
+        for (int j = 0; j < NL; j++) c[i + j] += (uint64_t)c2.l[i] * d.l[j];
+    }
+    return fp_mont_reduce(c);
+}
+
 // The shared multiplier instance.  On the device this is a REAL function (by-value args travel in v0..v27, the
 // result in v0..v13): one ~4.5 KB body per kernel instead of one per use keeps bucket kernels inside the
 // 64 KB instruction cache (see ec.cuh).  On the host it is plain inline code.

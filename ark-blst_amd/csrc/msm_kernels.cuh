@@ -47,6 +47,7 @@ __device__ __forceinline__ void store_fp16(uint32_t* p, const Fp& r, uint32_t w1
 }
 
 using F1 = ec::FpOps;
+using ACC_F = ec::FpOpsInline;  // accumulate hot loop: multiplier inlined (see ec.cuh)
 using X1 = ec::Xyzz<F1>;
 using P1 = ec::Proj<F1>;
 
@@ -471,7 +472,7 @@ __global__ void __launch_bounds__(256, 2) k_accumulate_g1(const uint32_t* __rest
         if (inf) {
             acc.x = x; acc.y = y; acc.zz = fp28::fp_one(); acc.zzz = fp28::fp_one();
             inf = false;
-        } else if (ec::xyzz_madd<F1>(acc, x, y)) {
+        } else if (ec::xyzz_madd<ACC_F>(reinterpret_cast<ec::Xyzz<ACC_F>&>(acc), x, y)) {
             break;  // exceptional pair at entry e: acc untouched
         }
         e++;

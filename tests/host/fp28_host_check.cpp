@@ -6,7 +6,8 @@
 
 using namespace fp28;
 using F = ec::FpOps;
-using X = ec::Xyzz<F>;
+using FI = ec::FpOpsInline;  // the accumulate hot loop's field (inlined multiplier, mul2add)
+using X = ec::Xyzz<FI>;
 using Pj = ec::Proj<F>;
 
 static Fp load_blst(const uint8_t* p) {
@@ -74,10 +75,10 @@ void h28_g1_bucket(const uint8_t* bases, const uint8_t* neg, size_t n, uint8_t* 
         Fp x = load_blst(p), y = load_blst(p + 48);
         if (neg && neg[e]) y = fp_neg<4>(y);
         if (inf) { acc.x = x; acc.y = y; acc.zz = fp_one(); acc.zzz = fp_one(); inf = false; }
-        else if (ec::xyzz_madd<F>(acc, x, y)) break;
+        else if (ec::xyzz_madd<FI>(acc, x, y)) break;
     }
     Pj o = ec::proj_inf<F>();
-    if (!inf) o = ec::xyzz_to_proj<F>(acc);
+    if (!inf) { ec::Xyzz<F> a2; a2.x = acc.x; a2.y = acc.y; a2.zz = acc.zz; a2.zzz = acc.zzz; o = ec::xyzz_to_proj<F>(a2); }
     *took_cold = e < n;
     for (; e < n; e++) {
         const uint8_t* p = bases + 96 * e;

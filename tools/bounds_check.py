@@ -22,6 +22,11 @@ def mul(a, b):
     return V(2)
 
 
+def mul2add(a, b, c, d):
+    assert a.v * b.v + c.v * d.v < LIM, f"mul2add overflow: {a.v}*{b.v} + {c.v}*{d.v}"
+    return V(2)
+
+
 def add(a, b):
     r = V(a.v + b.v)
     assert r.v < LIM
@@ -49,11 +54,11 @@ def check_madd(X=10, Y=6, x2=4, y2=4):
     ZZ = mul(ZZ, t2)
     t2 = mul(X, t2)                   # Q
     ZZZ = mul(ZZZ, t0)
-    Y = mul(Y, t0)
-    t0 = add(add(t0, t2), t2)         # PPP + 2Q
-    X = sub(8, mul(t1, t1), t0)       # X3
+    ny = sub(8, V(0), Y)              # 8p - Y1
+    t3 = add(add(t0, t2), t2)         # PPP + 2Q
+    X = sub(8, mul(t1, t1), t3)       # X3
     t2 = sub(16, t2, X)               # Q - X3
-    Y = sub(4, mul(t1, t2), Y)        # Y3
+    Y = mul2add(t1, t2, ny, t0)       # Y3 = R (Q - X3) + (8p - Y1) PPP
     assert X.v <= 10 and Y.v <= 6 and ZZ.v <= 2 and ZZZ.v <= 2, (X.v, Y.v)
     return X.v, Y.v
 
