@@ -51,6 +51,15 @@ using ACC_F = ec::FpOpsInline;  // accumulate hot loop: multiplier inlined (see 
 using X1 = ec::Xyzz<F1>;
 using P1 = ec::Proj<F1>;
 
+// Complete addition as ONE out-of-line body with the twelve multiplications inlined inside it (~55 KB): the reduce /
+// merge / cold paths call it from several sites; their additions are latency-bound (few waves), so the per-call
+// register shuffling of the shared multiplier (~16 %) is worth removing here too.
+__device__ __noinline__ void g1_add_inplace(P1& a, const P1& b) {
+    ec::Proj<ec::FpOpsInline>& ai = reinterpret_cast<ec::Proj<ec::FpOpsInline>&>(a);
+    const ec::Proj<ec::FpOpsInline>& bi = reinterpret_cast<const ec::Proj<ec::FpOpsInline>&>(b);
+    ec::proj_add<ec::FpOpsInline>(ai, bi);
+}
+
 __device__ __forceinline__ P1 load_bucket(const uint32_t* p) {
     P1 r;
     load_fp16(r.x, p); load_fp16(r.y, p + 16); load_fp16(r.z, p + 32);
@@ -551,26 +560,26 @@ __global__ void __launch_bounds__(64, WPS) k_reduce_g1(const uint32_t* __restric
 #pragma unroll 1
     for (int t = (int)L - 1; t >= 0; t--) {
         P1 B = load_bucket(partial + (size_t)wp[t] * G1_BK_WORDS);
-        ec::proj_add<F1>(run, B);
-        ec::proj_add<F1>(acc, run);
+        g1_add_inplace(run, B);
+        g1_add_inplace(acc, run);
     }
     // suffix scan of the lane sums: P_l = sum_{j >= l} S_j
 #pragma unroll 1
     for (int d = 1; d < 64; d <<= 1) {
         P1 Q = shfl_down_pt(run, d);
         Q = ec::proj_select<F1>(lane + d < 64, ec::proj_inf<F1>(), Q);
-        ec::proj_add<F1>(run, Q);
+        g1_add_inplace(run, Q);
     }
     // V_l = T_l + L * P_l (l >= 1), V_0 = T_0 ; chunk T = sum_l V_l
     P1 LP = run;
-    ec::proj_dbl_n<F1>(LP, (int)logL);
+    for (uint32_t i = 0; i < logL; i++) { P1 c2 = LP; g1_add_inplace(LP, c2); }
     LP = ec::proj_select<F1>(lane == 0, LP, ec::proj_inf<F1>());
-    ec::proj_add<F1>(acc, LP);
+    g1_add_inplace(acc, LP);
 #pragma unroll 1
     for (int d = 32; d >= 1; d >>= 1) {
         P1 Q = shfl_down_pt(acc, d);
         Q = ec::proj_select<F1>((int)lane < d, ec::proj_inf<F1>(), Q);
-        ec::proj_add<F1>(acc, Q);
+        g1_add_inplace(acc, Q);
     }
     if (lane == 0) {
         store_jac_blst(pairs + (size_t)chunk * 72, run);
