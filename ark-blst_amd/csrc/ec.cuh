@@ -61,6 +61,73 @@ struct FpOpsInline : FpOps {
     static FP_HD E mul2add(const E& a, const E& b, const E& c, const E& d) { return fp28::fp_mul2add(a, b, c, d); }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Fp2 = Fp[u]/(u^2 + 1) for G2 (layout (c0, c1): /root/reference/src/fp2.rs:228).  A product is two fused
+// two-term multiply-adds, each with ONE Montgomery reduction, so every component of a product is < 2p and the
+// bound analysis of the Fp formulas carries over component-wise (tools/bounds_check.py, fp2 mode):
+//   c0 = a0 b0 + a1 (32p - b1)      needs b1 <= 31p and a (b + 32) < 2^392/p ~ 2520
+//   c1 = a0 b1 + a1 b0              needs 2 a b < 2520
+// b3 = 3 * 4(1 + u) = 12 + 12u is applied as a field multiplication (keeps the result < 2p).
+struct Fp2 {
+    fp28::Fp c0, c1;
+};
+
+template <bool INLINE>
+struct Fp2OpsT {
+    using E = Fp2;
+    using Fp = fp28::Fp;
+    static FP_HD Fp m1(const Fp& a, const Fp& b) {
+        if constexpr (INLINE) return fp28::fp_mul(a, b); else return fp28::fp_mul_call(a, b);
+    }
+    static FP_HD Fp m2(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
+        if constexpr (INLINE) return fp28::fp_mul2add(a, b, c, d); else return fp28::fp_mul2add_call(a, b, c, d);
+    }
+    static FP_HD E zero() { return E{fp28::fp_zero(), fp28::fp_zero()}; }
+    static FP_HD E one() { return E{fp28::fp_one(), fp28::fp_zero()}; }
+    static FP_HD E mul(const E& a, const E& b) {
+        Fp nb1 = fp28::fp_neg<32>(b.c1);
+        E r;
+        r.c0 = m2(a.c0, b.c0, a.c1, nb1);
+        r.c1 = m2(a.c0, b.c1, a.c1, b.c0);
+        return r;
+    }
+    static FP_HD E sqr(const E& a) {  // (a0 + a1)(a0 - a1) + 2 a0 a1 u ; a < 22p
+        E r;
+        r.c0 = m1(fp28::fp_add(a.c0, a.c1), fp28::fp_sub<32>(a.c0, a.c1));
+        r.c1 = m1(fp28::fp_add(a.c0, a.c0), a.c1);
+        return r;
+    }
+    static FP_HD E mul2add(const E& a, const E& b, const E& c, const E& d) {  // a b + c d ; b, d <= 31p
+        Fp nb1 = fp28::fp_neg<32>(b.c1), nd1 = fp28::fp_neg<32>(d.c1);
+        E r;
+        if constexpr (INLINE) {
+            r.c0 = fp28::fp_mul4add(a.c0, b.c0, a.c1, nb1, c.c0, d.c0, c.c1, nd1);
+            r.c1 = fp28::fp_mul4add(a.c0, b.c1, a.c1, b.c0, c.c0, d.c1, c.c1, d.c0);
+        } else {
+            r.c0 = fp28::fp_add(m2(a.c0, b.c0, a.c1, nb1), m2(c.c0, d.c0, c.c1, nd1));
+            r.c1 = fp28::fp_add(m2(a.c0, b.c1, a.c1, b.c0), m2(c.c0, d.c1, c.c1, d.c0));
+        }
+        return r;
+    }
+    static FP_HD E add(const E& a, const E& b) { return E{fp28::fp_add(a.c0, b.c0), fp28::fp_add(a.c1, b.c1)}; }
+    template <int K>
+    static FP_HD E sub(const E& a, const E& b) { return E{fp28::fp_sub<K>(a.c0, b.c0), fp28::fp_sub<K>(a.c1, b.c1)}; }
+    template <int K>
+    static FP_HD E neg(const E& a) { return E{fp28::fp_neg<K>(a.c0), fp28::fp_neg<K>(a.c1)}; }
+    static FP_HD E mul3(const E& a) { return E{fp28::fp_mul_small<3>(a.c0), fp28::fp_mul_small<3>(a.c1)}; }
+    static FP_HD E mul_b3(const E& a) {
+        E b3{fp28::fp_const(fp28::TWELVE), fp28::fp_const(fp28::TWELVE)};
+        return mul(a, b3);
+    }
+    static FP_HD bool is_zero_2p(const E& a) { return fp28::fp_is_zero_2p(a.c0) && fp28::fp_is_zero_2p(a.c1); }
+    static FP_HD E select(bool take_b, const E& a, const E& b) {
+        return E{fp28::fp_select(take_b, a.c0, b.c0), fp28::fp_select(take_b, a.c1, b.c1)};
+    }
+    static FP_HD bool limbs_all_zero(const E& a) { return FpOps::limbs_all_zero(a.c0) && FpOps::limbs_all_zero(a.c1); }
+};
+using Fp2Ops = Fp2OpsT<false>;
+using Fp2OpsInline = Fp2OpsT<true>;
+
 template <class F>
 struct Xyzz {
     typename F::E x, y, zz, zzz;
@@ -109,7 +176,7 @@ FP_HD void proj_add(Proj<F>& a, const Proj<F>& b) {
     E u = F::add(t1, t2);                          // Y1Y2 + b3 Z1Z2
     t1 = F::template sub<32>(t1, t2);              // Y1Y2 - b3 Z1Z2
     t5 = F::mul_b3(t5);                            // b3 (X1Z2 + X2Z1)
-    a.x = F::template sub<4>(F::mul(t3, t1), F::mul(t4, t5));
+    a.x = F::template sub<4>(F::mul(t1, t3), F::mul(t5, t4));  // (Fp2: second operand <= 31p)
     a.y = F::add(F::mul(t1, u), F::mul(t5, t0));
     a.z = F::add(F::mul(u, t4), F::mul(t0, t3));
 }

@@ -168,6 +168,30 @@ FP_HD Fp fp_mul2add(const Fp& a, const Fp& b, const Fp& c2, const Fp& d) {
     return fp_mont_reduce(c);
 }
 
+// r = (a*b + c*d + e*f + g*h) / 2^392 mod p, one reduction (Fp2 fused multiply-add): 56 + 14 terms < 2^62.2.
+FP_HD Fp fp_mul4add(const Fp& a, const Fp& b, const Fp& c2, const Fp& d, const Fp& e, const Fp& f, const Fp& g, const Fp& h) {
+    uint64_t c[2 * NL];
+#pragma unroll
+    for (int k = 0; k < 2 * NL; k++) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            c[i + j] += (uint64_t)a.l[i] * b.l[j];
+            c[i + j] += (uint64_t)c2.l[i] * d.l[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            c[i + j] += (uint64_t)e.l[i] * f.l[j];
+            c[i + j] += (uint64_t)g.l[i] * h.l[j];
+        }
+    }
+    return fp_mont_reduce(c);
+}
+
 // The shared multiplier instance.  On the device this is a REAL function (by-value args travel in v0..v27, the
 // result in v0..v13): one ~4.5 KB body per kernel instead of one per use keeps bucket kernels inside the
 // 64 KB instruction cache (see ec.cuh).  On the host it is plain inline code.
@@ -193,6 +217,13 @@ FP_HD Fp fp_sqr(const Fp& a) {
     }
     return fp_mont_reduce(c);
 }
+
+// shared fused two-product instance (Fp2 arithmetic outside the hot loop)
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __noinline__ Fp fp_mul2add_call(Fp a, Fp b, Fp c, Fp d) { return fp_mul2add(a, b, c, d); }
+#else
+FP_HD Fp fp_mul2add_call(const Fp& a, const Fp& b, const Fp& c, const Fp& d) { return fp_mul2add(a, b, c, d); }
+#endif
 
 // shared squaring instance (see fp_mul_call)
 #if defined(__HIP_DEVICE_COMPILE__)

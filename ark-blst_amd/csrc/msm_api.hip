@@ -27,6 +27,7 @@
 namespace {
 
 using hostec::G1;
+using hostec::G2;
 
 struct HipFail {
     std::string msg;
@@ -62,6 +63,13 @@ Plan make_plan(size_t n, unsigned forced_c) {
         uint32_t nwin = (256 + c - 1) / c;
         double nb = (double)(1u << (c - 1));
         double cost = (double)n * nwin + 6.0 * nb * nwin;
+        // The top window holds only 255 - c (nwin - 1) significant bits: all n entries of that window fall into
+        // 2^top_bits buckets, i.e. into few coarse bins of the fine sort, each streamed by ONE workgroup
+        // (~22 addition-times per entry, measured).  Penalise window sizes whose top window is nearly empty.
+        int top_bits = 255 - (int)c * ((int)nwin - 1);
+        if (top_bits < 0) top_bits = 0;
+        double maxbin = (double)n / (double)(1u << std::max(0, std::min<int>(top_bits, (int)c - 1) - (int)lo_bits));
+        cost += 22.0 * maxbin;
         if (cost < best_cost) {
             best_cost = cost;
             best.c = c;
@@ -104,12 +112,14 @@ struct DevState {
     int dev = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[10] = {};
-    // resident bases (device form) for G1
-    DevBuf g1_bases;
-    size_t g1_resident = 0;      // points resident on this device
-    size_t g1_shard_lo = 0;      // global index of the first resident point
+    // resident bases (device form) per group: [0] = G1, [1] = G2
+    struct Resident {
+        DevBuf buf;
+        size_t n = 0;    // points resident on this device
+        size_t lo = 0;   // global index of the first resident point
+    } res[2];
     // scratch
-    DevBuf raw, call_bases, scalars, hist, offsets, cursor, woff, meta, sched, sorted, partial, order, item_bucket, pairs;
+    DevBuf raw, call_bases, scalars, hist, offsets, woff, meta, sched, sorted, partial, order, item_bucket, pairs;
     DevBuf tilecnt, bin_tot, bin_base, coarse;
     void* h_pairs = nullptr;
     size_t h_pairs_cap = 0;
@@ -143,26 +153,41 @@ double ev_ms(hipEvent_t a, hipEvent_t b) {
     return ms;
 }
 
+// host-side view of a curve: the reference's raw sizes and the CPU Jacobian type used for the O(windows) tail
+template <class C> struct HostCurve;
+template <> struct HostCurve<msmk::G1C> {
+    using J = hostec::G1;
+    static constexpr int IDX = 0;
+};
+template <> struct HostCurve<msmk::G2C> {
+    using J = hostec::G2;
+    static constexpr int IDX = 1;
+};
+template <class C> constexpr size_t aff_bytes() { return (size_t)msmk::Geo<C>::RAW_AFF * 4; }
+template <class C> constexpr size_t jac_bytes() { return (size_t)msmk::Geo<C>::RAW_JAC * 4; }
+
 // bases raw (host or device) -> device form in `dst`
-void ingest_g1(DevState& d, const void* bases, bool bases_on_device, size_t n, DevBuf& dst) {
-    dst.ensure(n * msmk::G1_PT_WORDS * 4);
+template <class C>
+void ingest(DevState& d, const void* bases, bool bases_on_device, size_t n, DevBuf& dst) {
+    dst.ensure(n * msmk::Geo<C>::PT_WORDS * 4);
     const void* src = bases;
     if (!bases_on_device) {
-        d.raw.ensure(n * 96);
-        HIP_TRY(hipMemcpyAsync(d.raw.p, bases, n * 96, hipMemcpyHostToDevice, d.stream));
+        d.raw.ensure(n * aff_bytes<C>());
+        HIP_TRY(hipMemcpyAsync(d.raw.p, bases, n * aff_bytes<C>(), hipMemcpyHostToDevice, d.stream));
         src = d.raw.p;
     }
     uint32_t grid = (uint32_t)((n + 255) / 256);
-    hipLaunchKernelGGL(msmk::k_ingest_g1, dim3(grid), dim3(256), 0, d.stream, (const uint32_t*)src, (uint32_t*)dst.p, (uint32_t)n);
+    hipLaunchKernelGGL(msmk::k_ingest<C>, dim3(grid), dim3(256), 0, d.stream, (const uint32_t*)src, (uint32_t*)dst.p, (uint32_t)n);
     HIP_TRY(hipGetLastError());
 }
 
 // Host tail: combine chunk sums per window and Horner-fold the windows (cf. /root/reference/src/gpu.rs:193-209).
-G1 host_fold_g1(mi_ctx* ctx, const G1* pairs, const Plan& pl) {
-    std::vector<G1> win(pl.nwin);
+template <class J>
+J host_fold(mi_ctx* ctx, const J* pairs, const Plan& pl) {
+    std::vector<J> win(pl.nwin);
     auto do_window = [&](unsigned w) {
-        const G1* p = pairs + (size_t)w * pl.chunks_per_win * 2;
-        G1 run = G1::inf(), acc = G1::inf(), tsum = G1::inf();
+        const J* p = pairs + (size_t)w * pl.chunks_per_win * 2;
+        J run = J::inf(), acc = J::inf(), tsum = J::inf();
         for (int j = (int)pl.chunks_per_win - 1; j >= 0; j--) {
             tsum = tsum.add(p[2 * j + 1]);
             if (j >= 1) {
@@ -178,32 +203,35 @@ G1 host_fold_g1(mi_ctx* ctx, const G1* pairs, const Plan& pl) {
     } else {
         for (uint32_t w = 0; w < pl.nwin; w++) do_window(w);
     }
-    G1 r = G1::inf();
+    J r = J::inf();
     for (int w = (int)pl.nwin - 1; w >= 0; w--) r = r.dbl_n(pl.c).add(win[w]);
     return r;
 }
 
 // The pipeline on one device.  d_bases: device-form points for indices [0, n); d_scalars: n x 32 B on device.
-G1 run_g1(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, unsigned fmt, int ev0) {
+template <class C>
+typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, unsigned fmt,
+                                 int ev0) {
+    using J = typename HostCurve<C>::J;
     Plan pl = make_plan(n, ctx->forced_c);
     if (pl.c == 0) throw HipFail{"window_bits not usable for this n (sort geometry)"};
     d.prof.window_bits = pl.c;
     d.prof.num_windows = pl.nwin;
     d.prof.n = n;
+    const size_t pair_bytes = 2 * jac_bytes<C>();
     d.hist.ensure(pl.nbuckets * 4);
     d.offsets.ensure((pl.nbuckets + 1) * 4);
-    d.cursor.ensure(pl.nbuckets * 4);
     d.woff.ensure((pl.nbuckets + 1) * 4);
     d.meta.ensure(16);
     d.sorted.ensure((size_t)n * pl.nwin * 4);
-    d.pairs.ensure(pl.nchunks * 2 * 144);
-    ensure_host(d, pl.nchunks * 2 * 144 + 16);
+    d.pairs.ensure(pl.nchunks * pair_bytes);
+    ensure_host(d, pl.nchunks * pair_bytes + 16);
 
     hipStream_t s = d.stream;
     HIP_TRY(hipEventRecord(d.ev[ev0], s));
     // ---- two-level LDS-staged bucket sort (geometry in msmk::SortGeom)
     msmk::SortGeom g{};
-    g.n = (uint32_t)n; g.fmt = fmt; g.c = pl.c; g.nwin = pl.nwin; g.pt_words = msmk::G1_PT_WORDS;
+    g.n = (uint32_t)n; g.fmt = fmt; g.c = pl.c; g.nwin = pl.nwin; g.pt_words = msmk::Geo<C>::PT_WORDS;
     g.lo_bits = pl.lo_bits;
     g.H = pl.nb >> g.lo_bits;
     g.tiles = (uint32_t)std::min<size_t>(512, std::max<size_t>(1, n / 4096));
@@ -227,12 +255,11 @@ G1 run_g1(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_s
     hipLaunchKernelGGL(msmk::k_fine_sort, dim3(g.nbins), dim3(256), 0, s, (const uint32_t*)d.coarse.p, (const uint32_t*)d.bin_base.p, g,
                        (uint32_t*)d.sorted.p, (uint32_t*)d.hist.p);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 2], s));
-    // schedule: <= 256 blocks of 1024 lanes, each lane owning per_blk/1024 consecutive buckets
+    // ---- schedule: <= 256 blocks of 1024 lanes, each lane owning per_blk/1024 consecutive buckets
     uint32_t per_blk = 4096;
     while ((pl.nbuckets + per_blk - 1) / per_blk > 256) per_blk <<= 1;
     uint32_t nblk = (uint32_t)((pl.nbuckets + per_blk - 1) / per_blk);
-    // upper bound on items: one per bucket plus one per T entries
-    size_t items_cap = pl.nbuckets + (((size_t)n * pl.nwin) >> pl.logT) + 1;
+    size_t items_cap = pl.nbuckets + (((size_t)n * pl.nwin) >> pl.logT) + 1;  // one per bucket plus one per T entries
     d.sched.ensure((size_t)(3 + msmk::SCHED_CLASSES) * nblk * 4);
     d.order.ensure(items_cap * 4);
     d.item_bucket.ensure(items_cap * 4);
@@ -246,26 +273,26 @@ G1 run_g1(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_s
                        (uint32_t*)d.meta.p);
     hipLaunchKernelGGL(msmk::k_sched3, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT,
                        nblk, (const uint32_t*)blk_e, (const uint32_t*)blk_i, (const uint32_t*)blk_cls, (uint32_t*)d.offsets.p,
-                       (uint32_t*)d.cursor.p, (uint32_t*)d.woff.p, (uint32_t*)d.order.p, (uint32_t*)d.item_bucket.p);
+                       (uint32_t*)d.woff.p, (uint32_t*)d.order.p, (uint32_t*)d.item_bucket.p);
     // the item count sizes the next launches: one small read-back (the only mid-pipeline sync)
     uint32_t meta[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(meta, d.meta.p, 12, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(d.ev[ev0 + 3], s));
     HIP_TRY(hipStreamSynchronize(s));
     uint32_t nitems = meta[0], max_items = meta[1];
-    d.partial.ensure((size_t)nitems * msmk::G1_BK_WORDS * 4);
+    d.partial.ensure((size_t)nitems * msmk::Geo<C>::BK_WORDS * 4);
     uint32_t grid_items = (nitems + 255) / 256;
-    hipLaunchKernelGGL(msmk::k_accumulate_g1, dim3(grid_items), dim3(256), 0, s, d_bases, (const uint32_t*)d.sorted.p,
+    hipLaunchKernelGGL(msmk::k_accumulate<C>, dim3(grid_items), dim3(256), 0, s, d_bases, (const uint32_t*)d.sorted.p,
                        (const uint32_t*)d.offsets.p, (const uint32_t*)d.woff.p, (const uint32_t*)d.order.p,
                        (const uint32_t*)d.item_bucket.p, nitems, pl.logT, (uint32_t*)d.partial.p);
     for (uint32_t dd = 1; dd < max_items; dd <<= 1)
-        hipLaunchKernelGGL(msmk::k_merge_g1, dim3(grid_items), dim3(256), 0, s, (uint32_t*)d.partial.p, (const uint32_t*)d.item_bucket.p,
+        hipLaunchKernelGGL(msmk::k_merge<C>, dim3(grid_items), dim3(256), 0, s, (uint32_t*)d.partial.p, (const uint32_t*)d.item_bucket.p,
                            (const uint32_t*)d.woff.p, nitems, dd);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 4], s));
-    hipLaunchKernelGGL(msmk::k_reduce_g1<1>, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
+    hipLaunchKernelGGL(msmk::k_reduce<C>, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
                        (const uint32_t*)d.woff.p, (uint32_t*)d.pairs.p, pl.logL);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 5], s));
-    HIP_TRY(hipMemcpyAsync(d.h_pairs, d.pairs.p, pl.nchunks * 2 * 144, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(d.h_pairs, d.pairs.p, pl.nchunks * pair_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(d.ev[ev0 + 6], s));
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipGetLastError());
@@ -281,18 +308,20 @@ G1 run_g1(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_s
     d.prof.max_items_per_bucket = max_items;
 
     auto t0 = std::chrono::steady_clock::now();
-    G1 r = host_fold_g1(ctx, reinterpret_cast<const G1*>(d.h_pairs), pl);
+    J r = host_fold<J>(ctx, reinterpret_cast<const J*>(d.h_pairs), pl);
     d.prof.host_fold_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return r;
 }
 
 // One device's share of an MSM call. bases: host raw pointer for this shard or nullptr (= resident).
-G1 device_msm_g1(mi_ctx* ctx, DevState& d, const mi_g1_affine* bases, const uint8_t* scalars, bool scalars_on_device, size_t n,
-                 unsigned fmt) {
+template <class C>
+typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bases, const uint8_t* scalars, bool scalars_on_device,
+                                    size_t n, unsigned fmt) {
+    using J = typename HostCurve<C>::J;
     HIP_TRY(hipSetDevice(d.dev));
     d.prof = mi_profile{};
     auto t0 = std::chrono::steady_clock::now();
-    if (n == 0) return G1::inf();
+    if (n == 0) return J::inf();
     hipStream_t s = d.stream;
     HIP_TRY(hipEventRecord(d.ev[0], s));
     const uint32_t* d_scalars;
@@ -305,16 +334,16 @@ G1 device_msm_g1(mi_ctx* ctx, DevState& d, const mi_g1_affine* bases, const uint
     }
     const uint32_t* d_bases;
     if (bases) {
-        d.raw.ensure(n * 96);
-        HIP_TRY(hipMemcpyAsync(d.raw.p, bases, n * 96, hipMemcpyHostToDevice, s));
+        d.raw.ensure(n * aff_bytes<C>());
+        HIP_TRY(hipMemcpyAsync(d.raw.p, bases, n * aff_bytes<C>(), hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(d.ev[1], s));
-        ingest_g1(d, d.raw.p, true, n, d.call_bases);
+        ingest<C>(d, d.raw.p, true, n, d.call_bases);
         d_bases = reinterpret_cast<const uint32_t*>(d.call_bases.p);
     } else {
         HIP_TRY(hipEventRecord(d.ev[1], s));
-        d_bases = reinterpret_cast<const uint32_t*>(d.g1_bases.p);
+        d_bases = reinterpret_cast<const uint32_t*>(d.res[HostCurve<C>::IDX].buf.p);
     }
-    G1 r = run_g1(ctx, d, d_bases, d_scalars, n, fmt, 2);
+    J r = run_msm<C>(ctx, d, d_bases, d_scalars, n, fmt, 2);
     d.prof.h2d_ms = ev_ms(d.ev[0], d.ev[1]);
     d.prof.ingest_ms = ev_ms(d.ev[1], d.ev[2]);
     d.prof.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -347,22 +376,48 @@ void shard_range(size_t n, size_t g, size_t k, size_t& lo, size_t& hi) {
     hi = std::min(n, lo + per);
 }
 
-int msm_g1_impl(mi_ctx* ctx, const mi_g1_affine* bases, const uint8_t* scalars, bool scalars_on_device, size_t n, unsigned fmt,
-                mi_g1* out) {
+template <class C>
+int set_bases_impl(mi_ctx* ctx, const void* bases, size_t n) {
+    if (!ctx || (n && !bases)) return fail(ctx, MI_E_INVALID, "invalid argument");
+    if (n > 0x3fffffffull) return fail(ctx, MI_E_INVALID, "n exceeds 2^30-1 points");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return guarded(ctx, [&]() -> int {
+        size_t g = ctx->devs.size();
+        for (size_t k = 0; k < g; k++) {
+            DevState& d = ctx->devs[k];
+            auto& res = d.res[HostCurve<C>::IDX];
+            size_t lo, hi;
+            shard_range(n, g, k, lo, hi);
+            HIP_TRY(hipSetDevice(d.dev));
+            res.lo = lo;
+            res.n = hi - lo;
+            if (hi > lo) {
+                ingest<C>(d, (const uint8_t*)bases + lo * aff_bytes<C>(), false, hi - lo, res.buf);
+                HIP_TRY(hipStreamSynchronize(d.stream));
+            }
+        }
+        return MI_OK;
+    });
+}
+
+template <class C>
+int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scalars_on_device, size_t n, unsigned fmt, void* out) {
+    using J = typename HostCurve<C>::J;
+    const uint8_t* bases = static_cast<const uint8_t*>(bases_v);
     if (!ctx || !out || (n && !scalars) || fmt > 1) return fail(ctx, MI_E_INVALID, "invalid argument");
-    if (n > 0x7fffffffull) return fail(ctx, MI_E_INVALID, "n exceeds 2^31-1 points per call");
+    if (n > 0x3fffffffull) return fail(ctx, MI_E_INVALID, "n exceeds 2^30-1 points per call");
     std::lock_guard<std::mutex> lk(ctx->mu);
     return guarded(ctx, [&]() -> int {
         size_t g = ctx->devs.size();
         if (scalars_on_device && g != 1) return fail(ctx, MI_E_INVALID, "device-resident scalars need a single-device context");
-        std::vector<G1> part(g, G1::inf());
+        std::vector<J> part(g, J::inf());
         std::vector<std::string> errs(g);
         // resident path: each device covers the overlap of [0, n) with its resident shard
         if (!bases) {
             size_t have = 0;
-            for (auto& d : ctx->devs) have += d.g1_resident;
-            if (have == 0 && n) return fail(ctx, MI_E_NO_BASES, "no resident G1 base set");
-            if (n > have) return fail(ctx, MI_E_INVALID, "n exceeds the resident G1 base set");
+            for (auto& d : ctx->devs) have += d.res[HostCurve<C>::IDX].n;
+            if (have == 0 && n) return fail(ctx, MI_E_NO_BASES, "no resident base set for this group");
+            if (n > have) return fail(ctx, MI_E_INVALID, "n exceeds the resident base set");
         }
         auto work = [&](size_t k) {
             DevState& d = ctx->devs[k];
@@ -371,11 +426,12 @@ int msm_g1_impl(mi_ctx* ctx, const mi_g1_affine* bases, const uint8_t* scalars, 
                 if (bases) {
                     shard_range(n, g, k, lo, hi);
                 } else {
-                    lo = std::min(n, d.g1_shard_lo);
-                    hi = std::min(n, d.g1_shard_lo + d.g1_resident);
+                    auto& res = d.res[HostCurve<C>::IDX];
+                    lo = std::min(n, res.lo);
+                    hi = std::min(n, res.lo + res.n);
                 }
                 const uint8_t* sc = scalars_on_device ? scalars : scalars + lo * 32;
-                part[k] = device_msm_g1(ctx, d, bases ? bases + lo : nullptr, sc, scalars_on_device, hi - lo, fmt);
+                part[k] = device_msm<C>(ctx, d, bases ? bases + lo * aff_bytes<C>() : nullptr, sc, scalars_on_device, hi - lo, fmt);
             } catch (const HipFail& e) {
                 errs[k] = e.msg;
             }
@@ -390,7 +446,7 @@ int msm_g1_impl(mi_ctx* ctx, const mi_g1_affine* bases, const uint8_t* scalars, 
         }
         for (size_t k = 0; k < g; k++)
             if (!errs[k].empty()) return fail(ctx, MI_E_HIP, errs[k]);
-        G1 r = G1::inf();
+        J r = J::inf();
         for (size_t k = 0; k < g; k++) r = r.add(part[k]);
         memcpy(out, &r, sizeof r);
         // report the slowest device's profile
@@ -445,7 +501,7 @@ void mi_msm_destroy(mi_ctx* ctx) {
     for (auto& d : ctx->devs) {
         (void)hipSetDevice(d.dev);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
-        for (DevBuf* b : {&d.g1_bases, &d.raw, &d.call_bases, &d.scalars, &d.hist, &d.offsets, &d.cursor, &d.woff, &d.meta, &d.sched, &d.sorted,
+        for (DevBuf* b : {&d.res[0].buf, &d.res[1].buf, &d.raw, &d.call_bases, &d.scalars, &d.hist, &d.offsets, &d.woff, &d.meta, &d.sched, &d.sorted,
                           &d.partial, &d.order, &d.item_bucket, &d.pairs, &d.tilecnt, &d.bin_tot, &d.bin_base, &d.coarse})
             b->release();
         if (d.h_pairs) (void)hipHostFree(d.h_pairs);
@@ -458,39 +514,21 @@ void mi_msm_destroy(mi_ctx* ctx) {
 
 int mi_msm_num_devices(const mi_ctx* ctx) { return ctx ? (int)ctx->devs.size() : 0; }
 
-int mi_msm_g1_set_bases(mi_ctx* ctx, const mi_g1_affine* bases, size_t n) {
-    if (!ctx || (n && !bases)) return fail(ctx, MI_E_INVALID, "invalid argument");
-    if (n > 0x7fffffffull) return fail(ctx, MI_E_INVALID, "n exceeds 2^31-1 points");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    return guarded(ctx, [&]() -> int {
-        size_t g = ctx->devs.size();
-        for (size_t k = 0; k < g; k++) {
-            DevState& d = ctx->devs[k];
-            size_t lo, hi;
-            shard_range(n, g, k, lo, hi);
-            HIP_TRY(hipSetDevice(d.dev));
-            d.g1_shard_lo = lo;
-            d.g1_resident = hi - lo;
-            if (hi > lo) {
-                ingest_g1(d, bases + lo, false, hi - lo, d.g1_bases);
-                HIP_TRY(hipStreamSynchronize(d.stream));
-            }
-        }
-        return MI_OK;
-    });
-}
+int mi_msm_g1_set_bases(mi_ctx* ctx, const mi_g1_affine* bases, size_t n) { return set_bases_impl<msmk::G1C>(ctx, bases, n); }
+int mi_msm_g2_set_bases(mi_ctx* ctx, const mi_g2_affine* bases, size_t n) { return set_bases_impl<msmk::G2C>(ctx, bases, n); }
 
 int mi_msm_g1(mi_ctx* ctx, const mi_g1_affine* bases, const uint8_t* scalars, size_t n, unsigned scalar_fmt, mi_g1* out) {
-    return msm_g1_impl(ctx, bases, scalars, false, n, scalar_fmt, out);
+    return msm_impl<msmk::G1C>(ctx, bases, scalars, false, n, scalar_fmt, out);
 }
-
+int mi_msm_g2(mi_ctx* ctx, const mi_g2_affine* bases, const uint8_t* scalars, size_t n, unsigned scalar_fmt, mi_g2* out) {
+    return msm_impl<msmk::G2C>(ctx, bases, scalars, false, n, scalar_fmt, out);
+}
 int mi_msm_g1_device(mi_ctx* ctx, const void* d_scalars, size_t n, unsigned scalar_fmt, mi_g1* out) {
-    return msm_g1_impl(ctx, nullptr, static_cast<const uint8_t*>(d_scalars), true, n, scalar_fmt, out);
+    return msm_impl<msmk::G1C>(ctx, nullptr, static_cast<const uint8_t*>(d_scalars), true, n, scalar_fmt, out);
 }
-
-int mi_msm_g2_set_bases(mi_ctx* ctx, const mi_g2_affine*, size_t) { return fail(ctx, MI_E_UNSUPPORTED, "G2 not built yet"); }
-int mi_msm_g2(mi_ctx* ctx, const mi_g2_affine*, const uint8_t*, size_t, unsigned, mi_g2*) { return fail(ctx, MI_E_UNSUPPORTED, "G2 not built yet"); }
-int mi_msm_g2_device(mi_ctx* ctx, const void*, size_t, unsigned, mi_g2*) { return fail(ctx, MI_E_UNSUPPORTED, "G2 not built yet"); }
+int mi_msm_g2_device(mi_ctx* ctx, const void* d_scalars, size_t n, unsigned scalar_fmt, mi_g2* out) {
+    return msm_impl<msmk::G2C>(ctx, nullptr, static_cast<const uint8_t*>(d_scalars), true, n, scalar_fmt, out);
+}
 
 int mi_g1_sum(const mi_g1* partials, size_t n, mi_g1* out) {
     if (!out || (n && !partials)) return MI_E_INVALID;

@@ -5,7 +5,7 @@
 // (one thread = one (base-group, window) with 2^w private Jacobian buckets in global memory, unsigned digits,
 // host-side fold of ~32k partials at gpu.rs:193-209) with a sort-based pipeline:
 //
-//   k_ingest      bases: blst_p1_affine (96 B, R = 2^384)  ->  device form (2 x 14 x 28-bit limbs, R' = 2^392)
+//   k_ingest<C>   bases: blst_p{1,2}_affine (R = 2^384)  ->  device form (14 x 28-bit limbs per Fp, R' = 2^392)
 //   k_coarse<0/1>, k_colscan, k_binscan, k_fine_sort: scalars -> signed c-bit digits (NEGATION_IS_CHEAP,
 //                 src/g1.rs:595) -> two-level LDS-staged bucket sort -> sorted (index|sign) entries + histogram
 //   k_sched1-3    prefix sums of the histogram -> bucket offsets, work items (heavy buckets split), length-sorted order
@@ -25,11 +25,11 @@ using fp28::Fp;
 using fp28::NL;
 
 // ---------------------------------------------------------------------------------------------- layouts
-// device affine point (G1): 32 words = 128 B: x limbs [0,14), y limbs [16,30), word 31 = 1 if infinity
-constexpr int G1_PT_WORDS = 32;
-// device bucket (G1 projective, complete-formula form): 48 words = 192 B: coordinate k at words [16k, 16k+14)
-constexpr int G1_BK_WORDS = 48;
-
+// Every field element occupies a 16-word (64 B) aligned slot per Fp component (14 limbs + 2 spare words), so it moves
+// as 4 x dwordx4.  Curve descriptor C:
+//   G1: affine point = 2 slots  (128 B: x, y; word 31 = infinity flag), projective bucket = 3 slots (192 B)
+//   G2: affine point = 4 slots  (256 B: x.c0, x.c1, y.c0, y.c1; word 63 = flag),       bucket = 6 slots (384 B)
+// Raw (reference) forms: blst_p1_affine 24 words, blst_p1 36 words; blst_p2_affine 48 words, blst_p2 72 words.
 __device__ __forceinline__ void load_fp16(Fp& r, const uint32_t* p) {  // 16-word aligned slot, 14 used
     const uint4* q = reinterpret_cast<const uint4*>(p);
     uint4 a = q[0], b = q[1], c = q[2], d = q[3];
@@ -45,51 +45,110 @@ __device__ __forceinline__ void store_fp16(uint32_t* p, const Fp& r, uint32_t w1
     q[2] = make_uint4(r.l[8], r.l[9], r.l[10], r.l[11]);
     q[3] = make_uint4(r.l[12], r.l[13], w14, w15);
 }
+__device__ __forceinline__ Fp shfl_down_fp(const Fp& a, int d) {
+    Fp r;
+#pragma unroll
+    for (int k = 0; k < NL; k++) r.l[k] = __shfl_down(a.l[k], d, 64);
+    return r;
+}
+__device__ __forceinline__ void fp_from_raw(Fp& r, const uint32_t* raw) {  // 12 raw words -> device form
+    uint32_t w[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) w[k] = raw[k];
+    r = fp28::fp_from_blst(w);
+}
+__device__ __forceinline__ uint32_t fp_to_raw(uint32_t* out, const Fp& a, bool keep) {  // returns OR of the words
+    uint32_t w[12], any = 0;
+    fp28::fp_to_blst(w, a);
+#pragma unroll
+    for (int k = 0; k < 12; k++) { out[k] = keep ? w[k] : 0u; any |= w[k]; }
+    return any;
+}
 
-using F1 = ec::FpOps;
-using ACC_F = ec::FpOpsInline;  // accumulate hot loop: multiplier inlined (see ec.cuh)
-using X1 = ec::Xyzz<F1>;
-using P1 = ec::Proj<F1>;
+// element I/O, generic over Fp / Fp2
+template <class E> struct ElemIO;
+template <> struct ElemIO<Fp> {
+    static constexpr int SLOT = 16, RAW = 12;
+    static __device__ __forceinline__ void load(Fp& r, const uint32_t* p) { load_fp16(r, p); }
+    static __device__ __forceinline__ void store(uint32_t* p, const Fp& r, uint32_t flag = 0) { store_fp16(p, r, 0, flag); }
+    static __device__ __forceinline__ Fp shfl_down(const Fp& a, int d) { return shfl_down_fp(a, d); }
+    static __device__ __forceinline__ void from_raw(Fp& r, const uint32_t* raw) { fp_from_raw(r, raw); }
+    static __device__ __forceinline__ uint32_t to_raw(uint32_t* out, const Fp& a, bool keep) { return fp_to_raw(out, a, keep); }
+};
+template <> struct ElemIO<ec::Fp2> {
+    static constexpr int SLOT = 32, RAW = 24;
+    static __device__ __forceinline__ void load(ec::Fp2& r, const uint32_t* p) { load_fp16(r.c0, p); load_fp16(r.c1, p + 16); }
+    static __device__ __forceinline__ void store(uint32_t* p, const ec::Fp2& r, uint32_t flag = 0) {
+        store_fp16(p, r.c0);
+        store_fp16(p + 16, r.c1, 0, flag);
+    }
+    static __device__ __forceinline__ ec::Fp2 shfl_down(const ec::Fp2& a, int d) {
+        return ec::Fp2{shfl_down_fp(a.c0, d), shfl_down_fp(a.c1, d)};
+    }
+    static __device__ __forceinline__ void from_raw(ec::Fp2& r, const uint32_t* raw) { fp_from_raw(r.c0, raw); fp_from_raw(r.c1, raw + 12); }
+    static __device__ __forceinline__ uint32_t to_raw(uint32_t* out, const ec::Fp2& a, bool keep) {
+        return fp_to_raw(out, a.c0, keep) | fp_to_raw(out + 12, a.c1, keep);
+    }
+};
 
-// Complete addition as ONE out-of-line body with the twelve multiplications inlined inside it (~55 KB): the reduce /
-// merge / cold paths call it from several sites; their additions are latency-bound (few waves), so the per-call
-// register shuffling of the shared multiplier (~16 %) is worth removing here too.
-__device__ __noinline__ void g1_add_inplace(P1& a, const P1& b) {
+struct G1C {                         // /root/reference/src/g1.rs: G1Affine / G1Projective over Fp
+    using F = ec::FpOps;             // shared-call multiplier: everything outside the hot loop
+    using FA = ec::FpOpsInline;      // accumulate hot loop
+    static constexpr int OCC = 2;    // waves per SIMD the accumulate kernel is built for
+};
+struct G2C {                         // /root/reference/src/g2.rs: G2Affine / G2Projective over Fp2
+    using F = ec::Fp2Ops;
+    using FA = ec::Fp2Ops;           // 4 x 28 limbs per Xyzz coordinate pair: the shared bodies keep code and registers in check
+    static constexpr int OCC = 2;
+};
+template <class C> struct Geo {
+    using E = typename C::F::E;
+    static constexpr int SLOT = ElemIO<E>::SLOT;
+    static constexpr int PT_WORDS = 2 * SLOT, BK_WORDS = 3 * SLOT;
+    static constexpr int RAW_AFF = 2 * ElemIO<E>::RAW, RAW_JAC = 3 * ElemIO<E>::RAW;
+};
+constexpr int G1_PT_WORDS = Geo<G1C>::PT_WORDS, G1_BK_WORDS = Geo<G1C>::BK_WORDS;
+constexpr int G2_PT_WORDS = Geo<G2C>::PT_WORDS, G2_BK_WORDS = Geo<G2C>::BK_WORDS;
+
+template <class C>
+__device__ __forceinline__ ec::Proj<typename C::F> load_bucket(const uint32_t* p) {
+    using E = typename C::F::E;
+    ec::Proj<typename C::F> r;
+    ElemIO<E>::load(r.x, p); ElemIO<E>::load(r.y, p + Geo<C>::SLOT); ElemIO<E>::load(r.z, p + 2 * Geo<C>::SLOT);
+    return r;
+}
+template <class C>
+__device__ __forceinline__ void store_bucket(uint32_t* p, const ec::Proj<typename C::F>& r) {
+    using E = typename C::F::E;
+    ElemIO<E>::store(p, r.x); ElemIO<E>::store(p + Geo<C>::SLOT, r.y); ElemIO<E>::store(p + 2 * Geo<C>::SLOT, r.z);
+}
+
+// Complete addition as ONE out-of-line body per curve: the reduce / merge / cold paths call it from several sites.
+// G1 inlines its twelve multiplications inside it (latency-bound callers; ~16 % faster than the shared multiplier).
+__device__ __noinline__ void add_inplace(ec::Proj<ec::FpOps>& a, const ec::Proj<ec::FpOps>& b) {
     ec::Proj<ec::FpOpsInline>& ai = reinterpret_cast<ec::Proj<ec::FpOpsInline>&>(a);
     const ec::Proj<ec::FpOpsInline>& bi = reinterpret_cast<const ec::Proj<ec::FpOpsInline>&>(b);
     ec::proj_add<ec::FpOpsInline>(ai, bi);
 }
-
-__device__ __forceinline__ P1 load_bucket(const uint32_t* p) {
-    P1 r;
-    load_fp16(r.x, p); load_fp16(r.y, p + 16); load_fp16(r.z, p + 32);
-    return r;
-}
-__device__ __forceinline__ void store_bucket(uint32_t* p, const P1& r) {
-    store_fp16(p, r.x); store_fp16(p + 16, r.y); store_fp16(p + 32, r.z);
-}
+__device__ __noinline__ void add_inplace(ec::Proj<ec::Fp2Ops>& a, const ec::Proj<ec::Fp2Ops>& b) { ec::proj_add<ec::Fp2Ops>(a, b); }
 
 // ---------------------------------------------------------------------------------------------- ingest
-// raw: n x 24 words (blst_p1_affine).  One thread per point.
-__global__ void __launch_bounds__(256) k_ingest_g1(const uint32_t* __restrict__ raw, uint32_t* __restrict__ out, uint32_t n) {
+// raw: n affine points in the reference's form.  One thread per point.
+template <class C>
+__global__ void __launch_bounds__(256) k_ingest(const uint32_t* __restrict__ raw, uint32_t* __restrict__ out, uint32_t n) {
+    using E = typename C::F::E;
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint4* q = reinterpret_cast<const uint4*>(raw + (size_t)i * 24);
-    uint32_t w[24];
+    const uint32_t* q = raw + (size_t)i * Geo<C>::RAW_AFF;
     uint32_t any = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        uint4 v = q[k];
-        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
-        any |= v.x | v.y | v.z | v.w;
-    }
-    uint32_t xw[12], yw[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) { xw[k] = w[k]; yw[k] = w[12 + k]; }
-    Fp x = fp28::fp_from_blst(xw), y = fp28::fp_from_blst(yw);
-    uint32_t* o = out + (size_t)i * G1_PT_WORDS;
-    store_fp16(o, x);
-    store_fp16(o + 16, y, 0, any == 0 ? 1u : 0u);
+#pragma unroll 4
+    for (int k = 0; k < Geo<C>::RAW_AFF; k++) any |= q[k];
+    E x, y;
+    ElemIO<E>::from_raw(x, q);
+    ElemIO<E>::from_raw(y, q + ElemIO<E>::RAW);
+    uint32_t* o = out + (size_t)i * Geo<C>::PT_WORDS;
+    ElemIO<E>::store(o, x);
+    ElemIO<E>::store(o + Geo<C>::SLOT, y, any == 0 ? 1u : 0u);
 }
 
 // ---------------------------------------------------------------------------------------------- scalars
@@ -397,7 +456,7 @@ __global__ void __launch_bounds__(1024) k_sched2(uint32_t nblk, uint32_t* __rest
 __global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hist, uint32_t m, uint32_t per_blk, uint32_t logT,
                                                  uint32_t nblk, const uint32_t* __restrict__ blk_e, const uint32_t* __restrict__ blk_i,
                                                  const uint32_t* __restrict__ blk_cls, uint32_t* __restrict__ offsets,
-                                                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ woff,
+                                                 uint32_t* __restrict__ woff,
                                                  uint32_t* __restrict__ order, uint32_t* __restrict__ item_bucket) {
     __shared__ uint32_t pe[1024], pi[1024], cur[SCHED_CLASSES];
     uint32_t t = threadIdx.x, blk = blockIdx.x;
@@ -424,7 +483,6 @@ __global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hi
     for (uint32_t k = lo; k < hi; k++) {
         uint32_t h = hist[k], it = items_of(h, logT);
         offsets[k] = run_e;
-        cursor[k] = run_e;
         woff[k] = run_i;
         if (it > 1) {  // full-length chunks of a split bucket: one reservation in the longest class
             uint32_t pos = atomicAdd(&cur[64], it - 1);
@@ -441,23 +499,29 @@ __global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hi
 }
 
 // ---------------------------------------------------------------------------------------------- accumulate
-__device__ __forceinline__ void load_point(Fp& x, Fp& y, const uint32_t* bases, uint32_t ent) {
-    const uint32_t* p = bases + (size_t)(ent & 0x7fffffffu) * G1_PT_WORDS;
-    load_fp16(x, p);
-    load_fp16(y, p + 16);
+template <class C>
+__device__ __forceinline__ void load_point(typename C::F::E& x, typename C::F::E& y, const uint32_t* bases, uint32_t ent) {
+    using E = typename C::F::E;
+    const uint32_t* p = bases + (size_t)(ent & 0x7fffffffu) * Geo<C>::PT_WORDS;
+    ElemIO<E>::load(x, p);
+    ElemIO<E>::load(y, p + Geo<C>::SLOT);
 }
 
 // One lane per WORK ITEM = (bucket, chunk): item i of bucket b covers entries
 // sorted[offsets[b] + k*T .. min(offsets[b] + (k+1)*T, offsets[b+1])), k = i - woff[b]; entries are (index | sign<<31).
 // Hot loop: XYZZ mixed additions.  Register budget is the constraint (256 VGPRs at 2 waves/SIMD), so the next
-// point is not staged in registers: its index is fetched one iteration ahead and its 128-byte line is touched
-// early so the real load hits L2; the other resident wave covers what latency is left.
+// point is not staged in registers: its index is fetched one iteration ahead and its line(s) touched early so the
+// real load hits L2; the other resident wave covers what latency is left.
 // A lane that meets an exceptional pair (same x) leaves the hot loop and finishes on the complete formulas.
 // Output: partial[i] (projective), i = natural item id.
-__global__ void __launch_bounds__(256, 2) k_accumulate_g1(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                                                          const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ woff,
-                                                          const uint32_t* __restrict__ order, const uint32_t* __restrict__ item_bucket,
-                                                          uint32_t nitems, uint32_t logT, uint32_t* __restrict__ partial) {
+template <class C>
+__global__ void __launch_bounds__(256, C::OCC) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                            const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ woff,
+                                                            const uint32_t* __restrict__ order, const uint32_t* __restrict__ item_bucket,
+                                                            uint32_t nitems, uint32_t logT, uint32_t* __restrict__ partial) {
+    using F = typename C::F;
+    using FA = typename C::FA;
+    using E = typename F::E;
     uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= nitems) return;
     uint32_t i = order[j];          // items are processed longest class first; partial[] keeps natural item order
@@ -465,46 +529,47 @@ __global__ void __launch_bounds__(256, 2) k_accumulate_g1(const uint32_t* __rest
     uint32_t k = i - woff[b];
     uint32_t e = offsets[b] + (k << logT), bend = offsets[b + 1];
     uint32_t end = e + (1u << logT) < bend ? e + (1u << logT) : bend;
-    X1 acc;
-    acc.x = fp28::fp_zero(); acc.y = fp28::fp_zero(); acc.zz = fp28::fp_zero(); acc.zzz = fp28::fp_zero();
+    ec::Xyzz<FA> acc;
+    acc.x = F::zero(); acc.y = F::zero(); acc.zz = F::zero(); acc.zzz = F::zero();
     bool inf = true;
     uint32_t nent = e < end ? sorted[e] : 0u;
     while (e < end) {
         uint32_t ent = nent;
-        Fp x, y;
-        load_point(x, y, bases, ent);
+        E x, y;
+        load_point<C>(x, y, bases, ent);
         if (e + 1 < end) {
             nent = sorted[e + 1];
-            __builtin_prefetch(bases + (size_t)(nent & 0x7fffffffu) * G1_PT_WORDS, 0, 1);
+            __builtin_prefetch(bases + (size_t)(nent & 0x7fffffffu) * Geo<C>::PT_WORDS, 0, 1);
         }
-        y = fp28::fp_select((ent >> 31) != 0, y, fp28::fp_neg<4>(y));
+        y = F::select((ent >> 31) != 0, y, F::template neg<4>(y));
         if (inf) {
-            acc.x = x; acc.y = y; acc.zz = fp28::fp_one(); acc.zzz = fp28::fp_one();
+            acc.x = x; acc.y = y; acc.zz = F::one(); acc.zzz = F::one();
             inf = false;
-        } else if (ec::xyzz_madd<ACC_F>(reinterpret_cast<ec::Xyzz<ACC_F>&>(acc), x, y)) {
+        } else if (ec::xyzz_madd<FA>(acc, x, y)) {
             break;  // exceptional pair at entry e: acc untouched
         }
         e++;
     }
-    P1 out = ec::proj_inf<F1>();
-    if (!inf) out = ec::xyzz_to_proj<F1>(acc);
+    ec::Proj<F> out = ec::proj_inf<F>();
+    if (!inf) out = ec::xyzz_to_proj<F>(reinterpret_cast<const ec::Xyzz<F>&>(acc));
     while (e < end) {  // cold path (never taken on random inputs): complete additions
         uint32_t ent = sorted[e];
-        Fp x, y;
-        load_point(x, y, bases, ent);
-        y = fp28::fp_select((ent >> 31) != 0, y, fp28::fp_neg<4>(y));
-        P1 q = ec::proj_from_affine<F1>(x, y);
-        ec::proj_add<F1>(out, q);
+        E x, y;
+        load_point<C>(x, y, bases, ent);
+        y = F::select((ent >> 31) != 0, y, F::template neg<4>(y));
+        ec::Proj<F> q = ec::proj_from_affine<F>(x, y);
+        ec::proj_add<F>(out, q);  // shared-call multiplier: keeps the cold path out of the hot loop's register budget
         e++;
     }
-    store_bucket(partial + (size_t)i * G1_BK_WORDS, out);
+    store_bucket<C>(partial + (size_t)i * Geo<C>::BK_WORDS, out);
 }
 
 // One binary-tree level of the per-bucket merge of split buckets: partial[i] += partial[i + d] for the items whose
 // chunk index is a multiple of 2d.  After ceil(log2(max items)) levels partial[woff[b]] is bucket b.  Launched only
 // when some bucket was split (meta[1] > 1).
-__global__ void __launch_bounds__(256, 2) k_merge_g1(uint32_t* __restrict__ partial, const uint32_t* __restrict__ item_bucket,
-                                                     const uint32_t* __restrict__ woff, uint32_t nitems, uint32_t d) {
+template <class C>
+__global__ void __launch_bounds__(256, C::OCC) k_merge(uint32_t* __restrict__ partial, const uint32_t* __restrict__ item_bucket,
+                                                       const uint32_t* __restrict__ woff, uint32_t nitems, uint32_t d) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nitems) return;
     uint32_t b = item_bucket[i];
@@ -512,78 +577,76 @@ __global__ void __launch_bounds__(256, 2) k_merge_g1(uint32_t* __restrict__ part
     if (n <= d) return;
     uint32_t k = i - woff[b];
     if ((k & (2 * d - 1)) != 0 || k + d >= n) return;
-    P1 a = load_bucket(partial + (size_t)i * G1_BK_WORDS);
-    P1 c = load_bucket(partial + (size_t)(i + d) * G1_BK_WORDS);
-    ec::proj_add<F1>(a, c);
-    store_bucket(partial + (size_t)i * G1_BK_WORDS, a);
+    auto a = load_bucket<C>(partial + (size_t)i * Geo<C>::BK_WORDS);
+    auto c = load_bucket<C>(partial + (size_t)(i + d) * Geo<C>::BK_WORDS);
+    add_inplace(a, c);
+    store_bucket<C>(partial + (size_t)i * Geo<C>::BK_WORDS, a);
 }
 
 // ---------------------------------------------------------------------------------------------- reduce
-__device__ __forceinline__ Fp shfl_down_fp(const Fp& a, int d) {
-    Fp r;
-#pragma unroll
-    for (int k = 0; k < NL; k++) r.l[k] = __shfl_down(a.l[k], d, 64);
-    return r;
-}
-__device__ __forceinline__ P1 shfl_down_pt(const P1& a, int d) {
-    P1 r;
-    r.x = shfl_down_fp(a.x, d); r.y = shfl_down_fp(a.y, d); r.z = shfl_down_fp(a.z, d);
+template <class C>
+__device__ __forceinline__ ec::Proj<typename C::F> shfl_down_pt(const ec::Proj<typename C::F>& a, int d) {
+    using E = typename C::F::E;
+    ec::Proj<typename C::F> r;
+    r.x = ElemIO<E>::shfl_down(a.x, d); r.y = ElemIO<E>::shfl_down(a.y, d); r.z = ElemIO<E>::shfl_down(a.z, d);
     return r;
 }
 
-// projective (X : Y : Z) -> blst_p1 Jacobian words (X Z, Y Z^2, Z); infinity (Z == 0 mod p) -> all-zero
-__device__ __forceinline__ void store_jac_blst(uint32_t* out, const P1& p) {
-    uint32_t w[12];
-    fp28::fp_to_blst(w, p.z);
-    uint32_t any = 0;
-#pragma unroll
-    for (int k = 0; k < 12; k++) { out[24 + k] = w[k]; any |= w[k]; }
-    Fp zz = fp28::fp_mul_call(p.z, p.z);
-    fp28::fp_to_blst(w, fp28::fp_mul_call(p.x, p.z));
-#pragma unroll
-    for (int k = 0; k < 12; k++) out[k] = any ? w[k] : 0u;
-    fp28::fp_to_blst(w, fp28::fp_mul_call(p.y, zz));
-#pragma unroll
-    for (int k = 0; k < 12; k++) out[12 + k] = any ? w[k] : 0u;
+// projective (X : Y : Z) -> Jacobian in the reference's form (X Z, Y Z^2, Z); infinity (Z == 0 mod p) -> all-zero
+template <class C>
+__device__ __forceinline__ void store_jac_raw(uint32_t* out, const ec::Proj<typename C::F>& p) {
+    using F = typename C::F;
+    using E = typename F::E;
+    constexpr int R = ElemIO<E>::RAW;
+    uint32_t any = ElemIO<E>::to_raw(out + 2 * R, p.z, true);
+    E zz = F::mul(p.z, p.z);
+    ElemIO<E>::to_raw(out, F::mul(p.x, p.z), any != 0);
+    ElemIO<E>::to_raw(out + R, F::mul(p.y, zz), any != 0);
 }
 
 // One wave per chunk of 64*L consecutive buckets of one window (L = 2^logL).  Lane l owns buckets
 // [l*L, l*L+L) of the chunk.  Output per chunk: S = sum B, T = sum (rel+1) B with rel = index inside the chunk,
-// as two blst_p1 (36 words each).  All additions are the complete projective formulas: no exceptional cases.
-template <int WPS>
-__global__ void __launch_bounds__(64, WPS) k_reduce_g1(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ woff,
+// as two Jacobian points in the reference's form.  All additions are the complete projective formulas.
+template <class C>
+__global__ void __launch_bounds__(64, 1) k_reduce(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ woff,
                                                   uint32_t* __restrict__ pairs, uint32_t logL) {
+    using F = typename C::F;
+    using PJ = ec::Proj<F>;
     uint32_t chunk = blockIdx.x, lane = threadIdx.x;
     uint32_t L = 1u << logL;
     const uint32_t* wp = woff + (size_t)chunk * 64 * L + (size_t)lane * L;  // bucket b lives at partial[woff[b]]
-    P1 run = ec::proj_inf<F1>(), acc = ec::proj_inf<F1>();
+    PJ run = ec::proj_inf<F>(), acc = ec::proj_inf<F>();
 #pragma unroll 1
     for (int t = (int)L - 1; t >= 0; t--) {
-        P1 B = load_bucket(partial + (size_t)wp[t] * G1_BK_WORDS);
-        g1_add_inplace(run, B);
-        g1_add_inplace(acc, run);
+        PJ B = load_bucket<C>(partial + (size_t)wp[t] * Geo<C>::BK_WORDS);
+        add_inplace(run, B);
+        add_inplace(acc, run);
     }
     // suffix scan of the lane sums: P_l = sum_{j >= l} S_j
 #pragma unroll 1
     for (int d = 1; d < 64; d <<= 1) {
-        P1 Q = shfl_down_pt(run, d);
-        Q = ec::proj_select<F1>(lane + d < 64, ec::proj_inf<F1>(), Q);
-        g1_add_inplace(run, Q);
+        PJ Q = shfl_down_pt<C>(run, d);
+        Q = ec::proj_select<F>(lane + d < 64, ec::proj_inf<F>(), Q);
+        add_inplace(run, Q);
     }
     // V_l = T_l + L * P_l (l >= 1), V_0 = T_0 ; chunk T = sum_l V_l
-    P1 LP = run;
-    for (uint32_t i = 0; i < logL; i++) { P1 c2 = LP; g1_add_inplace(LP, c2); }
-    LP = ec::proj_select<F1>(lane == 0, LP, ec::proj_inf<F1>());
-    g1_add_inplace(acc, LP);
+    PJ LP = run;
+#pragma unroll 1
+    for (uint32_t i = 0; i < logL; i++) {
+        PJ c2 = LP;
+        add_inplace(LP, c2);
+    }
+    LP = ec::proj_select<F>(lane == 0, LP, ec::proj_inf<F>());
+    add_inplace(acc, LP);
 #pragma unroll 1
     for (int d = 32; d >= 1; d >>= 1) {
-        P1 Q = shfl_down_pt(acc, d);
-        Q = ec::proj_select<F1>((int)lane < d, ec::proj_inf<F1>(), Q);
-        g1_add_inplace(acc, Q);
+        PJ Q = shfl_down_pt<C>(acc, d);
+        Q = ec::proj_select<F>((int)lane < d, ec::proj_inf<F>(), Q);
+        add_inplace(acc, Q);
     }
     if (lane == 0) {
-        store_jac_blst(pairs + (size_t)chunk * 72, run);
-        store_jac_blst(pairs + (size_t)chunk * 72 + 36, acc);
+        store_jac_raw<C>(pairs + (size_t)chunk * 2 * Geo<C>::RAW_JAC, run);
+        store_jac_raw<C>(pairs + (size_t)chunk * 2 * Geo<C>::RAW_JAC + Geo<C>::RAW_JAC, acc);
     }
 }
 

@@ -144,3 +144,59 @@ def test_g1_msm_2_16_and_2_20_closed_form(ctx, co, pkg):
         p2 = ctx.msm("g1", bases[96 * h:], scalars[32 * h:], h, pkg.SCALAR_CANONICAL)
         assert _canon(co, "g1", pkg.g1_sum([p1, p2])) == _canon(co, "g1", got)
         print(f"n=2^{logn}", ctx.profile())
+
+
+# ------------------------------------------------------------------------------------------------ golden fixtures, G2
+import json
+import os
+
+
+def _golden():
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "msm_vectors.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_golden_vectors(ctx, co, pkg, group):
+    """Committed fixtures (tests/golden/msm_vectors.json): random sizes + every edge case, both scalar formats."""
+    for case in _golden()[group]:
+        n = case["n"]
+        bases, sc, scm = bytes.fromhex(case["bases"]), bytes.fromhex(case["scalars"]), bytes.fromhex(case["scalars_mont"])
+        want = bytes.fromhex(case["expected_affine"])
+        assert _canon(co, group, ctx.msm(group, bases, sc, n, pkg.SCALAR_CANONICAL)) == want, case["name"]
+        assert _canon(co, group, ctx.msm(group, bases, scm, n, pkg.SCALAR_MONTGOMERY)) == want, case["name"]
+
+
+@pytest.mark.parametrize("n", [1, 7, 300, 4096])
+def test_g2_msm_vs_oracle(ctx, co, pkg, n):
+    """G2 (Fp2) MSM — /root/reference/src/g2.rs:582-612 — against the oracle and the closed form."""
+    bases = co.gen_bases("g2", SEED_B + 7, n, 8)
+    scalars = co.gen_scalars(SEED_S + 7, n)
+    got = ctx.msm("g2", bases, scalars, n, pkg.SCALAR_CANONICAL)
+    want = co.msm("g2", bases, scalars, n, 0, 8)
+    assert _canon(co, "g2", got) == _canon(co, "g2", want) == co.dlog_expected("g2", scalars, SEED_B + 7, n)
+
+
+def test_g2_msm_skew_and_resident(ctx, co, o, pkg):
+    n = 3000
+    rnd = random.Random(9)
+    bases = co.gen_bases("g2", SEED_B + 8, n, 8)
+    s = rnd.randrange(o.R_ORDER)
+    ss = b"".join(o.fr_to_canon_bytes(s if rnd.randrange(3) else rnd.randrange(2)) for _ in range(n))
+    ctx.set_bases("g2", bases, n)
+    got = ctx.msm("g2", None, ss, n, pkg.SCALAR_CANONICAL)
+    assert _canon(co, "g2", got) == co.dlog_expected("g2", ss, SEED_B + 8, n)
+    assert ctx.profile()["max_items_per_bucket"] > 1
+    h = n // 2
+    p1 = ctx.msm("g2", bases[:192 * h], ss[:32 * h], h, pkg.SCALAR_CANONICAL)
+    p2 = ctx.msm("g2", bases[192 * h:], ss[32 * h:], n - h, pkg.SCALAR_CANONICAL)
+    assert _canon(co, "g2", pkg.g2_sum([p1, p2])) == _canon(co, "g2", got)
+
+
+def test_g2_msm_2_16_closed_form(ctx, co, pkg):
+    n = 1 << 16
+    bases = co.gen_bases("g2", SEED_B + 9, n, 16)
+    scalars = co.gen_scalars(SEED_S + 9, n)
+    got = ctx.msm("g2", bases, scalars, n, pkg.SCALAR_CANONICAL)
+    assert _canon(co, "g2", got) == co.dlog_expected("g2", scalars, SEED_B + 9, n)
+    print("g2 n=2^16", ctx.profile())
