@@ -63,13 +63,6 @@ Plan make_plan(size_t n, unsigned forced_c) {
         uint32_t nwin = (256 + c - 1) / c;
         double nb = (double)(1u << (c - 1));
         double cost = (double)n * nwin + 6.0 * nb * nwin;
-        // The top window holds only 255 - c (nwin - 1) significant bits: all n entries of that window fall into
-        // 2^top_bits buckets, i.e. into few coarse bins of the fine sort, each streamed by ONE workgroup
-        // (~22 addition-times per entry, measured).  Penalise window sizes whose top window is nearly empty.
-        int top_bits = 255 - (int)c * ((int)nwin - 1);
-        if (top_bits < 0) top_bits = 0;
-        double maxbin = (double)n / (double)(1u << std::max(0, std::min<int>(top_bits, (int)c - 1) - (int)lo_bits));
-        cost += 22.0 * maxbin;
         if (cost < best_cost) {
             best_cost = cost;
             best.c = c;
@@ -120,7 +113,7 @@ struct DevState {
     } res[2];
     // scratch
     DevBuf raw, call_bases, scalars, hist, offsets, woff, meta, sched, sorted, partial, order, item_bucket, pairs;
-    DevBuf tilecnt, bin_tot, bin_base, coarse;
+    DevBuf tilecnt, bin_tot, bin_base, coarse, seg_cnt, seg_base, segcnt;
     void* h_pairs = nullptr;
     size_t h_pairs_cap = 0;
     mi_profile prof{};
@@ -252,8 +245,20 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     hipLaunchKernelGGL(msmk::k_coarse<true>, dim3(g.tiles, g.ngroups), dim3(256), 0, s, d_scalars, d_bases, g, (uint32_t*)d.tilecnt.p,
                        (const uint32_t*)d.bin_base.p, (uint32_t*)d.coarse.p);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 1], s));
-    hipLaunchKernelGGL(msmk::k_fine_sort, dim3(g.nbins), dim3(256), 0, s, (const uint32_t*)d.coarse.p, (const uint32_t*)d.bin_base.p, g,
-                       (uint32_t*)d.sorted.p, (uint32_t*)d.hist.p);
+    // fine sort over bin segments (upper bound on the segment count: one per bin plus one per FINE_SEG entries)
+    uint32_t segs_cap = g.nbins + (uint32_t)(((size_t)n * pl.nwin) / msmk::FINE_SEG) + 1;
+    d.seg_cnt.ensure((size_t)g.nbins * 4);
+    d.seg_base.ensure((size_t)(g.nbins + 1) * 4);
+    d.segcnt.ensure((size_t)segs_cap * (1u << g.lo_bits) * 4);
+    hipLaunchKernelGGL(msmk::k_seg_count, dim3((g.nbins + 255) / 256), dim3(256), 0, s, (const uint32_t*)d.bin_base.p, g.nbins,
+                       (uint32_t*)d.seg_cnt.p);
+    hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.seg_cnt.p, g.nbins, (uint32_t*)d.seg_base.p);
+    hipLaunchKernelGGL(msmk::k_fine_count, dim3(segs_cap), dim3(256), 0, s, (const uint32_t*)d.coarse.p, (const uint32_t*)d.bin_base.p,
+                       (const uint32_t*)d.seg_base.p, g, (uint32_t*)d.segcnt.p);
+    hipLaunchKernelGGL(msmk::k_fine_scan, dim3(g.nbins), dim3(256), 0, s, (const uint32_t*)d.seg_base.p, g, (uint32_t*)d.segcnt.p,
+                       (uint32_t*)d.hist.p);
+    hipLaunchKernelGGL(msmk::k_fine_scatter, dim3(segs_cap), dim3(256), 0, s, (const uint32_t*)d.coarse.p, (const uint32_t*)d.bin_base.p,
+                       (const uint32_t*)d.seg_base.p, g, (const uint32_t*)d.segcnt.p, (uint32_t*)d.sorted.p);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 2], s));
     // ---- schedule: <= 256 blocks of 1024 lanes, each lane owning per_blk/1024 consecutive buckets
     uint32_t per_blk = 4096;
@@ -502,7 +507,7 @@ void mi_msm_destroy(mi_ctx* ctx) {
         (void)hipSetDevice(d.dev);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         for (DevBuf* b : {&d.res[0].buf, &d.res[1].buf, &d.raw, &d.call_bases, &d.scalars, &d.hist, &d.offsets, &d.woff, &d.meta, &d.sched, &d.sorted,
-                          &d.partial, &d.order, &d.item_bucket, &d.pairs, &d.tilecnt, &d.bin_tot, &d.bin_base, &d.coarse})
+                          &d.partial, &d.order, &d.item_bucket, &d.pairs, &d.tilecnt, &d.bin_tot, &d.bin_base, &d.coarse, &d.seg_cnt, &d.seg_base, &d.segcnt})
             b->release();
         if (d.h_pairs) (void)hipHostFree(d.h_pairs);
         for (auto& e : d.ev)

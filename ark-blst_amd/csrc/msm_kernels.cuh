@@ -232,7 +232,7 @@ __device__ __forceinline__ void for_each_digit(const uint32_t (&s)[8], uint32_t 
 //                              k_binscan        exclusive scan of the bin totals                     -> bin_base[bin]
 //                              k_coarse_scatter per tile: LDS cursors seeded with the scanned bases; entries
 //                                               (index | sign | lo) land in their coarse bin of `coarse`
-//   level 2 (LDS, fine):       k_fine_sort      one workgroup per coarse bin: LDS histogram of lo, scan, scatter
+//   level 2 (LDS, fine):       k_fine_count / k_fine_scan / k_fine_scatter over bin SEGMENTS (see below)
 //                                               -> sorted[] in (window, bucket) order and hist[window][bucket]
 // Windows are processed in groups of `wgroup` so that wgroup * H counters fit LDS (<= 8192 counters, 32 KB).
 struct SortGeom {
@@ -320,19 +320,79 @@ __global__ void __launch_bounds__(1024) k_binscan(const uint32_t* __restrict__ i
     if (t == 1023) out[m] = part[1023];
 }
 
-// one workgroup per coarse bin: sort its entries by lo in LDS-counter space, emit sorted[] and the bucket histogram
-__global__ void __launch_bounds__(256) k_fine_sort(const uint32_t* __restrict__ coarse, const uint32_t* __restrict__ bin_base,
-                                                   SortGeom g, uint32_t* __restrict__ sorted, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t cnt[256], scan[256];
-    uint32_t bin = blockIdx.x, t = threadIdx.x;
-    uint32_t beg = bin_base[bin], end = bin_base[bin + 1];
-    uint32_t F = 1u << g.lo_bits, lo_mask = F - 1u;
+// ---- level 2: fine sort.  A coarse bin is cut into SEGMENTS of at most FINE_SEG entries, one workgroup each, so a
+// heavy bin (skewed scalars; the short top window, whose n entries share a handful of buckets) is spread over
+// the chip instead of being streamed by a single workgroup (measured: 30 ms for two 8 M-entry bins at n = 2^24).
+//   k_seg_count   segments per bin                       -> seg_cnt[bin]      (then k_binscan -> seg_base[bin])
+//   k_fine_count  per segment: LDS histogram of lo       -> segcnt[seg][lo]
+//   k_fine_scan   per bin: scan over its segments and over lo -> segcnt becomes the start of (seg, lo) inside the
+//                 bin; emits hist[window][bucket]
+//   k_fine_scatter per segment: LDS cursors seeded from segcnt -> sorted[]
+constexpr uint32_t FINE_SEG = 8192;
+
+__global__ void __launch_bounds__(256) k_seg_count(const uint32_t* __restrict__ bin_base, uint32_t nbins, uint32_t* __restrict__ seg_cnt) {
+    uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nbins) return;
+    uint32_t sz = bin_base[b + 1] - bin_base[b];
+    seg_cnt[b] = sz == 0 ? 1u : (sz + FINE_SEG - 1) / FINE_SEG;
+}
+
+// segment id -> (bin, first entry, one-past-last entry); identity guess first (no bin split before it), else binary search
+__device__ __forceinline__ bool seg_locate(uint32_t seg, const uint32_t* seg_base, const uint32_t* bin_base, uint32_t nbins,
+                                           uint32_t& bin, uint32_t& beg, uint32_t& end) {
+    if (seg >= seg_base[nbins]) return false;
+    uint32_t b = seg < nbins ? seg : nbins - 1;
+    if (!(seg_base[b] <= seg && seg < seg_base[b + 1])) {
+        uint32_t lo = 0, hi = b;
+        while (lo < hi) {
+            uint32_t mid = (lo + hi + 1) >> 1;
+            if (seg_base[mid] <= seg) lo = mid; else hi = mid - 1;
+        }
+        b = lo;
+    }
+    uint32_t k = seg - seg_base[b];
+    bin = b;
+    beg = bin_base[b] + k * FINE_SEG;
+    uint32_t bend = bin_base[b + 1];
+    end = beg + FINE_SEG < bend ? beg + FINE_SEG : bend;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_fine_count(const uint32_t* __restrict__ coarse, const uint32_t* __restrict__ bin_base,
+                                                    const uint32_t* __restrict__ seg_base, SortGeom g, uint32_t* __restrict__ segcnt) {
+    __shared__ uint32_t cnt[256];
+    __shared__ uint32_t sb[3];
+    uint32_t t = threadIdx.x, seg = blockIdx.x;
+    if (t == 0) {
+        uint32_t bin = 0, beg = 0, end = 0;
+        bool ok = seg_locate(seg, seg_base, bin_base, g.nbins, bin, beg, end);
+        sb[0] = ok ? beg : 1u; sb[1] = ok ? end : 0u; sb[2] = ok ? 1u : 0u;
+    }
     cnt[t] = 0;
     __syncthreads();
+    if (!sb[2]) return;
+    uint32_t beg = sb[0], end = sb[1];
+    uint32_t F = 1u << g.lo_bits, lo_mask = F - 1u;
     for (uint32_t i = beg + t; i < end; i += 256) atomicAdd(&cnt[coarse[i] & lo_mask], 1u);
     __syncthreads();
-    uint32_t own = cnt[t];
-    scan[t] = own;
+    if (t < F) segcnt[(size_t)seg * F + t] = cnt[t];
+}
+
+// one workgroup per bin, lane = lo.  segcnt[seg][lo] <- offset of (seg, lo) relative to the bin start.
+__global__ void __launch_bounds__(256) k_fine_scan(const uint32_t* __restrict__ seg_base, SortGeom g, uint32_t* __restrict__ segcnt,
+                                                   uint32_t* __restrict__ hist) {
+    __shared__ uint32_t scan[256];
+    uint32_t bin = blockIdx.x, t = threadIdx.x;
+    uint32_t F = 1u << g.lo_bits;
+    uint32_t s0 = seg_base[bin], s1 = seg_base[bin + 1];
+    uint32_t tot = 0;
+    if (t < F)
+        for (uint32_t sg = s0; sg < s1; sg++) {
+            uint32_t v = segcnt[(size_t)sg * F + t];
+            segcnt[(size_t)sg * F + t] = tot;   // exclusive over the segments of this (bin, lo)
+            tot += v;
+        }
+    scan[t] = t < F ? tot : 0;
     __syncthreads();
     for (uint32_t d = 1; d < 256; d <<= 1) {
         uint32_t v = t >= d ? scan[t - d] : 0;
@@ -340,14 +400,34 @@ __global__ void __launch_bounds__(256) k_fine_sort(const uint32_t* __restrict__ 
         scan[t] += v;
         __syncthreads();
     }
-    if (t < F) hist[(size_t)bin * F + t] = own;      // bucket (window, hi, lo) has index bin * F + lo
+    if (t < F) {
+        hist[(size_t)bin * F + t] = tot;                 // bucket (window, hi, lo) has index bin * F + lo
+        uint32_t lo_base = scan[t] - tot;                // start of fine bucket lo inside the bin
+        for (uint32_t sg = s0; sg < s1; sg++) segcnt[(size_t)sg * F + t] += lo_base;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_fine_scatter(const uint32_t* __restrict__ coarse, const uint32_t* __restrict__ bin_base,
+                                                      const uint32_t* __restrict__ seg_base, SortGeom g,
+                                                      const uint32_t* __restrict__ segcnt, uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t cur[256];
+    __shared__ uint32_t sb[4];
+    uint32_t t = threadIdx.x, seg = blockIdx.x;
+    if (t == 0) {
+        uint32_t bin = 0, beg = 0, end = 0;
+        bool ok = seg_locate(seg, seg_base, bin_base, g.nbins, bin, beg, end);
+        sb[0] = beg; sb[1] = end; sb[2] = ok ? 1u : 0u; sb[3] = ok ? bin_base[bin] : 0u;
+    }
     __syncthreads();
-    cnt[t] = beg + scan[t] - own;                    // cursor: start of this fine bucket in sorted[]
+    if (!sb[2]) return;
+    uint32_t beg = sb[0], end = sb[1], bin_beg = sb[3];
+    uint32_t F = 1u << g.lo_bits, lo_mask = F - 1u;
+    cur[t] = t < F ? bin_beg + segcnt[(size_t)seg * F + t] : 0u;
     __syncthreads();
     uint32_t sh = g.lo_bits + 1;
     for (uint32_t i = beg + t; i < end; i += 256) {
         uint32_t e = coarse[i];
-        uint32_t pos = atomicAdd(&cnt[e & lo_mask], 1u);
+        uint32_t pos = atomicAdd(&cur[e & lo_mask], 1u);
         sorted[pos] = (e >> sh) | (((e >> g.lo_bits) & 1u) << 31);
     }
 }
@@ -568,7 +648,7 @@ __global__ void __launch_bounds__(256, C::OCC) k_accumulate(const uint32_t* __re
 // chunk index is a multiple of 2d.  After ceil(log2(max items)) levels partial[woff[b]] is bucket b.  Launched only
 // when some bucket was split (meta[1] > 1).
 template <class C>
-__global__ void __launch_bounds__(256, C::OCC) k_merge(uint32_t* __restrict__ partial, const uint32_t* __restrict__ item_bucket,
+__global__ void __launch_bounds__(256, 1) k_merge(uint32_t* __restrict__ partial, const uint32_t* __restrict__ item_bucket,
                                                        const uint32_t* __restrict__ woff, uint32_t nitems, uint32_t d) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nitems) return;

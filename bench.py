@@ -41,7 +41,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=20, help="log2 of points PER GPU")
-    ap.add_argument("--group", default="g1", choices=["g1"])
+    ap.add_argument("--group", default="g1", choices=["g1", "g2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
     args = ap.parse_args()
@@ -83,7 +83,8 @@ def main() -> None:
     d_scalars = torch.frombuffer(bytearray(scalars), dtype=torch.uint8).cuda()
     torch.cuda.synchronize()
 
-    gather = [torch.empty(144, dtype=torch.uint8, device="cuda") for _ in range(world)] if world > 1 else None
+    jac_bytes = 144 if g == "g1" else 288
+    gather = [torch.empty(jac_bytes, dtype=torch.uint8, device="cuda") for _ in range(world)] if world > 1 else None
 
     def step() -> bytes:
         part = ctx.msm_device(g, d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)
@@ -91,7 +92,7 @@ def main() -> None:
             return part
         mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).cuda()
         dist.all_gather(gather, mine)                       # RCCL over xGMI: N x 144 B
-        return pkg.g1_sum([t.cpu().numpy().tobytes() for t in gather])   # fold in rank order on every rank
+        return (pkg.g1_sum if g == "g1" else pkg.g2_sum)([t.cpu().numpy().tobytes() for t in gather])   # fold in rank order on every rank
 
     def fence():
         if world > 1:
@@ -126,7 +127,8 @@ def main() -> None:
     bit_exact = None
     if rank == 0:
         # lift each shard's expected affine point to Jacobian (x, y, 1) and add them up
-        jac = b"".join((e + _mont_one()) if e != bytes(aff) else bytes(aff + 48) for e in expected_parts)
+        zc = _mont_one() if g == "g1" else _mont_one() + bytes(48)   # Z = 1 (Fp) or 1 + 0u (Fp2)
+        jac = b"".join((e + zc) if e != bytes(aff) else bytes(aff + len(zc)) for e in expected_parts)
         want = co.to_affine(g, co.sum_jac(g, jac, world))
         bit_exact = co.to_affine(g, result) == want
 
@@ -139,7 +141,7 @@ def main() -> None:
         alg_bytes = ALG_BYTES_PER_POINT[g] * n
         achieved_gbs = alg_bytes / (acc_ms * 1e-3) / 1e9
         out = {
-            "metric": "G1 MSM points/sec",
+            "metric": f"{g.upper()} MSM points/sec",
             "value": value,
             "unit": "points/s",
             "n_gpus": world,
@@ -149,13 +151,14 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 (14 x 28-bit limbs, 64-bit MAD accumulation)",
+            "dtype": "u32",
             "data": "synthetic",
             "bit_exact": bit_exact,
-            "config": {"workload": f"G1 MSM, 2^{args.log_n} random bases+scalars per GPU, bases resident, scalars in HBM",
+            "config": {"workload": f"{g.upper()} MSM, 2^{args.log_n} random bases+scalars per GPU, bases resident, scalars in HBM",
                        "points_per_gpu": n, "total_points": total_points, "window_bits": p0["window_bits"],
-                       "num_windows": p0["num_windows"], "parallelism": f"base-set sharded x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_accumulate_g1", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
+                       "num_windows": p0["num_windows"], "parallelism": f"base-set sharded x{world}",
+                       "field_repr": "14 x 28-bit limbs in u32, products accumulated with v_mad_u64_u32"},
+            "roofline": {"bound": "hbm", "kernel": f"k_accumulate<{g.upper()}C>", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms},
             "valu_roofline": {"model_mads_per_point": MADS_PER_POINT[g],
