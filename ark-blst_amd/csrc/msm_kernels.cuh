@@ -94,11 +94,13 @@ template <> struct ElemIO<ec::Fp2> {
 struct G1C {                         // /root/reference/src/g1.rs: G1Affine / G1Projective over Fp
     using F = ec::FpOps;             // shared-call multiplier: everything outside the hot loop
     using FA = ec::FpOpsInline;      // accumulate hot loop
+    using FR = ec::FpOpsInline;      // the single addition site of the reduce loop
     static constexpr int OCC = 2;    // waves per SIMD the accumulate kernel is built for
 };
 struct G2C {                         // /root/reference/src/g2.rs: G2Affine / G2Projective over Fp2
     using F = ec::Fp2Ops;
     using FA = ec::Fp2Ops;           // 4 x 28 limbs per Xyzz coordinate pair: the shared bodies keep code and registers in check
+    using FR = ec::Fp2Ops;
     static constexpr int OCC = 2;
 };
 template <class C> struct Geo {
@@ -687,42 +689,61 @@ __device__ __forceinline__ void store_jac_raw(uint32_t* out, const ec::Proj<type
 // One wave per chunk of 64*L consecutive buckets of one window (L = 2^logL).  Lane l owns buckets
 // [l*L, l*L+L) of the chunk.  Output per chunk: S = sum B, T = sum (rel+1) B with rel = index inside the chunk,
 // as two Jacobian points in the reference's form.  All additions are the complete projective formulas.
+//
+// The whole reduction is ONE loop with ONE inlined addition site: the operands of step s are selected by the
+// (wave-uniform) step number.  An out-of-line addition would pass its 2 x 42 limbs through scratch (the AMDGPU
+// calling convention puts large structs on the stack): measured 568 MB of scratch writes per launch and ~15 % of
+// the kernel time; five inlined sites would be 5 x 55 KB of code.  Steps:
+//   [0, 2L)            t = L-1 .. 0 :  run += B_t ;  acc += run          (lane-serial running sums)
+//   [2L, 2L+6)         run += shfl_down(run, 1, 2, 4, .., 32)             (suffix scan: run_l = sum_{j>=l} S_j)
+//   [.., +logL)        LP = 2 LP  (LP starts as run)                      (L * P_l)
+//   one step           acc += (lane == 0 ? inf : LP)                      (V_l = T_l + L P_l)
+//   six steps          acc += shfl_down(acc, 32, 16, .., 1)               (sum over lanes)
 template <class C>
 __global__ void __launch_bounds__(64, 1) k_reduce(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ woff,
                                                   uint32_t* __restrict__ pairs, uint32_t logL) {
     using F = typename C::F;
+    using FR = typename C::FR;
     using PJ = ec::Proj<F>;
+    using PR = ec::Proj<FR>;
     uint32_t chunk = blockIdx.x, lane = threadIdx.x;
     uint32_t L = 1u << logL;
     const uint32_t* wp = woff + (size_t)chunk * 64 * L + (size_t)lane * L;  // bucket b lives at partial[woff[b]]
-    PJ run = ec::proj_inf<F>(), acc = ec::proj_inf<F>();
+    PJ run = ec::proj_inf<F>(), acc = ec::proj_inf<F>(), LP = ec::proj_inf<F>();
+    const uint32_t s_scan = 2 * L, s_dbl = s_scan + 6, s_comb = s_dbl + logL, s_end = s_comb + 7;
 #pragma unroll 1
-    for (int t = (int)L - 1; t >= 0; t--) {
-        PJ B = load_bucket<C>(partial + (size_t)wp[t] * Geo<C>::BK_WORDS);
-        add_inplace(run, B);
-        add_inplace(acc, run);
-    }
-    // suffix scan of the lane sums: P_l = sum_{j >= l} S_j
-#pragma unroll 1
-    for (int d = 1; d < 64; d <<= 1) {
-        PJ Q = shfl_down_pt<C>(run, d);
-        Q = ec::proj_select<F>(lane + d < 64, ec::proj_inf<F>(), Q);
-        add_inplace(run, Q);
-    }
-    // V_l = T_l + L * P_l (l >= 1), V_0 = T_0 ; chunk T = sum_l V_l
-    PJ LP = run;
-#pragma unroll 1
-    for (uint32_t i = 0; i < logL; i++) {
-        PJ c2 = LP;
-        add_inplace(LP, c2);
-    }
-    LP = ec::proj_select<F>(lane == 0, LP, ec::proj_inf<F>());
-    add_inplace(acc, LP);
-#pragma unroll 1
-    for (int d = 32; d >= 1; d >>= 1) {
-        PJ Q = shfl_down_pt<C>(acc, d);
-        Q = ec::proj_select<F>((int)lane < d, ec::proj_inf<F>(), Q);
-        add_inplace(acc, Q);
+    for (uint32_t s = 0; s < s_end; s++) {
+        PJ A, B;
+        uint32_t dst;  // 0 run, 1 acc, 2 LP
+        if (s < s_scan) {
+            if ((s & 1u) == 0) {
+                A = run; B = load_bucket<C>(partial + (size_t)wp[L - 1 - (s >> 1)] * Geo<C>::BK_WORDS); dst = 0;
+            } else {
+                A = acc; B = run; dst = 1;
+            }
+        } else if (s < s_dbl) {
+            int d = 1 << (s - s_scan);
+            A = run;
+            B = ec::proj_select<F>(lane + d < 64, ec::proj_inf<F>(), shfl_down_pt<C>(run, d));
+            dst = 0;
+        } else if (s < s_comb) {
+            if (s == s_dbl) LP = run;
+            A = LP; B = LP; dst = 2;
+        } else if (s == s_comb) {
+            if (logL == 0) LP = run;
+            A = acc;
+            B = ec::proj_select<F>(lane == 0, LP, ec::proj_inf<F>());
+            dst = 1;
+        } else {
+            int d = 32 >> (s - s_comb - 1);
+            A = acc;
+            B = ec::proj_select<F>((int)lane < d, ec::proj_inf<F>(), shfl_down_pt<C>(acc, d));
+            dst = 1;
+        }
+        ec::proj_add<FR>(reinterpret_cast<PR&>(A), reinterpret_cast<const PR&>(B));
+        if (dst == 0) run = A;
+        else if (dst == 1) acc = A;
+        else LP = A;
     }
     if (lane == 0) {
         store_jac_raw<C>(pairs + (size_t)chunk * 2 * Geo<C>::RAW_JAC, run);
