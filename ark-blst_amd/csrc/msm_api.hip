@@ -63,6 +63,11 @@ Plan make_plan(size_t n, unsigned forced_c) {
         uint32_t nwin = (256 + c - 1) / c;
         double nb = (double)(1u << (c - 1));
         double cost = (double)n * nwin + 6.0 * nb * nwin;
+        // The top window holds only 255 - c (nwin - 1) significant bits, so its n entries share 2^top_bits buckets;
+        // buckets beyond T entries are split and merged by a binary tree: ~0.1 ms (~6e5 addition-times) per level.
+        int top_bits = std::max(0, std::min<int>(255 - (int)c * ((int)nwin - 1), (int)c - 1));
+        double per_bucket = (double)n / (double)(1u << top_bits), mean = std::max(1.0, (double)n / nb);
+        for (double x = per_bucket; x > 2.0 * mean; x *= 0.5) cost += 6e5;
         if (cost < best_cost) {
             best_cost = cost;
             best.c = c;
@@ -113,7 +118,7 @@ struct DevState {
     } res[2];
     // scratch
     DevBuf raw, call_bases, scalars, hist, offsets, woff, meta, sched, sorted, partial, order, item_bucket, pairs;
-    DevBuf tilecnt, bin_tot, bin_base, coarse, seg_cnt, seg_base, segcnt;
+    DevBuf tilecnt, bin_tot, bin_base, coarse, seg_cnt, seg_base, segcnt, merge_list;
     void* h_pairs = nullptr;
     size_t h_pairs_cap = 0;
     mi_profile prof{};
@@ -268,6 +273,7 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     d.sched.ensure((size_t)(3 + msmk::SCHED_CLASSES) * nblk * 4);
     d.order.ensure(items_cap * 4);
     d.item_bucket.ensure(items_cap * 4);
+    d.merge_list.ensure(items_cap * 4);
     uint32_t* blk_e = (uint32_t*)d.sched.p;
     uint32_t* blk_i = blk_e + nblk;
     uint32_t* blk_max = blk_i + nblk;
@@ -278,10 +284,11 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
                        (uint32_t*)d.meta.p);
     hipLaunchKernelGGL(msmk::k_sched3, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT,
                        nblk, (const uint32_t*)blk_e, (const uint32_t*)blk_i, (const uint32_t*)blk_cls, (uint32_t*)d.offsets.p,
-                       (uint32_t*)d.woff.p, (uint32_t*)d.order.p, (uint32_t*)d.item_bucket.p);
+                       (uint32_t*)d.woff.p, (uint32_t*)d.order.p, (uint32_t*)d.item_bucket.p, (uint32_t*)d.merge_list.p,
+                       (uint32_t*)d.meta.p);
     // the item count sizes the next launches: one small read-back (the only mid-pipeline sync)
     uint32_t meta[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(meta, d.meta.p, 12, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(meta, d.meta.p, 16, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(d.ev[ev0 + 3], s));
     HIP_TRY(hipStreamSynchronize(s));
     uint32_t nitems = meta[0], max_items = meta[1];
@@ -290,9 +297,10 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     hipLaunchKernelGGL(msmk::k_accumulate<C>, dim3(grid_items), dim3(256), 0, s, d_bases, (const uint32_t*)d.sorted.p,
                        (const uint32_t*)d.offsets.p, (const uint32_t*)d.woff.p, (const uint32_t*)d.order.p,
                        (const uint32_t*)d.item_bucket.p, nitems, pl.logT, (uint32_t*)d.partial.p);
-    for (uint32_t dd = 1; dd < max_items; dd <<= 1)
-        hipLaunchKernelGGL(msmk::k_merge<C>, dim3(grid_items), dim3(256), 0, s, (uint32_t*)d.partial.p, (const uint32_t*)d.item_bucket.p,
-                           (const uint32_t*)d.woff.p, nitems, dd);
+    uint32_t nlist = meta[3];
+    for (uint32_t dd = 1; dd < max_items && nlist; dd <<= 1)
+        hipLaunchKernelGGL(msmk::k_merge<C>, dim3((nlist + 255) / 256), dim3(256), 0, s, (uint32_t*)d.partial.p,
+                           (const uint32_t*)d.item_bucket.p, (const uint32_t*)d.woff.p, (const uint32_t*)d.merge_list.p, nlist, dd);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 4], s));
     hipLaunchKernelGGL(msmk::k_reduce<C>, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
                        (const uint32_t*)d.woff.p, (uint32_t*)d.pairs.p, pl.logL);
@@ -507,7 +515,7 @@ void mi_msm_destroy(mi_ctx* ctx) {
         (void)hipSetDevice(d.dev);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         for (DevBuf* b : {&d.res[0].buf, &d.res[1].buf, &d.raw, &d.call_bases, &d.scalars, &d.hist, &d.offsets, &d.woff, &d.meta, &d.sched, &d.sorted,
-                          &d.partial, &d.order, &d.item_bucket, &d.pairs, &d.tilecnt, &d.bin_tot, &d.bin_base, &d.coarse, &d.seg_cnt, &d.seg_base, &d.segcnt})
+                          &d.partial, &d.order, &d.item_bucket, &d.pairs, &d.tilecnt, &d.bin_tot, &d.bin_base, &d.coarse, &d.seg_cnt, &d.seg_base, &d.segcnt, &d.merge_list})
             b->release();
         if (d.h_pairs) (void)hipHostFree(d.h_pairs);
         for (auto& e : d.ev)

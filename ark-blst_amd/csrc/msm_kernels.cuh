@@ -531,6 +531,7 @@ __global__ void __launch_bounds__(1024) k_sched2(uint32_t nblk, uint32_t* __rest
         meta[0] = b[255];  // total items   (a[], b[] are inclusive scans; entries past nblk are zero)
         meta[1] = mx;      // max items of any bucket
         meta[2] = a[255];  // total entries
+        meta[3] = 0;       // merge-list length, filled by k_sched3
     }
 }
 
@@ -539,7 +540,8 @@ __global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hi
                                                  uint32_t nblk, const uint32_t* __restrict__ blk_e, const uint32_t* __restrict__ blk_i,
                                                  const uint32_t* __restrict__ blk_cls, uint32_t* __restrict__ offsets,
                                                  uint32_t* __restrict__ woff,
-                                                 uint32_t* __restrict__ order, uint32_t* __restrict__ item_bucket) {
+                                                 uint32_t* __restrict__ order, uint32_t* __restrict__ item_bucket,
+                                                 uint32_t* __restrict__ merge_list, uint32_t* __restrict__ meta) {
     __shared__ uint32_t pe[1024], pi[1024], cur[SCHED_CLASSES];
     uint32_t t = threadIdx.x, blk = blockIdx.x;
     if (t < SCHED_CLASSES) cur[t] = blk_cls[t * nblk + blk];
@@ -569,6 +571,8 @@ __global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hi
         if (it > 1) {  // full-length chunks of a split bucket: one reservation in the longest class
             uint32_t pos = atomicAdd(&cur[64], it - 1);
             for (uint32_t j = 0; j + 1 < it; j++) { order[pos + j] = run_i + j; item_bucket[run_i + j] = k; }
+            uint32_t mp = atomicAdd(&meta[3], it);     // the merge passes only visit the items of split buckets
+            for (uint32_t j = 0; j < it; j++) merge_list[mp + j] = run_i + j;
         }
         uint32_t last = run_i + it - 1;
         uint32_t pos = atomicAdd(&cur[class_of(h - (it - 1) * T, logT)], 1u);
@@ -648,12 +652,14 @@ __global__ void __launch_bounds__(256, C::OCC) k_accumulate(const uint32_t* __re
 
 // One binary-tree level of the per-bucket merge of split buckets: partial[i] += partial[i + d] for the items whose
 // chunk index is a multiple of 2d.  After ceil(log2(max items)) levels partial[woff[b]] is bucket b.  Launched only
-// when some bucket was split (meta[1] > 1).
+// when some bucket was split (meta[1] > 1), over the items of split buckets only (merge_list, meta[3] entries).
 template <class C>
 __global__ void __launch_bounds__(256, 1) k_merge(uint32_t* __restrict__ partial, const uint32_t* __restrict__ item_bucket,
-                                                       const uint32_t* __restrict__ woff, uint32_t nitems, uint32_t d) {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nitems) return;
+                                                       const uint32_t* __restrict__ woff, const uint32_t* __restrict__ merge_list,
+                                                       uint32_t nlist, uint32_t d) {
+    uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nlist) return;
+    uint32_t i = merge_list[j];
     uint32_t b = item_bucket[i];
     uint32_t n = woff[b + 1] - woff[b];
     if (n <= d) return;
