@@ -44,6 +44,9 @@ def main() -> None:
     ap.add_argument("--group", default="g1", choices=["g1", "g2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --share-device rehearses the N>1 path on a single-GPU box")
+    ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (rehearsal only)")
     args = ap.parse_args()
 
     import torch  # plumbing only: device buffers, synchronize, torch.distributed (RCCL)
@@ -56,9 +59,15 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the MSM path")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    on_gpu = args.backend == "nccl"   # collectives on device tensors (RCCL) or on host tensors (gloo rehearsal)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     import __graft_entry__ as ge
     from oracle import coracle as co   # input generation, checker, cpu_baseline only
@@ -84,13 +93,14 @@ def main() -> None:
     torch.cuda.synchronize()
 
     jac_bytes = 144 if g == "g1" else 288
-    gather = [torch.empty(jac_bytes, dtype=torch.uint8, device="cuda") for _ in range(world)] if world > 1 else None
+    cdev = "cuda" if on_gpu else "cpu"
+    gather = [torch.empty(jac_bytes, dtype=torch.uint8, device=cdev) for _ in range(world)] if world > 1 else None
 
     def step() -> bytes:
         part = ctx.msm_device(g, d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)
         if world == 1:
             return part
-        mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).cuda()
+        mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(cdev)
         dist.all_gather(gather, mine)                       # RCCL over xGMI: N x 144 B
         return (pkg.g1_sum if g == "g1" else pkg.g2_sum)([t.cpu().numpy().tobytes() for t in gather])   # fold in rank order on every rank
 
@@ -111,7 +121,7 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -119,8 +129,8 @@ def main() -> None:
     expected_parts = []
     mine_expected = co.dlog_expected(g, scalars, seed_b, n)          # affine bytes of this rank's shard
     if world > 1:
-        buf = [torch.empty(aff, dtype=torch.uint8, device="cuda") for _ in range(world)]
-        dist.all_gather(buf, torch.frombuffer(bytearray(mine_expected), dtype=torch.uint8).cuda())
+        buf = [torch.empty(aff, dtype=torch.uint8, device=cdev) for _ in range(world)]
+        dist.all_gather(buf, torch.frombuffer(bytearray(mine_expected), dtype=torch.uint8).to(cdev))
         expected_parts = [t.cpu().numpy().tobytes() for t in buf]
     else:
         expected_parts = [mine_expected]
@@ -140,6 +150,17 @@ def main() -> None:
         p0 = prof_acc[-1]
         alg_bytes = ALG_BYTES_PER_POINT[g] * n
         achieved_gbs = alg_bytes / (acc_ms * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel: measured with rocprofv3 PMC passes (tools/profile_bench.sh) on this exact
+        # workload and committed under profiles/; bench.py cannot collect counters itself.
+        traffic, traffic_src = None, None
+        try:
+            prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
+            if prof and g == "g1" and args.log_n == 20:
+                pj = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
+                traffic = pj["kernels"]["msmk::k_accumulate<msmk::G1C>"]["hbm_bytes_per_launch_corrected"]
+                traffic_src = "profiles/" + prof[-1]
+        except Exception:
+            pass
         out = {
             "metric": f"{g.upper()} MSM points/sec",
             "value": value,
@@ -159,8 +180,10 @@ def main() -> None:
                        "num_windows": p0["num_windows"], "parallelism": f"base-set sharded x{world}",
                        "field_repr": "14 x 28-bit limbs in u32, products accumulated with v_mad_u64_u32"},
             "roofline": {"bound": "hbm", "kernel": f"k_accumulate<{g.upper()}C>", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms},
+                         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms,
+                         "note": "the bucket method re-reads each 128-B device point once per window (16x at c=16): "
+                                 "traffic ~ 16 x algorithmic by design; the kernel is VALU-bound, see valu_roofline"},
             "valu_roofline": {"model_mads_per_point": MADS_PER_POINT[g],
                               "achieved_Tmad_s": MADS_PER_POINT[g] * n / (acc_ms * 1e-3) / 1e12,
                               "peak_Tmad_s": MAD_PEAK_TLOPS,
