@@ -182,27 +182,56 @@ void ingest(DevState& d, const void* bases, bool bases_on_device, size_t n, DevB
 // Host tail: combine chunk sums per window and Horner-fold the windows (cf. /root/reference/src/gpu.rs:193-209).
 template <class J>
 J host_fold(mi_ctx* ctx, const J* pairs, const Plan& pl) {
-    std::vector<J> win(pl.nwin);
-    auto do_window = [&](unsigned w) {
-        const J* p = pairs + (size_t)w * pl.chunks_per_win * 2;
+    // window sum = sum_j T_j + (64 L) * sum_j j * S_j over its chunks j.  The chunk range of a window is cut into
+    // `parts` sub-ranges so that windows x parts work units keep the pool busy: for a sub-range [a, b)
+    //   sum_{j in [a,b)} j S_j = W_ab + a * S_ab,  W_ab = sum (j - a) S_j (running sums),  S_ab = sum S_j.
+    const uint32_t cpw = pl.chunks_per_win;
+    uint32_t parts = 1;
+    while (parts < 8 && cpw / (parts * 2) >= 16 && pl.nwin * parts < 48) parts *= 2;
+    const uint32_t seg = (cpw + parts - 1) / parts;
+    struct Part { J w, s, t; };
+    std::vector<Part> part((size_t)pl.nwin * parts);
+    auto do_part = [&](unsigned u) {
+        uint32_t w = u / parts, q = u % parts;
+        const J* p = pairs + (size_t)w * cpw * 2;
+        uint32_t a = q * seg, b = std::min(cpw, a + seg);
         J run = J::inf(), acc = J::inf(), tsum = J::inf();
-        for (int j = (int)pl.chunks_per_win - 1; j >= 0; j--) {
+        for (int j = (int)b - 1; j >= (int)a; j--) {
             tsum = tsum.add(p[2 * j + 1]);
-            if (j >= 1) {
+            if (j > (int)a) {
                 run = run.add(p[2 * j]);
                 acc = acc.add(run);
             }
         }
-        win[w] = acc.dbl_n(6 + pl.logL).add(tsum);
+        J sab = a < b ? run.add(p[2 * a]) : J::inf();
+        part[u] = Part{acc, sab, tsum};
     };
-    size_t work = (size_t)pl.nwin * pl.chunks_per_win;
+    size_t work = (size_t)pl.nwin * cpw;
     if (work >= 128 && ctx->pool && ctx->devs.size() == 1) {
-        ctx->pool->parallel_for(pl.nwin, do_window);
+        ctx->pool->parallel_for(pl.nwin * parts, do_part);
     } else {
-        for (uint32_t w = 0; w < pl.nwin; w++) do_window(w);
+        for (uint32_t u = 0; u < pl.nwin * parts; u++) do_part(u);
     }
+    // seg is a power of two whenever parts > 1 (chunks_per_win is): a * S = (q * seg) * S by doublings
+    unsigned log_seg = 0;
+    while ((1u << log_seg) < seg) log_seg++;
     J r = J::inf();
-    for (int w = (int)pl.nwin - 1; w >= 0; w--) r = r.dbl_n(pl.c).add(win[w]);
+    for (int w = (int)pl.nwin - 1; w >= 0; w--) {
+        // sum_q [W_q + q * seg * S_q] = sum_q W_q + seg * sum_q q S_q
+        J wsum = J::inf(), tsum = J::inf(), run = J::inf(), qs = J::inf();
+        for (int q = (int)parts - 1; q >= 0; q--) {
+            const Part& pt = part[(size_t)w * parts + q];
+            wsum = wsum.add(pt.w);
+            tsum = tsum.add(pt.t);
+            if (q >= 1) {
+                run = run.add(pt.s);
+                qs = qs.add(run);
+            }
+        }
+        J win = parts > 1 ? wsum.add(qs.dbl_n(log_seg)) : wsum;
+        win = win.dbl_n(6 + pl.logL).add(tsum);
+        r = r.dbl_n(pl.c).add(win);
+    }
     return r;
 }
 
@@ -483,7 +512,7 @@ int mi_msm_init(mi_ctx** out, const int* device_ids, int n_devices) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MI_E_NO_DEVICE;
     if (n_devices == 0) n_devices = device_ids ? 0 : count;
-    if (n_devices <= 0 || n_devices > count) return MI_E_NO_DEVICE;
+    if (n_devices <= 0 || (!device_ids && n_devices > count) || n_devices > 64) return MI_E_NO_DEVICE;
     mi_ctx* ctx = new (std::nothrow) mi_ctx();
     if (!ctx) return MI_E_NOMEM;
     int rc = guarded(ctx, [&]() -> int {

@@ -236,7 +236,7 @@ __device__ __forceinline__ void for_each_digit(const uint32_t (&s)[8], uint32_t 
 //                                               (index | sign | lo) land in their coarse bin of `coarse`
 //   level 2 (LDS, fine):       k_fine_count / k_fine_scan / k_fine_scatter over bin SEGMENTS (see below)
 //                                               -> sorted[] in (window, bucket) order and hist[window][bucket]
-// Windows are processed in groups of `wgroup` so that wgroup * H counters fit LDS (<= 8192 counters, 32 KB).
+// Windows are processed in groups of `wgroup` so that wgroup * H counters fit LDS (<= 16384 counters, 64 KB).
 struct SortGeom {
     uint32_t n, fmt, c, nwin, pt_words;
     uint32_t lo_bits, H;          // fine bits, coarse bins per window
@@ -244,7 +244,7 @@ struct SortGeom {
     uint32_t wgroup, ngroups;     // windows per group, groups (grid.y)
     uint32_t nbins;               // nwin * H
 };
-constexpr uint32_t SORT_MAX_COUNTERS = 8192;
+constexpr uint32_t SORT_MAX_COUNTERS = 16384;  // 64 KB of LDS counters per workgroup (2 workgroups per CU)
 
 // entry in `coarse`: (point index << (lo_bits+1)) | (negative << lo_bits) | lo
 template <bool SCATTER>

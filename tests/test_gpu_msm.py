@@ -200,3 +200,36 @@ def test_g2_msm_2_16_closed_form(ctx, co, pkg):
     got = ctx.msm("g2", bases, scalars, n, pkg.SCALAR_CANONICAL)
     assert _canon(co, "g2", got) == co.dlog_expected("g2", scalars, SEED_B + 9, n)
     print("g2 n=2^16", ctx.profile())
+
+
+def test_in_library_multi_device_sharding(pkg, co):
+    """mi_msm_init with several device ids: contiguous shards per device, one host thread each, partials folded in
+    device order.  A one-GPU box exercises the same code with device 0 listed twice (two streams, two shards)."""
+    n = 5001
+    bases = co.gen_bases("g1", SEED_B + 11, n, 8)
+    scalars = co.gen_scalars(SEED_S + 11, n)
+    with pkg.Context([0, 0, 0]) as c3:
+        assert c3.num_devices() == 3
+        got = c3.msm("g1", bases, scalars, n, pkg.SCALAR_CANONICAL)
+        assert _canon(co, "g1", got) == co.dlog_expected("g1", scalars, SEED_B + 11, n)
+        c3.set_bases("g1", bases, n)
+        for m in (n, 1700, 3):   # prefixes that end inside the first / second / third shard
+            got = c3.msm("g1", None, scalars, m, pkg.SCALAR_CANONICAL)
+            assert _canon(co, "g1", got) == co.dlog_expected("g1", scalars, SEED_B + 11, m)
+        b2 = co.gen_bases("g2", SEED_B + 12, 700, 8)
+        got = c3.msm("g2", b2, scalars, 700, pkg.SCALAR_CANONICAL)
+        assert _canon(co, "g2", got) == co.dlog_expected("g2", scalars, SEED_B + 12, 700)
+
+
+def test_error_paths(ctx, pkg):
+    with pytest.raises(pkg.MsmError) as e:
+        ctx2 = pkg.Context([0])
+        try:
+            ctx2.msm("g1", None, bytes(32), 1, pkg.SCALAR_CANONICAL)   # no resident bases
+        finally:
+            ctx2.close()
+    assert e.value.code == -5
+    with pytest.raises(pkg.MsmError):
+        ctx.msm("g1", bytes(96), bytes(32), 1, 7)                      # unknown scalar format
+    with pytest.raises(pkg.MsmError):
+        ctx.set_window_bits(3)
