@@ -99,8 +99,8 @@ struct G1C {                         // /root/reference/src/g1.rs: G1Affine / G1
 };
 struct G2C {                         // /root/reference/src/g2.rs: G2Affine / G2Projective over Fp2
     using F = ec::Fp2Ops;
-    using FA = ec::Fp2Ops;           // 4 x 28 limbs per Xyzz coordinate pair: the shared bodies keep code and registers in check
-    using FR = ec::Fp2Ops;
+    using FA = ec::Fp2OpsInline;     // measured at 2^18: accumulate 2.25 vs 5.05 ms against the shared bodies (despite spills)
+    using FR = ec::Fp2OpsInline;     // reduce 2.28 vs 3.93 ms
     static constexpr int OCC = 2;
 };
 template <class C> struct Geo {
@@ -597,7 +597,8 @@ __device__ __forceinline__ void load_point(typename C::F::E& x, typename C::F::E
 // sorted[offsets[b] + k*T .. min(offsets[b] + (k+1)*T, offsets[b+1])), k = i - woff[b]; entries are (index | sign<<31).
 // Hot loop: XYZZ mixed additions.  Register budget is the constraint (256 VGPRs at 2 waves/SIMD), so the next
 // point is not staged in registers: its index is fetched one iteration ahead and its line(s) touched early so the
-// real load hits L2; the other resident wave covers what latency is left.
+// real load hits L2; the other resident wave covers what latency is left (staging the next point in 28 more
+// registers was measured slower: 3.06 vs 2.88 ms, it pushes the loop into scratch spills).
 // A lane that meets an exceptional pair (same x) leaves the hot loop and finishes on the complete formulas.
 // Output: partial[i] (projective), i = natural item id.
 template <class C>
