@@ -94,15 +94,18 @@ def main() -> None:
 
     jac_bytes = 144 if g == "g1" else 288
     cdev = "cuda" if on_gpu else "cpu"
-    gather = [torch.empty(jac_bytes, dtype=torch.uint8, device=cdev) for _ in range(world)] if world > 1 else None
+    gather = torch.empty(world * jac_bytes, dtype=torch.uint8, device=cdev) if world > 1 else None
+    mine_dev = torch.empty(jac_bytes, dtype=torch.uint8, device=cdev) if world > 1 else None
 
     def step() -> bytes:
         part = ctx.msm_device(g, d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)
         if world == 1:
             return part
-        mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(cdev)
-        dist.all_gather(gather, mine)                       # RCCL over xGMI: N x 144 B
-        return (pkg.g1_sum if g == "g1" else pkg.g2_sum)([t.cpu().numpy().tobytes() for t in gather])   # fold in rank order on every rank
+        mine_dev.copy_(torch.frombuffer(bytearray(part), dtype=torch.uint8))
+        dist.all_gather_into_tensor(gather, mine_dev)       # RCCL over xGMI: N x 144 B (latency-bound)
+        allp = gather.cpu().numpy().tobytes()               # one D2H copy of the N partials
+        # all-reduce under the curve group law: fold in rank order on every rank (identical result everywhere)
+        return (pkg.g1_sum if g == "g1" else pkg.g2_sum)([allp[k * jac_bytes:(k + 1) * jac_bytes] for k in range(world)])
 
     def fence():
         if world > 1:
