@@ -112,12 +112,12 @@ struct DevState {
     hipEvent_t ev[10] = {};
     // resident bases (device form) per group: [0] = G1, [1] = G2
     struct Resident {
-        DevBuf buf;
+        DevBuf buf, flags;   // device-form points; one byte per point: 1 = point at infinity
         size_t n = 0;    // points resident on this device
         size_t lo = 0;   // global index of the first resident point
     } res[2];
     // scratch
-    DevBuf raw, call_bases, scalars, hist, offsets, woff, meta, sched, sorted, partial, order, item_bucket, pairs;
+    DevBuf raw, call_bases, call_flags, scalars, hist, offsets, woff, meta, sched, sorted, partial, order, item_bucket, pairs;
     DevBuf tilecnt, bin_tot, bin_base, coarse, seg_cnt, seg_base, segcnt, merge_list;
     void* h_pairs = nullptr;
     size_t h_pairs_cap = 0;
@@ -166,8 +166,9 @@ template <class C> constexpr size_t jac_bytes() { return (size_t)msmk::Geo<C>::R
 
 // bases raw (host or device) -> device form in `dst`
 template <class C>
-void ingest(DevState& d, const void* bases, bool bases_on_device, size_t n, DevBuf& dst) {
+void ingest(DevState& d, const void* bases, bool bases_on_device, size_t n, DevBuf& dst, DevBuf& flags) {
     dst.ensure(n * msmk::Geo<C>::PT_WORDS * 4);
+    flags.ensure(n);
     const void* src = bases;
     if (!bases_on_device) {
         d.raw.ensure(n * aff_bytes<C>());
@@ -175,7 +176,7 @@ void ingest(DevState& d, const void* bases, bool bases_on_device, size_t n, DevB
         src = d.raw.p;
     }
     uint32_t grid = (uint32_t)((n + 255) / 256);
-    hipLaunchKernelGGL(msmk::k_ingest<C>, dim3(grid), dim3(256), 0, d.stream, (const uint32_t*)src, (uint32_t*)dst.p, (uint32_t)n);
+    hipLaunchKernelGGL(msmk::k_ingest<C>, dim3(grid), dim3(256), 0, d.stream, (const uint32_t*)src, (uint32_t*)dst.p, (uint8_t*)flags.p, (uint32_t)n);
     HIP_TRY(hipGetLastError());
 }
 
@@ -243,8 +244,8 @@ J host_fold(mi_ctx* ctx, const J* pairs, const Plan& pl) {
 
 // The pipeline on one device.  d_bases: device-form points for indices [0, n); d_scalars: n x 32 B on device.
 template <class C>
-typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, unsigned fmt,
-                                 int ev0) {
+typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint8_t* d_flags, const uint32_t* d_scalars,
+                                 size_t n, unsigned fmt, int ev0) {
     using J = typename HostCurve<C>::J;
     Plan pl = make_plan(n, ctx->forced_c);
     if (pl.c == 0) throw HipFail{"window_bits not usable for this n (sort geometry)"};
@@ -264,12 +265,15 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     HIP_TRY(hipEventRecord(d.ev[ev0], s));
     // ---- two-level LDS-staged bucket sort (geometry in msmk::SortGeom)
     msmk::SortGeom g{};
-    g.n = (uint32_t)n; g.fmt = fmt; g.c = pl.c; g.nwin = pl.nwin; g.pt_words = msmk::Geo<C>::PT_WORDS;
+    g.n = (uint32_t)n; g.fmt = fmt; g.c = pl.c; g.nwin = pl.nwin;
     g.lo_bits = pl.lo_bits;
     g.H = pl.nb >> g.lo_bits;
-    g.tiles = (uint32_t)std::min<size_t>(512, std::max<size_t>(1, n / 4096));
-    g.tile_pts = (uint32_t)(((n + g.tiles - 1) / g.tiles + 255) / 256 * 256);
+    // A tile contributes tile_pts / H entries to each coarse bin of a window, written as one contiguous run: keep
+    // runs >= 64 entries (256 B) or the 4-byte scatter is write-amplified (9.5 ms at n = 2^24 with 16-entry runs).
+    size_t want = std::max<size_t>(std::max<size_t>(4096, n / 512), (size_t)64 * g.H);
+    g.tile_pts = (uint32_t)((std::min(want, n) + 1023) / 1024 * 1024);
     g.tiles = (uint32_t)((n + g.tile_pts - 1) / g.tile_pts);
+    const uint32_t coarse_block = g.tile_pts >= 16384 ? 1024 : 256;
     g.wgroup = std::max<uint32_t>(1, std::min<uint32_t>(pl.nwin, msmk::SORT_MAX_COUNTERS / g.H));
     g.ngroups = (pl.nwin + g.wgroup - 1) / g.wgroup;
     g.nbins = pl.nwin * g.H;
@@ -277,12 +281,12 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     d.bin_tot.ensure((size_t)g.nbins * 4);
     d.bin_base.ensure((size_t)(g.nbins + 1) * 4);
     d.coarse.ensure((size_t)n * pl.nwin * 4);
-    hipLaunchKernelGGL(msmk::k_coarse<false>, dim3(g.tiles, g.ngroups), dim3(256), 0, s, d_scalars, d_bases, g, (uint32_t*)d.tilecnt.p,
+    hipLaunchKernelGGL(msmk::k_coarse<false>, dim3(g.tiles, g.ngroups), dim3(coarse_block), 0, s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
                        (const uint32_t*)nullptr, (uint32_t*)nullptr);
     hipLaunchKernelGGL(msmk::k_colscan, dim3((g.nbins + 255) / 256), dim3(256), 0, s, (uint32_t*)d.tilecnt.p, g.nbins, g.tiles,
                        (uint32_t*)d.bin_tot.p);
     hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.bin_tot.p, g.nbins, (uint32_t*)d.bin_base.p);
-    hipLaunchKernelGGL(msmk::k_coarse<true>, dim3(g.tiles, g.ngroups), dim3(256), 0, s, d_scalars, d_bases, g, (uint32_t*)d.tilecnt.p,
+    hipLaunchKernelGGL(msmk::k_coarse<true>, dim3(g.tiles, g.ngroups), dim3(coarse_block), 0, s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
                        (const uint32_t*)d.bin_base.p, (uint32_t*)d.coarse.p);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 1], s));
     // fine sort over bin segments (upper bound on the segment count: one per bin plus one per FINE_SEG entries)
@@ -383,17 +387,20 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
         d_scalars = reinterpret_cast<const uint32_t*>(d.scalars.p);
     }
     const uint32_t* d_bases;
+    const uint8_t* d_flags;
     if (bases) {
         d.raw.ensure(n * aff_bytes<C>());
         HIP_TRY(hipMemcpyAsync(d.raw.p, bases, n * aff_bytes<C>(), hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(d.ev[1], s));
-        ingest<C>(d, d.raw.p, true, n, d.call_bases);
+        ingest<C>(d, d.raw.p, true, n, d.call_bases, d.call_flags);
         d_bases = reinterpret_cast<const uint32_t*>(d.call_bases.p);
+        d_flags = reinterpret_cast<const uint8_t*>(d.call_flags.p);
     } else {
         HIP_TRY(hipEventRecord(d.ev[1], s));
         d_bases = reinterpret_cast<const uint32_t*>(d.res[HostCurve<C>::IDX].buf.p);
+        d_flags = reinterpret_cast<const uint8_t*>(d.res[HostCurve<C>::IDX].flags.p);
     }
-    J r = run_msm<C>(ctx, d, d_bases, d_scalars, n, fmt, 2);
+    J r = run_msm<C>(ctx, d, d_bases, d_flags, d_scalars, n, fmt, 2);
     d.prof.h2d_ms = ev_ms(d.ev[0], d.ev[1]);
     d.prof.ingest_ms = ev_ms(d.ev[1], d.ev[2]);
     d.prof.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -442,7 +449,7 @@ int set_bases_impl(mi_ctx* ctx, const void* bases, size_t n) {
             res.lo = lo;
             res.n = hi - lo;
             if (hi > lo) {
-                ingest<C>(d, (const uint8_t*)bases + lo * aff_bytes<C>(), false, hi - lo, res.buf);
+                ingest<C>(d, (const uint8_t*)bases + lo * aff_bytes<C>(), false, hi - lo, res.buf, res.flags);
                 HIP_TRY(hipStreamSynchronize(d.stream));
             }
         }
@@ -551,7 +558,7 @@ void mi_msm_destroy(mi_ctx* ctx) {
     for (auto& d : ctx->devs) {
         (void)hipSetDevice(d.dev);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
-        for (DevBuf* b : {&d.res[0].buf, &d.res[1].buf, &d.raw, &d.call_bases, &d.scalars, &d.hist, &d.offsets, &d.woff, &d.meta, &d.sched, &d.sorted,
+        for (DevBuf* b : {&d.res[0].buf, &d.res[1].buf, &d.res[0].flags, &d.res[1].flags, &d.raw, &d.call_bases, &d.call_flags, &d.scalars, &d.hist, &d.offsets, &d.woff, &d.meta, &d.sched, &d.sorted,
                           &d.partial, &d.order, &d.item_bucket, &d.pairs, &d.tilecnt, &d.bin_tot, &d.bin_base, &d.coarse, &d.seg_cnt, &d.seg_base, &d.segcnt, &d.merge_list})
             b->release();
         if (d.h_pairs) (void)hipHostFree(d.h_pairs);

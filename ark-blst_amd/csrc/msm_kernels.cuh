@@ -137,7 +137,8 @@ __device__ __noinline__ void add_inplace(ec::Proj<ec::Fp2Ops>& a, const ec::Proj
 // ---------------------------------------------------------------------------------------------- ingest
 // raw: n affine points in the reference's form.  One thread per point.
 template <class C>
-__global__ void __launch_bounds__(256) k_ingest(const uint32_t* __restrict__ raw, uint32_t* __restrict__ out, uint32_t n) {
+__global__ void __launch_bounds__(256) k_ingest(const uint32_t* __restrict__ raw, uint32_t* __restrict__ out,
+                                                uint8_t* __restrict__ inf_flags, uint32_t n) {
     using E = typename C::F::E;
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -151,6 +152,7 @@ __global__ void __launch_bounds__(256) k_ingest(const uint32_t* __restrict__ raw
     uint32_t* o = out + (size_t)i * Geo<C>::PT_WORDS;
     ElemIO<E>::store(o, x);
     ElemIO<E>::store(o + Geo<C>::SLOT, y, any == 0 ? 1u : 0u);
+    inf_flags[i] = any == 0 ? 1 : 0;   // compact copy for the sort passes (a 4-byte read per 128-byte point costs a line)
 }
 
 // ---------------------------------------------------------------------------------------------- scalars
@@ -238,9 +240,9 @@ __device__ __forceinline__ void for_each_digit(const uint32_t (&s)[8], uint32_t 
 //                                               -> sorted[] in (window, bucket) order and hist[window][bucket]
 // Windows are processed in groups of `wgroup` so that wgroup * H counters fit LDS (<= 16384 counters, 64 KB).
 struct SortGeom {
-    uint32_t n, fmt, c, nwin, pt_words;
+    uint32_t n, fmt, c, nwin;
     uint32_t lo_bits, H;          // fine bits, coarse bins per window
-    uint32_t tiles, tile_pts;     // point tiles (grid.x) and points per tile (multiple of 256)
+    uint32_t tiles, tile_pts;     // point tiles (grid.x) and points per tile (multiple of 1024)
     uint32_t wgroup, ngroups;     // windows per group, groups (grid.y)
     uint32_t nbins;               // nwin * H
 };
@@ -248,14 +250,14 @@ constexpr uint32_t SORT_MAX_COUNTERS = 16384;  // 64 KB of LDS counters per work
 
 // entry in `coarse`: (point index << (lo_bits+1)) | (negative << lo_bits) | lo
 template <bool SCATTER>
-__global__ void __launch_bounds__(256) k_coarse(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ bases, SortGeom g,
-                                                uint32_t* __restrict__ tilecnt, const uint32_t* __restrict__ bin_base,
-                                                uint32_t* __restrict__ coarse) {
+__global__ void __launch_bounds__(1024) k_coarse(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flags, SortGeom g,
+                                                 uint32_t* __restrict__ tilecnt, const uint32_t* __restrict__ bin_base,
+                                                 uint32_t* __restrict__ coarse) {
     __shared__ uint32_t cnt[SORT_MAX_COUNTERS];
-    uint32_t tile = blockIdx.x, grp = blockIdx.y, t = threadIdx.x;
+    const uint32_t tile = blockIdx.x, grp = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
     uint32_t w0 = grp * g.wgroup, w1 = w0 + g.wgroup < g.nwin ? w0 + g.wgroup : g.nwin;
     uint32_t ncnt = (w1 - w0) * g.H;
-    for (uint32_t k = t; k < ncnt; k += 256) {
+    for (uint32_t k = t; k < ncnt; k += nt) {
         if (SCATTER) {
             uint32_t bin = w0 * g.H + k;
             cnt[k] = bin_base[bin] + tilecnt[(size_t)tile * g.nbins + bin];  // where this tile's run of the bin starts
@@ -266,8 +268,8 @@ __global__ void __launch_bounds__(256) k_coarse(const uint32_t* __restrict__ sca
     __syncthreads();
     uint32_t lo_mask = (1u << g.lo_bits) - 1u;
     uint32_t p0 = tile * g.tile_pts, p1 = p0 + g.tile_pts < g.n ? p0 + g.tile_pts : g.n;
-    for (uint32_t i = p0 + t; i < p1; i += 256) {
-        if (bases[(size_t)i * g.pt_words + g.pt_words - 1] != 0) continue;  // infinity base
+    for (uint32_t i = p0 + t; i < p1; i += nt) {
+        if (inf_flags[i] != 0) continue;  // infinity base: contributes nothing
         uint32_t s[8];
         load_scalar(s, scalars, i, g.fmt);
         for_each_digit(s, g.c, w1, [&](uint32_t w, uint32_t b, bool neg) {
@@ -279,7 +281,7 @@ __global__ void __launch_bounds__(256) k_coarse(const uint32_t* __restrict__ sca
     }
     if (!SCATTER) {
         __syncthreads();
-        for (uint32_t k = t; k < ncnt; k += 256) tilecnt[(size_t)tile * g.nbins + w0 * g.H + k] = cnt[k];
+        for (uint32_t k = t; k < ncnt; k += nt) tilecnt[(size_t)tile * g.nbins + w0 * g.H + k] = cnt[k];
     }
 }
 
