@@ -242,6 +242,20 @@ J host_fold(mi_ctx* ctx, const J* pairs, const Plan& pl) {
     return r;
 }
 
+// k_coarse is compiled per window size (static digit extraction): dispatch on c = 7..22
+template <bool SCATTER, int CB = 7>
+void launch_coarse(uint32_t c, dim3 grid, dim3 block, hipStream_t s, const uint32_t* scalars, const uint8_t* flags, const msmk::SortGeom& g,
+                   uint32_t* tilecnt, const uint32_t* bin_base, uint32_t* coarse) {
+    if constexpr (CB > 22) {
+        throw HipFail{"window_bits out of range"};
+    } else {
+        if (c == CB)
+            hipLaunchKernelGGL((msmk::k_coarse<SCATTER, CB>), grid, block, 0, s, scalars, flags, g, tilecnt, bin_base, coarse);
+        else
+            launch_coarse<SCATTER, CB + 1>(c, grid, block, s, scalars, flags, g, tilecnt, bin_base, coarse);
+    }
+}
+
 // The pipeline on one device.  d_bases: device-form points for indices [0, n); d_scalars: n x 32 B on device.
 template <class C>
 typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint8_t* d_flags, const uint32_t* d_scalars,
@@ -281,13 +295,13 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     d.bin_tot.ensure((size_t)g.nbins * 4);
     d.bin_base.ensure((size_t)(g.nbins + 1) * 4);
     d.coarse.ensure((size_t)n * pl.nwin * 4);
-    hipLaunchKernelGGL(msmk::k_coarse<false>, dim3(g.tiles, g.ngroups), dim3(coarse_block), 0, s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
-                       (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    launch_coarse<false>(pl.c, dim3(g.tiles, g.ngroups), dim3(coarse_block), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
+                         (const uint32_t*)nullptr, (uint32_t*)nullptr);
     hipLaunchKernelGGL(msmk::k_colscan, dim3((g.nbins + 255) / 256), dim3(256), 0, s, (uint32_t*)d.tilecnt.p, g.nbins, g.tiles,
                        (uint32_t*)d.bin_tot.p);
     hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.bin_tot.p, g.nbins, (uint32_t*)d.bin_base.p);
-    hipLaunchKernelGGL(msmk::k_coarse<true>, dim3(g.tiles, g.ngroups), dim3(coarse_block), 0, s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
-                       (const uint32_t*)d.bin_base.p, (uint32_t*)d.coarse.p);
+    launch_coarse<true>(pl.c, dim3(g.tiles, g.ngroups), dim3(coarse_block), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
+                        (const uint32_t*)d.bin_base.p, (uint32_t*)d.coarse.p);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 1], s));
     // fine sort over bin segments (upper bound on the segment count: one per bin plus one per FINE_SEG entries)
     uint32_t segs_cap = g.nbins + (uint32_t)(((size_t)n * pl.nwin) / msmk::FINE_SEG) + 1;

@@ -227,6 +227,27 @@ __device__ __forceinline__ void for_each_digit(const uint32_t (&s)[8], uint32_t 
     }
 }
 
+// Same recoding with the window size known at compile time: the window loop unrolls, every bit-field extraction
+// becomes one or two shifts on statically indexed words (the runtime version spends 16 selects per window), and
+// windows outside [w0, w1) cost only their carry.  k_coarse is instantiated for c = 7..22.
+template <int CB, class Fn>
+__device__ __forceinline__ void for_each_digit_static(const uint32_t (&s)[8], uint32_t w0, uint32_t w1, Fn f) {
+    constexpr uint32_t NW = (256 + CB - 1) / CB, HALF = 1u << (CB - 1), MASKC = (1u << CB) - 1u;
+    uint32_t carry = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < NW; w++) {
+        constexpr uint32_t dummy = 0; (void)dummy;
+        const uint32_t off = w * CB, wi = off >> 5, sh = off & 31;
+        uint32_t v = wi < 8 ? s[wi < 8 ? wi : 0] >> sh : 0u;
+        if (sh + CB > 32 && wi + 1 < 8) v |= s[wi + 1 < 8 ? wi + 1 : 0] << (32 - sh);
+        uint32_t raw = (v & MASKC) + carry;
+        bool neg = raw > HALF;
+        carry = neg ? 1u : 0u;
+        uint32_t mag = neg ? (1u << CB) - raw : raw;
+        if (w >= w0 && w < w1 && mag != 0) f(w, mag - 1, neg);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- bucket sort
 // Two-level sort of the N*W (window, bucket) keys, staged through LDS — replaces one global atomic per key in the
 // histogram pass and one returning global atomic + 4-byte scatter per key in the scatter pass.
@@ -249,7 +270,7 @@ struct SortGeom {
 constexpr uint32_t SORT_MAX_COUNTERS = 16384;  // 64 KB of LDS counters per workgroup (2 workgroups per CU)
 
 // entry in `coarse`: (point index << (lo_bits+1)) | (negative << lo_bits) | lo
-template <bool SCATTER>
+template <bool SCATTER, int CB>
 __global__ void __launch_bounds__(1024) k_coarse(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flags, SortGeom g,
                                                  uint32_t* __restrict__ tilecnt, const uint32_t* __restrict__ bin_base,
                                                  uint32_t* __restrict__ coarse) {
@@ -272,8 +293,7 @@ __global__ void __launch_bounds__(1024) k_coarse(const uint32_t* __restrict__ sc
         if (inf_flags[i] != 0) continue;  // infinity base: contributes nothing
         uint32_t s[8];
         load_scalar(s, scalars, i, g.fmt);
-        for_each_digit(s, g.c, w1, [&](uint32_t w, uint32_t b, bool neg) {
-            if (w < w0) return;
+        for_each_digit_static<CB>(s, w0, w1, [&](uint32_t w, uint32_t b, bool neg) {
             uint32_t k = (w - w0) * g.H + (b >> g.lo_bits);
             uint32_t pos = atomicAdd(&cnt[k], 1u);
             if (SCATTER) coarse[pos] = (i << (g.lo_bits + 1)) | ((neg ? 1u : 0u) << g.lo_bits) | (b & lo_mask);
