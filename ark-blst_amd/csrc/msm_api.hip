@@ -78,6 +78,8 @@ Plan make_plan(size_t n, unsigned forced_c) {
     best.nb = 1u << (best.c - 1);
     // 8 buckets per lane, one reduce wave per SIMD: measured best of L in {2,4,8} x {1,2} waves/SIMD (tools/ab_reduce.sh)
     best.logL = std::min<uint32_t>(3, best.c - 7);
+    // many buckets (large n): more buckets per lane keep the chunk count (reduce waves, host pairs) near 4096
+    while (best.logL < 6 && best.logL < best.c - 7 && (((uint64_t)(1u << (best.c - 1)) * best.nwin) >> (6 + best.logL)) > 4096) best.logL++;
     best.chunks_per_win = best.nb >> (6 + best.logL);
     best.nbuckets = (uint64_t)best.nb * best.nwin;
     best.nchunks = (uint64_t)best.chunks_per_win * best.nwin;
@@ -188,7 +190,7 @@ J host_fold(mi_ctx* ctx, const J* pairs, const Plan& pl) {
     //   sum_{j in [a,b)} j S_j = W_ab + a * S_ab,  W_ab = sum (j - a) S_j (running sums),  S_ab = sum S_j.
     const uint32_t cpw = pl.chunks_per_win;
     uint32_t parts = 1;
-    while (parts < 8 && cpw / (parts * 2) >= 16 && pl.nwin * parts < 48) parts *= 2;
+    while (parts < 64 && cpw / (parts * 2) >= 16 && pl.nwin * parts < 192) parts *= 2;
     const uint32_t seg = (cpw + parts - 1) / parts;
     struct Part { J w, s, t; };
     std::vector<Part> part((size_t)pl.nwin * parts);
