@@ -196,7 +196,7 @@ def main() -> None:
                           ("digits_ms", "scan_ms", "scatter_ms", "accumulate_ms", "reduce_ms", "d2h_ms", "host_fold_ms", "total_ms")},
             "input_gen_s": gen_s,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
             best = 1e30
             runs = 3 if args.log_n <= 20 else 1
             for _ in range(runs):
