@@ -48,6 +48,7 @@ def load_library():
             getattr(L, f"mi_msm_{g}").argtypes = [vp, vp, vp, sz, u, vp]
             getattr(L, f"mi_msm_{g}_device").argtypes = [vp, vp, sz, u, vp]
             getattr(L, f"mi_{g}_sum").argtypes = [vp, sz, vp]
+            getattr(L, f"mi_{g}_normalize_batch").argtypes = [vp, vp, sz, vp]
         L.mi_msm_set_window_bits.argtypes = [vp, u]
         L.mi_msm_last_profile.argtypes = [vp, C.POINTER(Profile)]
         L.mi_msm_last_error.argtypes = [vp]
@@ -128,6 +129,14 @@ class Context:
         out = C.create_string_buffer(G1_JAC if group == "g1" else G2_JAC)
         self._check(getattr(self._L, f"mi_msm_{group}_device")(self._h, C.c_void_p(d_scalars_ptr), n, scalar_fmt, out),
                     f"mi_msm_{group}_device")
+        return out.raw
+
+    def normalize_batch(self, group: str, jac: bytes) -> bytes:
+        """CurveGroup::normalize_batch: packed Jacobian points -> packed affine points (infinity -> zeros)."""
+        jb, ab = (G1_JAC, G1_AFF) if group == "g1" else (G2_JAC, G2_AFF)
+        n = len(jac) // jb
+        out = C.create_string_buffer(ab * n)
+        self._check(getattr(self._L, f"mi_{group}_normalize_batch")(self._h, jac, n, out), f"mi_{group}_normalize_batch")
         return out.raw
 
     def profile(self) -> dict:

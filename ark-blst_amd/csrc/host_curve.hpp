@@ -95,6 +95,18 @@ struct Fp {
     }
     Fp sqr() const { return *this * *this; }
     Fp dbl() const { return *this + *this; }
+    // a^(p-2) (Fermat); inv(0) = 0.  Used once per normalize_batch call on the top of the product tree.
+    Fp inv() const {
+        uint64_t e[6];
+        memcpy(e, MOD, sizeof e);
+        e[0] -= 2;
+        Fp acc = one(), base = *this;
+        for (int i = 0; i < 384; i++) {
+            if ((e[i >> 6] >> (i & 63)) & 1) acc = acc * base;
+            base = base.sqr();
+        }
+        return acc;
+    }
 };
 
 struct Fp2 {
@@ -115,6 +127,10 @@ struct Fp2 {
         return {s * d, m + m};
     }
     Fp2 dbl() const { return *this + *this; }
+    Fp2 inv() const {  // conj(a) / (c0^2 + c1^2)
+        Fp n = (c0.sqr() + c1.sqr()).inv();
+        return {c0 * n, Fp::zero() - c1 * n};
+    }
 };
 
 template <class FE>

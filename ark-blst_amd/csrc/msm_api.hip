@@ -423,6 +423,74 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
     return r;
 }
 
+// normalize_batch on device 0 of the context (host pointers in the reference's forms)
+template <class C>
+void normalize_batch_dev(mi_ctx* ctx, DevState& d, const void* in, size_t n, void* out) {
+    using J = typename HostCurve<C>::J;
+    using FE = decltype(J::inf().x);
+    constexpr size_t SLOTB = (size_t)msmk::Geo<C>::SLOT * 4;
+    HIP_TRY(hipSetDevice(d.dev));
+    hipStream_t s = d.stream;
+    // level sizes: n, ceil(n/K), ... until <= 64
+    std::vector<size_t> sz{n};
+    while (sz.back() > 64) sz.push_back((sz.back() + msmk::NORM_K - 1) / msmk::NORM_K);
+    size_t total = 0;
+    for (size_t v : sz) total += v;
+    DevBuf raw_in, raw_out, vals, pref, inv, top_raw;
+    raw_in.ensure(n * jac_bytes<C>());
+    raw_out.ensure(n * aff_bytes<C>());
+    vals.ensure(total * SLOTB);
+    pref.ensure(total * SLOTB);
+    inv.ensure(total * SLOTB);
+    top_raw.ensure(64 * sizeof(FE));
+    std::vector<size_t> off(sz.size());
+    for (size_t l = 0, acc = 0; l < sz.size(); acc += sz[l], l++) off[l] = acc;
+    auto at = [&](DevBuf& b, size_t l) { return (uint32_t*)((char*)b.p + off[l] * SLOTB); };
+    try {
+        HIP_TRY(hipEventRecord(d.ev[0], s));
+        HIP_TRY(hipMemcpyAsync(raw_in.p, in, n * jac_bytes<C>(), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(d.ev[1], s));
+        hipLaunchKernelGGL(msmk::k_norm_load<C>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)raw_in.p, (uint32_t)n,
+                           at(vals, 0));
+        for (size_t l = 0; l + 1 < sz.size(); l++) {
+            uint32_t groups = (uint32_t)sz[l + 1];
+            hipLaunchKernelGGL(msmk::k_norm_up<C>, dim3((groups + 255) / 256), dim3(256), 0, s, (const uint32_t*)at(vals, l), (uint32_t)sz[l],
+                               at(pref, l), at(vals, l + 1));
+        }
+        // top level on the host: Montgomery's trick over <= 64 values, one inversion
+        size_t top = sz.size() - 1, m = sz[top];
+        hipLaunchKernelGGL(msmk::k_elems_to_raw<C>, dim3(1), dim3(64), 0, s, (const uint32_t*)at(vals, top), (uint32_t)m, (uint32_t*)top_raw.p);
+        std::vector<FE> v(m), pre(m), iv(m);
+        HIP_TRY(hipMemcpyAsync(v.data(), top_raw.p, m * sizeof(FE), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        FE run = FE::one();
+        for (size_t k = 0; k < m; k++) { pre[k] = run; run = run * v[k]; }
+        FE I = run.inv();
+        for (size_t k = m; k-- > 0;) { iv[k] = I * pre[k]; I = I * v[k]; }
+        HIP_TRY(hipMemcpyAsync(top_raw.p, iv.data(), m * sizeof(FE), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(msmk::k_elems_from_raw<C>, dim3(1), dim3(64), 0, s, (const uint32_t*)top_raw.p, (uint32_t)m, at(inv, top));
+        for (size_t l = top; l-- > 0;) {
+            uint32_t groups = (uint32_t)sz[l + 1];
+            hipLaunchKernelGGL(msmk::k_norm_down<C>, dim3((groups + 255) / 256), dim3(256), 0, s, (const uint32_t*)at(vals, l),
+                               (const uint32_t*)at(pref, l), (const uint32_t*)at(inv, l + 1), (uint32_t)sz[l], at(inv, l));
+        }
+        hipLaunchKernelGGL(msmk::k_norm_final<C>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)raw_in.p,
+                           (const uint32_t*)at(inv, 0), (uint32_t)n, (uint32_t*)raw_out.p);
+        HIP_TRY(hipEventRecord(d.ev[2], s));
+        HIP_TRY(hipMemcpyAsync(out, raw_out.p, n * aff_bytes<C>(), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipGetLastError());
+        ctx->prof = mi_profile{};
+        ctx->prof.n = n;
+        ctx->prof.h2d_ms = ev_ms(d.ev[0], d.ev[1]);
+        ctx->prof.accumulate_ms = ev_ms(d.ev[1], d.ev[2]);   // all normalize kernels incl. the host inversion round trip
+    } catch (...) {
+        for (DevBuf* b : {&raw_in, &raw_out, &vals, &pref, &inv, &top_raw}) b->release();
+        throw;
+    }
+    for (DevBuf* b : {&raw_in, &raw_out, &vals, &pref, &inv, &top_raw}) b->release();
+}
+
 int fail(mi_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
     return code;
@@ -601,6 +669,19 @@ int mi_msm_g1_device(mi_ctx* ctx, const void* d_scalars, size_t n, unsigned scal
 }
 int mi_msm_g2_device(mi_ctx* ctx, const void* d_scalars, size_t n, unsigned scalar_fmt, mi_g2* out) {
     return msm_impl<msmk::G2C>(ctx, nullptr, static_cast<const uint8_t*>(d_scalars), true, n, scalar_fmt, out);
+}
+
+int mi_g1_normalize_batch(mi_ctx* ctx, const mi_g1* in, size_t n, mi_g1_affine* out) {
+    if (!ctx || (n && (!in || !out))) return fail(ctx, MI_E_INVALID, "invalid argument");
+    if (n == 0) return MI_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return guarded(ctx, [&]() -> int { normalize_batch_dev<msmk::G1C>(ctx, ctx->devs[0], in, n, out); return MI_OK; });
+}
+int mi_g2_normalize_batch(mi_ctx* ctx, const mi_g2* in, size_t n, mi_g2_affine* out) {
+    if (!ctx || (n && (!in || !out))) return fail(ctx, MI_E_INVALID, "invalid argument");
+    if (n == 0) return MI_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return guarded(ctx, [&]() -> int { normalize_batch_dev<msmk::G2C>(ctx, ctx->devs[0], in, n, out); return MI_OK; });
 }
 
 int mi_g1_sum(const mi_g1* partials, size_t n, mi_g1* out) {

@@ -780,6 +780,114 @@ __global__ void __launch_bounds__(64, 1) k_reduce(const uint32_t* __restrict__ p
     }
 }
 
+// ---------------------------------------------------------------------------------------------- normalize_batch
+// Jacobian -> affine for n points with ONE field inversion (Montgomery's trick as a product tree of fan-out NORM_K):
+// replaces blstrs::G{1,2}Projective::batch_normalize behind CurveGroup::normalize_batch
+// (/root/reference/src/g1.rs:537-543, src/g2.rs:517-523; the step arkworks provers run right before an MSM,
+// `batch_convert_to_mul_base`, src/g1.rs:597-599).  Infinity (Z = 0) maps to the all-zero affine point.
+//   k_norm_load : Z_i (raw) -> device form, infinity replaced by 1
+//   k_norm_up   : per group of K values: exclusive prefix products + group total (= value of the next level)
+//   (top level <= 64 values: inverted on the host, one Fermat inversion)
+//   k_norm_down : per group: inverse of each value from the inverse of the group total
+//   k_norm_final: x = X / Z^2, y = Y / Z^3, back to the reference's form
+constexpr uint32_t NORM_K = 32;
+
+template <class C>
+__global__ void __launch_bounds__(256) k_norm_load(const uint32_t* __restrict__ raw_jac, uint32_t n, uint32_t* __restrict__ vals) {
+    using F = typename C::F;
+    using E = typename F::E;
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* zr = raw_jac + (size_t)i * Geo<C>::RAW_JAC + 2 * ElemIO<E>::RAW;
+    uint32_t any = 0;
+#pragma unroll 4
+    for (int k = 0; k < ElemIO<E>::RAW; k++) any |= zr[k];
+    E z;
+    ElemIO<E>::from_raw(z, zr);
+    z = F::select(any == 0, z, F::one());
+    ElemIO<E>::store(vals + (size_t)i * Geo<C>::SLOT, z);
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) k_norm_up(const uint32_t* __restrict__ vals, uint32_t m, uint32_t* __restrict__ pref,
+                                                 uint32_t* __restrict__ tot) {
+    using F = typename C::F;
+    using E = typename F::E;
+    uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    uint32_t lo = g * NORM_K, hi = lo + NORM_K < m ? lo + NORM_K : m;
+    if (lo >= m) return;
+    E run = F::one();
+    for (uint32_t k = lo; k < hi; k++) {
+        ElemIO<E>::store(pref + (size_t)k * Geo<C>::SLOT, run);
+        E v;
+        ElemIO<E>::load(v, vals + (size_t)k * Geo<C>::SLOT);
+        run = F::mul(run, v);
+    }
+    ElemIO<E>::store(tot + (size_t)g * Geo<C>::SLOT, run);
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) k_norm_down(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ pref,
+                                                   const uint32_t* __restrict__ inv_tot, uint32_t m, uint32_t* __restrict__ inv_vals) {
+    using F = typename C::F;
+    using E = typename F::E;
+    uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    uint32_t lo = g * NORM_K, hi = lo + NORM_K < m ? lo + NORM_K : m;
+    if (lo >= m) return;
+    E I;
+    ElemIO<E>::load(I, inv_tot + (size_t)g * Geo<C>::SLOT);
+    for (uint32_t k = hi; k-- > lo;) {
+        E p, v;
+        ElemIO<E>::load(p, pref + (size_t)k * Geo<C>::SLOT);
+        ElemIO<E>::load(v, vals + (size_t)k * Geo<C>::SLOT);
+        ElemIO<E>::store(inv_vals + (size_t)k * Geo<C>::SLOT, F::mul(I, p));
+        I = F::mul(I, v);
+    }
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) k_norm_final(const uint32_t* __restrict__ raw_jac, const uint32_t* __restrict__ zinv, uint32_t n,
+                                                    uint32_t* __restrict__ raw_aff) {
+    using F = typename C::F;
+    using E = typename F::E;
+    constexpr int R = ElemIO<E>::RAW;
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* q = raw_jac + (size_t)i * Geo<C>::RAW_JAC;
+    uint32_t any = 0;
+#pragma unroll 4
+    for (int k = 0; k < R; k++) any |= q[2 * R + k];
+    E x, y, zi;
+    ElemIO<E>::from_raw(x, q);
+    ElemIO<E>::from_raw(y, q + R);
+    ElemIO<E>::load(zi, zinv + (size_t)i * Geo<C>::SLOT);
+    E zi2 = F::mul(zi, zi);
+    E zi3 = F::mul(zi2, zi);
+    uint32_t* o = raw_aff + (size_t)i * Geo<C>::RAW_AFF;
+    ElemIO<E>::to_raw(o, F::mul(x, zi2), any != 0);
+    ElemIO<E>::to_raw(o + R, F::mul(y, zi3), any != 0);
+}
+
+// device form <-> reference form for a short vector of field elements (top of the product tree, host inversion)
+template <class C>
+__global__ void __launch_bounds__(64) k_elems_to_raw(const uint32_t* __restrict__ dev, uint32_t m, uint32_t* __restrict__ raw) {
+    using E = typename C::F::E;
+    uint32_t i = threadIdx.x;
+    if (i >= m) return;
+    E v;
+    ElemIO<E>::load(v, dev + (size_t)i * Geo<C>::SLOT);
+    ElemIO<E>::to_raw(raw + (size_t)i * ElemIO<E>::RAW, v, true);
+}
+template <class C>
+__global__ void __launch_bounds__(64) k_elems_from_raw(const uint32_t* __restrict__ raw, uint32_t m, uint32_t* __restrict__ dev) {
+    using E = typename C::F::E;
+    uint32_t i = threadIdx.x;
+    if (i >= m) return;
+    E v;
+    ElemIO<E>::from_raw(v, raw + (size_t)i * ElemIO<E>::RAW);
+    ElemIO<E>::store(dev + (size_t)i * Geo<C>::SLOT, v);
+}
+
 // ---------------------------------------------------------------------------------------------- field test hook
 __global__ void __launch_bounds__(256) k_test_fp_op(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
                                                     uint32_t* __restrict__ out, uint32_t n) {

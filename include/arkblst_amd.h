@@ -103,6 +103,13 @@ int mi_msm_g2(mi_ctx *ctx, const mi_g2_affine *bases, const uint8_t *scalars, si
 int mi_msm_g1_device(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g1 *out);
 int mi_msm_g2_device(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g2 *out);
 
+/* Jacobian -> affine for n points with one field inversion (product tree on the GPU).  Replaces
+ * CurveGroup::normalize_batch = blstrs::G{1,2}Projective::batch_normalize (src/g1.rs:537-543, src/g2.rs:517-523), the step
+ * arkworks provers run right before an MSM (ScalarMul::batch_convert_to_mul_base, src/g1.rs:597-599).  Infinity inputs
+ * (Z == 0) give the all-zero affine point.  Host pointers; runs on the context's first device. */
+int mi_g1_normalize_batch(mi_ctx *ctx, const mi_g1 *in, size_t n, mi_g1_affine *out);
+int mi_g2_normalize_batch(mi_ctx *ctx, const mi_g2 *in, size_t n, mi_g2_affine *out);
+
 /* Deterministic fold of partial sums (one per GPU / rank), in index order: the "all-reduce under the curve
  * group law" that follows the RCCL all-gather in the multi-process harness.  Host only. */
 int mi_g1_sum(const mi_g1 *partials, size_t n, mi_g1 *out);

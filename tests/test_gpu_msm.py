@@ -233,3 +233,47 @@ def test_error_paths(ctx, pkg):
         ctx.msm("g1", bytes(96), bytes(32), 1, 7)                      # unknown scalar format
     with pytest.raises(pkg.MsmError):
         ctx.set_window_bits(3)
+
+
+@pytest.mark.parametrize("group,n", [("g1", 1), ("g1", 33), ("g1", 64), ("g1", 65), ("g1", 5000), ("g2", 7), ("g2", 2100)])
+def test_normalize_batch_vs_oracle(ctx, co, o, group, n):
+    """CurveGroup::normalize_batch (/root/reference/src/g1.rs:537-543, src/g2.rs:517-523): Jacobian -> affine with one
+    inversion; every element against the oracle's per-point conversion, infinity (Z = 0) -> all-zero affine."""
+    rnd = random.Random(1234 + n)
+    F = o.F1 if group == "g1" else o.F2
+    aff = 96 if group == "g1" else 192
+    raw = co.gen_bases(group, SEED_B + 20, n, 8)
+    jac, want = [], []
+    for i in range(n):
+        pt = o.affine_from_bytes(F, raw[aff * i:aff * (i + 1)])
+        if i % 11 == 3:  # infinity with garbage X, Y
+            garbage = F.mul(pt[0], pt[1])
+            jac.append(o._felt_bytes(F, garbage) + o._felt_bytes(F, pt[1]) + o._felt_bytes(F, F.zero))
+            want.append(bytes(aff))
+            continue
+        lam = rnd.randrange(1, o.P) if group == "g1" else (rnd.randrange(1, o.P), rnd.randrange(o.P))
+        l2 = F.mul(lam, lam)
+        jac.append(o._felt_bytes(F, F.mul(pt[0], l2)) + o._felt_bytes(F, F.mul(pt[1], F.mul(l2, lam))) + o._felt_bytes(F, lam))
+        want.append(raw[aff * i:aff * (i + 1)])
+    blob = b"".join(jac)
+    got = ctx.normalize_batch(group, blob)
+    assert got == b"".join(want)
+    # and the C oracle agrees element by element on a sample
+    jb = 144 if group == "g1" else 288
+    for i in range(0, n, max(1, n // 20)):
+        assert co.to_affine(group, blob[jb * i:jb * (i + 1)]) == got[aff * i:aff * (i + 1)]
+
+
+def test_normalize_batch_feeds_msm(ctx, co, pkg):
+    """The prover sequence the reference's own test uses: msm(normalize_batch(bases), scalars) (src/tests.rs:63-66)."""
+    n = 512
+    bases = co.gen_bases("g1", SEED_B + 21, n, 8)
+    scalars = co.gen_scalars(SEED_S + 21, n)
+    # partial MSM results are genuine Jacobian points with non-trivial Z
+    parts = [ctx.msm("g1", bases[96 * k:96 * (k + 64)], scalars[32 * k:32 * (k + 64)], 64, pkg.SCALAR_CANONICAL) for k in range(0, n, 64)]
+    affs = ctx.normalize_batch("g1", b"".join(parts))
+    for k, p in enumerate(parts):
+        assert affs[96 * k:96 * (k + 1)] == co.to_affine("g1", p)
+    ones = b"".join((1).to_bytes(32, "little") for _ in parts)
+    total = ctx.msm("g1", affs, ones, len(parts), pkg.SCALAR_CANONICAL)
+    assert _canon(co, "g1", total) == co.dlog_expected("g1", scalars, SEED_B + 21, n)
