@@ -1,0 +1,139 @@
+// ark_blst_amd.hpp — C++ host-side mirror of the trait surface nikkolasg/ark-blst exposes for the MSM path, on top
+// of the C ABI (include/arkblst_amd.h).  The reference is Rust (no toolchain in this image), so this header is the
+// compiled-language host side: same names, argument meaning and error behaviour as
+//     impl ScalarMul        for G{1,2}Projective   /root/reference/src/g1.rs:593-600, src/g2.rs:573-580
+//     impl VariableBaseMSM  for G{1,2}Projective   /root/reference/src/g1.rs:602-632, src/g2.rs:582-612
+//     CurveGroup::normalize_batch                  /root/reference/src/g1.rs:537-543, src/g2.rs:517-523
+// Types are the reference's #[repr(transparent)] wrappers over the blst structs (src/g1.rs:55-56,436-437;
+// src/scalar.rs:24-25), i.e. plain limb arrays.  Header-only; link with -larkblst_amd.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+#include <variant>
+#include <vector>
+
+#include "../../include/arkblst_amd.h"
+
+namespace ark_blst {
+
+// Result<T, usize> of the reference: Ok(value) or Err(n).  Err(min(len)) on a length mismatch (arkworks' default),
+// Err(0) for any GPU failure (src/g1.rs:628-630).
+template <class T>
+class Result {
+public:
+    static Result Ok(const T& v) { Result r; r.v_ = v; r.ok_ = true; return r; }
+    static Result Err(size_t e) { Result r; r.e_ = e; r.ok_ = false; return r; }
+    bool is_ok() const { return ok_; }
+    bool is_err() const { return !ok_; }
+    const T& unwrap() const {
+        if (!ok_) throw std::runtime_error("called `Result::unwrap()` on an `Err` value");
+        return v_;
+    }
+    size_t unwrap_err() const { return e_; }
+
+private:
+    T v_{};
+    size_t e_ = 0;
+    bool ok_ = false;
+};
+
+struct Scalar { uint64_t l[4]; };                   // blst_fr: Montgomery, R = 2^256   (src/scalar.rs:23-25)
+struct BigInteger256 { uint64_t l[4]; };            // canonical little-endian integer  (PrimeField::BigInt)
+using G1Affine = mi_g1_affine;                      // blst_p1_affine, all-zero = identity (src/g1.rs:54-56)
+using G2Affine = mi_g2_affine;
+
+// One process-wide context, created on first use — the reference rebuilds program and kernel on every call
+// (src/gpu.rs:233-237) and panics if that fails (`.expect`, gpu.rs:235,237); here creation failure throws.
+inline mi_ctx* context() {
+    static mi_ctx* ctx = [] {
+        mi_ctx* c = nullptr;
+        int rc = mi_msm_init(&c, nullptr, 0);
+        if (rc != MI_OK) throw std::runtime_error(std::string("Cannot initialize MI355X MSM context: ") + mi_msm_strerror(rc));
+        return c;
+    }();
+    return ctx;
+}
+
+struct G1Projective {
+    mi_g1 p;                                        // blst_p1 (src/g1.rs:435-437)
+    using MulBase = G1Affine;                       // impl ScalarMul (src/g1.rs:593-600)
+    static constexpr bool NEGATION_IS_CHEAP = true;
+
+    static G1Projective zero() { G1Projective r; std::memset(&r.p, 0, sizeof r.p); return r; }
+    bool is_zero() const { mi_fp z{}; return std::memcmp(&p.z, &z, sizeof z) == 0; }
+
+    // fn msm(bases: &[Self::MulBase], scalars: &[Self::ScalarField]) -> Result<Self, usize>
+    static Result<G1Projective> msm(const std::vector<G1Affine>& bases, const std::vector<Scalar>& scalars) {
+        if (bases.size() != scalars.size()) return Result<G1Projective>::Err(std::min(bases.size(), scalars.size()));
+        G1Projective out;
+        int rc = mi_msm_g1(context(), bases.data(), reinterpret_cast<const uint8_t*>(scalars.data()), bases.size(),
+                           MI_SCALAR_MONTGOMERY, &out.p);
+        return rc == MI_OK ? Result<G1Projective>::Ok(out) : Result<G1Projective>::Err(0);
+    }
+    // fn msm_bigint(bases, bigints) — the form the reference's GPU impl builds first (src/g1.rs:624-627)
+    static Result<G1Projective> msm_bigint(const std::vector<G1Affine>& bases, const std::vector<BigInteger256>& bigints) {
+        if (bases.size() != bigints.size()) return Result<G1Projective>::Err(std::min(bases.size(), bigints.size()));
+        G1Projective out;
+        int rc = mi_msm_g1(context(), bases.data(), reinterpret_cast<const uint8_t*>(bigints.data()), bases.size(),
+                           MI_SCALAR_CANONICAL, &out.p);
+        return rc == MI_OK ? Result<G1Projective>::Ok(out) : Result<G1Projective>::Err(0);
+    }
+    // fn normalize_batch(projective: &[Self]) -> Vec<Self::Affine>  (= ScalarMul::batch_convert_to_mul_base)
+    static std::vector<G1Affine> normalize_batch(const std::vector<G1Projective>& projective) {
+        std::vector<G1Affine> out(projective.size());
+        if (projective.empty()) return out;
+        static_assert(sizeof(G1Projective) == sizeof(mi_g1), "transparent wrapper");
+        int rc = mi_g1_normalize_batch(context(), reinterpret_cast<const mi_g1*>(projective.data()), projective.size(), out.data());
+        if (rc != MI_OK) throw std::runtime_error(std::string("normalize_batch: ") + mi_msm_last_error(context()));
+        return out;
+    }
+    static std::vector<G1Affine> batch_convert_to_mul_base(const std::vector<G1Projective>& bases) { return normalize_batch(bases); }
+    // iter::Sum (src/g1.rs:634-660)
+    static G1Projective sum(const std::vector<G1Projective>& xs) {
+        G1Projective r = zero();
+        if (!xs.empty()) mi_g1_sum(reinterpret_cast<const mi_g1*>(xs.data()), xs.size(), &r.p);
+        return r;
+    }
+};
+
+struct G2Projective {
+    mi_g2 p;                                        // blst_p2 (src/g2.rs:415-417)
+    using MulBase = G2Affine;
+    static constexpr bool NEGATION_IS_CHEAP = true;
+
+    static G2Projective zero() { G2Projective r; std::memset(&r.p, 0, sizeof r.p); return r; }
+    bool is_zero() const { mi_fp2 z{}; return std::memcmp(&p.z, &z, sizeof z) == 0; }
+
+    static Result<G2Projective> msm(const std::vector<G2Affine>& bases, const std::vector<Scalar>& scalars) {
+        if (bases.size() != scalars.size()) return Result<G2Projective>::Err(std::min(bases.size(), scalars.size()));
+        G2Projective out;
+        int rc = mi_msm_g2(context(), bases.data(), reinterpret_cast<const uint8_t*>(scalars.data()), bases.size(),
+                           MI_SCALAR_MONTGOMERY, &out.p);
+        return rc == MI_OK ? Result<G2Projective>::Ok(out) : Result<G2Projective>::Err(0);
+    }
+    static Result<G2Projective> msm_bigint(const std::vector<G2Affine>& bases, const std::vector<BigInteger256>& bigints) {
+        if (bases.size() != bigints.size()) return Result<G2Projective>::Err(std::min(bases.size(), bigints.size()));
+        G2Projective out;
+        int rc = mi_msm_g2(context(), bases.data(), reinterpret_cast<const uint8_t*>(bigints.data()), bases.size(),
+                           MI_SCALAR_CANONICAL, &out.p);
+        return rc == MI_OK ? Result<G2Projective>::Ok(out) : Result<G2Projective>::Err(0);
+    }
+    static std::vector<G2Affine> normalize_batch(const std::vector<G2Projective>& projective) {
+        std::vector<G2Affine> out(projective.size());
+        if (projective.empty()) return out;
+        int rc = mi_g2_normalize_batch(context(), reinterpret_cast<const mi_g2*>(projective.data()), projective.size(), out.data());
+        if (rc != MI_OK) throw std::runtime_error(std::string("normalize_batch: ") + mi_msm_last_error(context()));
+        return out;
+    }
+    static std::vector<G2Affine> batch_convert_to_mul_base(const std::vector<G2Projective>& bases) { return normalize_batch(bases); }
+    static G2Projective sum(const std::vector<G2Projective>& xs) {
+        G2Projective r = zero();
+        if (!xs.empty()) mi_g2_sum(reinterpret_cast<const mi_g2*>(xs.data()), xs.size(), &r.p);
+        return r;
+    }
+};
+
+}  // namespace ark_blst

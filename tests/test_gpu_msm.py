@@ -277,3 +277,35 @@ def test_normalize_batch_feeds_msm(ctx, co, pkg):
     ones = b"".join((1).to_bytes(32, "little") for _ in parts)
     total = ctx.msm("g1", affs, ones, len(parts), pkg.SCALAR_CANONICAL)
     assert _canon(co, "g1", total) == co.dlog_expected("g1", scalars, SEED_B + 21, n)
+
+
+def test_cpp_host_mirror_group_test(tmp_path, co, o):
+    """The compiled-language host side (ark-blst_amd/host/ark_blst_amd.hpp) running the reference's own MSM test shape
+    (src/tests.rs:50-67): msm(normalize_batch(bases), scalars) == sum b_i * s_i, for G1 and G2, plus the
+    Err(min(len)) convention and iter::Sum.  Built with g++ against the C-ABI library and run as a child process."""
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    exe = os.path.join(here, "host", "group_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(here, "host", "group_test.cpp"),
+                           "-L" + os.path.join(root, "ark-blst_amd", "lib"), "-larkblst_amd",
+                           "-Wl,-rpath," + os.path.join(root, "ark-blst_amd", "lib")])
+    rnd = random.Random(77)
+    for group, F, n in (("g1", o.F1, 300), ("g2", o.F2, 120)):
+        aff = 96 if group == "g1" else 192
+        raw = co.gen_bases(group, SEED_B + 30, n, 8)
+        canon = co.gen_scalars(SEED_S + 30, n)
+        jac = []
+        for i in range(n):
+            pt = o.affine_from_bytes(F, raw[aff * i:aff * (i + 1)])
+            lam = rnd.randrange(1, o.P) if group == "g1" else (rnd.randrange(1, o.P), rnd.randrange(o.P))
+            l2 = F.mul(lam, lam)
+            jac.append(o._felt_bytes(F, F.mul(pt[0], l2)) + o._felt_bytes(F, F.mul(pt[1], F.mul(l2, lam))) + o._felt_bytes(F, lam))
+        (tmp_path / f"{group}_bases_jac.bin").write_bytes(b"".join(jac))
+        (tmp_path / f"{group}_scalars_canon.bin").write_bytes(canon)
+        (tmp_path / f"{group}_scalars_mont.bin").write_bytes(co.fr_to_mont(canon))
+        (tmp_path / f"{group}_expected_affine.bin").write_bytes(co.dlog_expected(group, canon, SEED_B + 30, n))
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "g1 group_test OK" in out.stdout and "g2 group_test OK" in out.stdout
