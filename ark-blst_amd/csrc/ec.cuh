@@ -43,6 +43,14 @@ struct FpOps {
     static FP_HD E mul_b3(const E& a) { return fp28::fp_mul_small<12>(a); }
     static FP_HD bool is_zero_2p(const E& a) { return fp28::fp_is_zero_2p(a); }
     static FP_HD E select(bool take_b, const E& a, const E& b) { return fp28::fp_select(take_b, a, b); }
+    // "lazy" hooks used by xyzz_madd: here they are the normalising operations (safe everywhere)
+    static FP_HD E add_l(const E& a, const E& b) { return fp28::fp_add(a, b); }
+    template <int K>
+    static FP_HD E sub_l(const E& a, const E& b) { return fp28::fp_sub<K>(a, b); }
+    template <int K>
+    static FP_HD E neg_l(const E& a) { return fp28::fp_neg<K>(a); }
+    static FP_HD E sub8_wide(const E& a, const E& b) { return fp28::fp_sub<8>(a, b); }
+    static FP_HD E norm(const E& a) { return a; }
     static FP_HD bool limbs_all_zero(const E& a) {
         uint32_t z = 0;
 #pragma unroll
@@ -59,6 +67,14 @@ struct FpOpsInline : FpOps {
     static FP_HD E mul(const E& a, const E& b) { return fp28::fp_mul(a, b); }
     static FP_HD E sqr(const E& a) { return fp28::fp_sqr(a); }
     static FP_HD E mul2add(const E& a, const E& b, const E& c, const E& d) { return fp28::fp_mul2add(a, b, c, d); }
+    // truly lazy linear operations (no carry pass); limb bounds proved in tools/bounds_check.py check_madd_lazy()
+    static FP_HD E add_l(const E& a, const E& b) { return fp28::fp_add_lazy(a, b); }
+    template <int K>
+    static FP_HD E sub_l(const E& a, const E& b) { return fp28::fp_sub_lazy<K>(a, b); }
+    template <int K>
+    static FP_HD E neg_l(const E& a) { return fp28::fp_sub_lazy<K>(fp28::fp_zero(), a); }
+    static FP_HD E sub8_wide(const E& a, const E& b) { return fp28::fp_sub8_lazy_wide(a, b); }
+    static FP_HD E norm(const E& a) { return fp28::fp_norm(a); }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -114,6 +130,13 @@ struct Fp2OpsT {
     static FP_HD E sub(const E& a, const E& b) { return E{fp28::fp_sub<K>(a.c0, b.c0), fp28::fp_sub<K>(a.c1, b.c1)}; }
     template <int K>
     static FP_HD E neg(const E& a) { return E{fp28::fp_neg<K>(a.c0), fp28::fp_neg<K>(a.c1)}; }
+    static FP_HD E add_l(const E& a, const E& b) { return add(a, b); }
+    template <int K>
+    static FP_HD E sub_l(const E& a, const E& b) { return sub<K>(a, b); }
+    template <int K>
+    static FP_HD E neg_l(const E& a) { return neg<K>(a); }
+    static FP_HD E sub8_wide(const E& a, const E& b) { return sub<8>(a, b); }
+    static FP_HD E norm(const E& a) { return a; }
     static FP_HD E mul3(const E& a) { return E{fp28::fp_mul_small<3>(a.c0), fp28::fp_mul_small<3>(a.c1)}; }
     static FP_HD E mul_b3(const E& a) {
         E b3{fp28::fp_const(fp28::TWELVE), fp28::fp_const(fp28::TWELVE)};
@@ -200,19 +223,21 @@ FP_HD bool proj_is_inf_exact(const Proj<F>& p) { return F::limbs_all_zero(p.z); 
 template <class F>
 FP_HD bool xyzz_madd(Xyzz<F>& acc, const typename F::E& x2, const typename F::E& y2) {
     using E = typename F::E;
-    E t0 = F::template sub<16>(F::mul(x2, acc.zz), acc.x);    // P = U2 - X1          < 18p
-    E t2 = F::sqr(t0);                                         // PP
+    // limb classes: E exact (< 2^28, every multiplier output), N (<= 2^28+15 after norm), U (< 2^29.6, one lazy sub).
+    // Invariant: acc.x is N, acc.y / acc.zz / acc.zzz are E; x2 is E, y2 is E or U (negated).
+    E t0 = F::template sub_l<16>(F::mul(x2, acc.zz), acc.x);  // P = U2 - X1          < 18p   U
+    E t2 = F::sqr(t0);                                         // PP                           E
     if (F::is_zero_2p(t2)) return true;
-    E t1 = F::template sub<8>(F::mul(y2, acc.zzz), acc.y);    // R = S2 - Y1          < 10p
-    t0 = F::mul(t0, t2);                                       // PPP
+    E t1 = F::template sub_l<8>(F::mul(y2, acc.zzz), acc.y);  // R = S2 - Y1          < 10p   U
+    t0 = F::mul(t0, t2);                                       // PPP                          E
     acc.zz = F::mul(acc.zz, t2);                               // ZZ3 = ZZ1 PP
-    t2 = F::mul(acc.x, t2);                                    // Q = X1 PP
+    t2 = F::mul(acc.x, t2);                                    // Q = X1 PP                    E
     acc.zzz = F::mul(acc.zzz, t0);                             // ZZZ3 = ZZZ1 PPP
-    E ny = F::template neg<8>(acc.y);                          // 8p - Y1              < 8p
-    E t3 = F::add(F::add(t0, t2), t2);                         // PPP + 2Q             < 6p
-    acc.x = F::template sub<8>(F::sqr(t1), t3);                // X3 = R^2 - PPP - 2Q  < 10p
-    t2 = F::template sub<16>(t2, acc.x);                       // Q - X3               < 18p
-    acc.y = F::mul2add(t1, t2, ny, t0);                        // Y3 = R (Q - X3) + (8p - Y1) PPP, one reduction  < 2p
+    E ny = F::template neg_l<8>(acc.y);                        // 8p - Y1              < 8p    U
+    E t3 = F::add_l(F::add_l(t0, t2), t2);                     // PPP + 2Q             < 6p    limbs < 3 * 2^28
+    acc.x = F::norm(F::sub8_wide(F::sqr(t1), t3));             // X3 = R^2 - PPP - 2Q  < 10p   N
+    t2 = F::template sub_l<16>(t2, acc.x);                     // Q - X3               < 18p   U
+    acc.y = F::mul2add(t1, t2, ny, t0);                        // Y3 = R (Q - X3) + (8p - Y1) PPP, one reduction  < 2p  E
     return false;
 }
 

@@ -650,9 +650,9 @@ __global__ void __launch_bounds__(256, C::OCC) k_accumulate(const uint32_t* __re
             nent = sorted[e + 1];
             __builtin_prefetch(bases + (size_t)(nent & 0x7fffffffu) * Geo<C>::PT_WORDS, 0, 1);
         }
-        y = F::select((ent >> 31) != 0, y, F::template neg<4>(y));
+        y = F::select((ent >> 31) != 0, y, FA::template neg_l<4>(y));
         if (inf) {
-            acc.x = x; acc.y = y; acc.zz = F::one(); acc.zzz = F::one();
+            acc.x = x; acc.y = FA::norm(y); acc.zz = F::one(); acc.zzz = F::one();   // acc.y must be subtractable: N-form
             inf = false;
         } else if (ec::xyzz_madd<FA>(acc, x, y)) {
             break;  // exceptional pair at entry e: acc untouched

@@ -73,8 +73,8 @@ void h28_g1_bucket(const uint8_t* bases, const uint8_t* neg, size_t n, uint8_t* 
     for (; e < n; e++) {
         const uint8_t* p = bases + 96 * e;
         Fp x = load_blst(p), y = load_blst(p + 48);
-        if (neg && neg[e]) y = fp_neg<4>(y);
-        if (inf) { acc.x = x; acc.y = y; acc.zz = fp_one(); acc.zzz = fp_one(); inf = false; }
+        if (neg && neg[e]) y = FI::neg_l<4>(y);
+        if (inf) { acc.x = x; acc.y = FI::norm(y); acc.zz = fp_one(); acc.zzz = fp_one(); inf = false; }
         else if (ec::xyzz_madd<FI>(acc, x, y)) break;
     }
     Pj o = ec::proj_inf<F>();

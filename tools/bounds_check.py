@@ -112,10 +112,77 @@ def check_rcb_add(B=8):
     return X3.v, Y3.v, Z3.v
 
 
+# ------------------------------------------------------------------------------------------------
+# limb-level check of the LAZY hot-loop mixed addition (FpOpsInline: no carry pass after add / sub)
+E_LIMB = 1 << 28                     # exact multiplier output: limbs < 2^28
+N_LIMB = (1 << 28) + 15              # after fp_norm1
+SPREAD_LO = (1 << 28) + 64           # floor of S_K limbs
+SPREAD_HI = SPREAD_LO + (1 << 28) + 4
+SPREAD_B_LO = 3 * (1 << 28) + 64     # floor of S8B limbs
+SPREAD_B_HI = SPREAD_B_LO + (1 << 28) + 4
+COL_MAX = (1 << 64) - 14 * (1 << 56) - (1 << 37)   # room left in a 64-bit column for the a*b terms
+
+
+class L:
+    def __init__(self, v, l):
+        self.v, self.l = v, l
+
+
+def lmul(a, b):
+    assert a.v * b.v < LIM
+    assert 14 * a.l * b.l < COL_MAX, f"column overflow {a.l:#x} * {b.l:#x}"
+    return L(2, E_LIMB)
+
+
+def lmul2add(a, b, c, d):
+    assert a.v * b.v + c.v * d.v < LIM
+    assert 14 * (a.l * b.l + c.l * d.l) < COL_MAX, "column overflow in mul2add"
+    return L(2, E_LIMB)
+
+
+def ladd(a, b):
+    assert a.l + b.l < 1 << 32
+    return L(a.v + b.v, a.l + b.l)
+
+
+def lsub(K, a, b, wide=False):
+    lo, hi = (SPREAD_B_LO, SPREAD_B_HI) if wide else (SPREAD_LO, SPREAD_HI)
+    assert b.l <= lo, f"subtrahend limbs {b.l:#x} above the spread floor {lo:#x}"
+    assert b.v <= K - 1
+    assert a.l + hi < 1 << 32
+    return L(a.v + K, a.l + hi)
+
+
+def lnorm(a):
+    return L(a.v, (1 << 28) - 1 + (a.l >> 28) + 1)
+
+
+def check_madd_lazy():
+    """ec::xyzz_madd<FpOpsInline>: returns the limb bounds of the stored accumulator."""
+    X, Y, ZZ, ZZZ = L(10, N_LIMB), L(6, N_LIMB), L(2, E_LIMB), L(2, E_LIMB)
+    x2, y2 = L(2, E_LIMB), L(4, SPREAD_HI)            # y2 possibly negated lazily: S4 - y
+    for _ in range(3):                                 # iterate to a fixed point of the invariants
+        t0 = lsub(16, lmul(x2, ZZ), X)
+        t2 = lmul(t0, t0)
+        t1 = lsub(8, lmul(y2, ZZZ), Y)
+        t0 = lmul(t0, t2)
+        ZZ = lmul(ZZ, t2)
+        t2 = lmul(X, t2)
+        ZZZ = lmul(ZZZ, t0)
+        ny = lsub(8, L(0, 0), Y)
+        t3 = ladd(ladd(t0, t2), t2)
+        X = lnorm(lsub(8, lmul(t1, t1), t3, wide=True))
+        t2 = lsub(16, t2, X)
+        Y = lmul2add(t1, t2, ny, t0)
+        assert X.v <= 10 and X.l <= SPREAD_LO and Y.l <= SPREAD_LO and Y.v <= 6
+    return X.l, Y.l
+
+
 if __name__ == "__main__":
     print("limit a*b <", LIM)
     print("madd out bounds", check_madd())
     check_mdbl()
     print("xyzz->proj", check_xyzz_to_proj())
     print("rcb add out bounds", check_rcb_add())
+    print("lazy madd limb bounds (X, Y): %#x %#x" % check_madd_lazy())
     print("all bounds OK")
