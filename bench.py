@@ -44,6 +44,8 @@ def main() -> None:
     ap.add_argument("--group", default="g1", choices=["g1", "g2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "zero_one", "small64", "all_equal"],
+                    help="scalar distribution (secondary robustness figures; the headline is uniform)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device rehearses the N>1 path on a single-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (rehearsal only)")
@@ -83,6 +85,17 @@ def main() -> None:
     seed_b, seed_s = SEED_B + 1000 * rank, SEED_S + 1000 * rank
     bases = co.gen_bases(g, seed_b, n, ncpu)
     scalars = co.gen_scalars(seed_s, n)
+    if args.dist != "uniform":
+        import numpy as np
+        a = np.frombuffer(scalars, dtype=np.uint8).reshape(n, 32).copy()
+        if args.dist == "zero_one":      # R1CS-like witness: bits
+            a[:, 1:] = 0
+            a[:, 0] &= 1
+        elif args.dist == "small64":     # 64-bit values
+            a[:, 8:] = 0
+        else:                            # every scalar identical: all points in one bucket per window
+            a[:] = a[0]
+        scalars = a.tobytes()
     gen_s = time.time() - t0
 
     ctx = pkg.Context([local_rank])
@@ -180,7 +193,7 @@ def main() -> None:
             "bit_exact": bit_exact,
             "config": {"workload": f"{g.upper()} MSM, 2^{args.log_n} random bases+scalars per GPU, bases resident, scalars in HBM",
                        "points_per_gpu": n, "total_points": total_points, "window_bits": p0["window_bits"],
-                       "num_windows": p0["num_windows"], "parallelism": f"base-set sharded x{world}",
+                       "num_windows": p0["num_windows"], "parallelism": f"base-set sharded x{world}", "scalar_dist": args.dist,
                        "field_repr": "14 x 28-bit limbs in u32, products accumulated with v_mad_u64_u32"},
             "roofline": {"bound": "hbm", "kernel": f"k_accumulate<{g.upper()}C>", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
