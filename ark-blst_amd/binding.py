@@ -49,6 +49,8 @@ def load_library():
             getattr(L, f"mi_msm_{g}_device").argtypes = [vp, vp, sz, u, vp]
             getattr(L, f"mi_{g}_sum").argtypes = [vp, sz, vp]
             getattr(L, f"mi_{g}_normalize_batch").argtypes = [vp, vp, sz, vp]
+        L.mi_g1_deserialize_batch.argtypes = [vp, vp, sz, i, i, vp, vp]
+        L.mi_g1_serialize_batch.argtypes = [vp, vp, sz, i, vp]
         L.mi_msm_set_window_bits.argtypes = [vp, u]
         L.mi_msm_last_profile.argtypes = [vp, C.POINTER(Profile)]
         L.mi_msm_last_error.argtypes = [vp]
@@ -137,6 +139,21 @@ class Context:
         n = len(jac) // jb
         out = C.create_string_buffer(ab * n)
         self._check(getattr(self._L, f"mi_{group}_normalize_batch")(self._h, jac, n, out), f"mi_{group}_normalize_batch")
+        return out.raw
+
+    def g1_deserialize_batch(self, data: bytes, compressed: bool = True, validate: bool = True):
+        """CanonicalDeserialize for many G1 points: returns (packed blst affine points, status bytes)."""
+        size = 48 if compressed else 96
+        n = len(data) // size
+        out = C.create_string_buffer(96 * n)
+        st = C.create_string_buffer(n)
+        self._check(self._L.mi_g1_deserialize_batch(self._h, data, n, int(compressed), int(validate), out, st), "mi_g1_deserialize_batch")
+        return out.raw, st.raw
+
+    def g1_serialize_batch(self, points: bytes, compressed: bool = True) -> bytes:
+        n = len(points) // 96
+        out = C.create_string_buffer((48 if compressed else 96) * n)
+        self._check(self._L.mi_g1_serialize_batch(self._h, points, n, int(compressed), out), "mi_g1_serialize_batch")
         return out.raw
 
     def profile(self) -> dict:

@@ -888,6 +888,173 @@ __global__ void __launch_bounds__(64) k_elems_from_raw(const uint32_t* __restric
     ElemIO<E>::store(dev + (size_t)i * Geo<C>::SLOT, v);
 }
 
+// ---------------------------------------------------------------------------------------------- G1 point decoding
+// Bulk CanonicalDeserialize + Valid::check for G1 (/root/reference/src/g1.rs:386-431): ZCash/IETF encoding
+// (48-byte compressed / 96-byte uncompressed, big-endian, flag bits 0x80 compressed, 0x40 infinity, 0x20 y is the
+// lexicographically larger root) -> blst_p1_affine, with per-point status instead of the reference's unwrap():
+//   0 ok, 1 malformed encoding (flags, x >= p, no square root), 2 not on the curve, 3 not in the prime-order subgroup.
+// Decompression: y = (x^3 + 4)^((p+1)/4).  Subgroup check (blstrs is_torsion_free [ext]) by the endomorphism test
+// (beta x, y) == -[z^2](x, y), z = 0xd201000000010000 (M. Scott, eprint 2021/1130): two 64-bit double-and-add ladders
+// on the complete projective formulas instead of a 255-bit multiplication by r.
+__device__ __forceinline__ bool words_lt_p(const uint32_t (&w)[12]) {
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        uint64_t v = (uint64_t)w[k] - fp28c::P32[k] - borrow;
+        borrow = (v >> 32) & 1;
+    }
+    return borrow != 0;
+}
+__device__ __forceinline__ void be48_to_words(uint32_t (&w)[12], const uint8_t* b, uint32_t top_mask) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const uint8_t* q = b + 44 - 4 * k;  // word k = bytes [44-4k, 48-4k) big-endian
+        w[k] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
+    }
+    w[11] &= top_mask;
+}
+// canonical integer of an internal value (< 50p), exact 28-bit limbs
+__device__ __forceinline__ Fp fp_to_canonical(const Fp& a) {
+    Fp one_int = fp28::fp_zero();
+    one_int.l[0] = 1;
+    return fp28::fp_canon_2p(fp28::fp_mul_call(a, one_int));
+}
+__device__ __forceinline__ bool fp_equal(const Fp& a, const Fp& b) {  // a == b (mod p), a, b < 15p
+    return fp28::fp_is_zero_any(fp28::fp_sub<16>(a, b));
+}
+
+// r = [|z|] p on the complete formulas (63 doublings + 5 additions)
+__device__ __noinline__ void g1_mul_z(ec::Proj<ec::FpOps>& r, const ec::Proj<ec::FpOps>& p) {
+    using F = ec::FpOps;
+    r = p;
+#pragma unroll 1
+    for (int bit = 62; bit >= 0; bit--) {
+        ec::Proj<F> c = r;
+        ec::proj_add<F>(r, c);
+        if ((fp28c::Z_ABS >> bit) & 1) ec::proj_add<F>(r, p);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_deserialize_g1(const uint8_t* __restrict__ bytes, uint32_t n, int compressed, int validate,
+                                                        uint32_t* __restrict__ out_aff, uint8_t* __restrict__ status) {
+    using F = ec::FpOps;
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t size = compressed ? 48u : 96u;
+    const uint8_t* b = bytes + (size_t)i * size;
+    uint32_t* o = out_aff + (size_t)i * 24;
+    uint8_t b0 = b[0];
+    uint32_t c_flag = b0 >> 7, i_flag = (b0 >> 6) & 1, s_flag = (b0 >> 5) & 1;
+    uint32_t xw[12], yw[12];
+    be48_to_words(xw, b, 0x1fffffffu);
+#pragma unroll
+    for (int k = 0; k < 12; k++) yw[k] = 0;
+    if (!compressed) be48_to_words(yw, b + 48, 0xffffffffu);
+    uint8_t st = 0;
+    bool is_inf = false;
+    if (c_flag != (uint32_t)(compressed ? 1 : 0)) st = 1;
+    if (st == 0 && i_flag) {
+        uint32_t any = s_flag;
+#pragma unroll
+        for (int k = 0; k < 12; k++) any |= xw[k] | yw[k];
+        if (any) st = 1;
+        is_inf = true;
+    }
+    if (st == 0 && !is_inf) {
+        if (!words_lt_p(xw) || (!compressed && (!words_lt_p(yw) || s_flag))) st = 1;
+    }
+    Fp x = fp28::fp_zero(), y = fp28::fp_zero();
+    if (st == 0 && !is_inf) {
+        const Fp r2 = fp28::fp_const(fp28c::R2);
+        x = fp28::fp_mul_call(fp28::fp_unpack384(xw), r2);                       // canonical integer -> internal
+        Fp rhs = fp28::fp_add(fp28::fp_mul_call(fp28::fp_sqr_call(x), x), fp28::fp_const(fp28c::FOUR));   // x^3 + 4  < 4p
+        bool on_curve;
+        if (compressed) {
+            // y = rhs^((p+1)/4): left-to-right square and multiply over the 379-bit exponent
+            Fp acc = rhs;
+#pragma unroll 1
+            for (int bit = 377; bit >= 0; bit--) {  // top set bit of (p+1)/4 is bit 378
+                acc = fp28::fp_sqr_call(acc);
+                if ((fp28c::SQRT_EXP32[bit >> 5] >> (bit & 31)) & 1) acc = fp28::fp_mul_call(acc, rhs);
+            }
+            y = acc;
+            on_curve = fp_equal(fp28::fp_sqr_call(y), rhs);
+            if (!on_curve) st = 1;  // no square root: malformed compressed encoding
+            // pick the root the sort flag asks for
+            Fp yc = fp_to_canonical(y);
+            bool larger = false, decided = false;
+#pragma unroll
+            for (int k = NL - 1; k >= 0; k--) {
+                if (!decided && yc.l[k] != fp28c::HALF_P[k]) { larger = yc.l[k] > fp28c::HALF_P[k]; decided = true; }
+            }
+            if (larger != (s_flag != 0)) y = fp28::fp_neg<4>(y);
+        } else {
+            y = fp28::fp_mul_call(fp28::fp_unpack384(yw), r2);
+            on_curve = !validate || fp_equal(fp28::fp_sqr_call(y), rhs);
+            if (!on_curve) st = 2;
+        }
+        if (st == 0 && validate) {
+            ec::Proj<F> p1 = ec::proj_from_affine<F>(x, y), q, q2;
+            g1_mul_z(q, p1);
+            g1_mul_z(q2, q);                                                     // [z^2] P
+            // membership: (beta x, y) == -[z^2] P, i.e. X == beta x Z, Y == -y Z, Z != 0
+            Fp bx = fp28::fp_mul_call(x, fp28::fp_const(fp28c::BETA));
+            bool ok = !fp28::fp_is_zero_any(q2.z);
+            ok = ok && fp_equal(q2.x, fp28::fp_mul_call(bx, q2.z));
+            ok = ok && fp28::fp_is_zero_any(fp28::fp_add(q2.y, fp28::fp_mul_call(y, q2.z)));
+            if (!ok) st = 3;
+        }
+    }
+    uint32_t w[12];
+    bool keep = st == 0 && !is_inf;
+    fp28::fp_to_blst(w, x);
+#pragma unroll
+    for (int k = 0; k < 12; k++) o[k] = keep ? w[k] : 0u;
+    fp28::fp_to_blst(w, y);
+#pragma unroll
+    for (int k = 0; k < 12; k++) o[12 + k] = keep ? w[k] : 0u;
+    status[i] = st;
+}
+
+// affine (blst form) -> ZCash encoding
+__global__ void __launch_bounds__(256) k_serialize_g1(const uint32_t* __restrict__ aff, uint32_t n, int compressed, uint8_t* __restrict__ bytes) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* q = aff + (size_t)i * 24;
+    const uint32_t size = compressed ? 48u : 96u;
+    uint8_t* b = bytes + (size_t)i * size;
+    uint32_t any = 0;
+#pragma unroll 4
+    for (int k = 0; k < 24; k++) any |= q[k];
+    Fp x, y;
+    fp_from_raw(x, q);
+    fp_from_raw(y, q + 12);
+    Fp xc = fp_to_canonical(x), yc = fp_to_canonical(y);
+    uint32_t xw[12], yw[12];
+    fp28::fp_pack384(xw, xc);
+    fp28::fp_pack384(yw, yc);
+    bool larger = false, decided = false;
+#pragma unroll
+    for (int k = NL - 1; k >= 0; k--) {
+        if (!decided && yc.l[k] != fp28c::HALF_P[k]) { larger = yc.l[k] > fp28c::HALF_P[k]; decided = true; }
+    }
+    for (uint32_t k = 0; k < size; k++) b[k] = 0;
+    if (any == 0) {
+        b[0] = compressed ? 0xC0 : 0x40;
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        uint8_t* d = b + 44 - 4 * k;
+        d[0] = (uint8_t)(xw[k] >> 24); d[1] = (uint8_t)(xw[k] >> 16); d[2] = (uint8_t)(xw[k] >> 8); d[3] = (uint8_t)xw[k];
+        if (!compressed) {
+            uint8_t* e = b + 48 + 44 - 4 * k;
+            e[0] = (uint8_t)(yw[k] >> 24); e[1] = (uint8_t)(yw[k] >> 16); e[2] = (uint8_t)(yw[k] >> 8); e[3] = (uint8_t)yw[k];
+        }
+    }
+    if (compressed) b[0] |= (uint8_t)(0x80 | (larger ? 0x20 : 0));
+}
+
 // ---------------------------------------------------------------------------------------------- field test hook
 __global__ void __launch_bounds__(256) k_test_fp_op(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
                                                     uint32_t* __restrict__ out, uint32_t n) {

@@ -110,6 +110,15 @@ int mi_msm_g2_device(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scal
 int mi_g1_normalize_batch(mi_ctx *ctx, const mi_g1 *in, size_t n, mi_g1_affine *out);
 int mi_g2_normalize_batch(mi_ctx *ctx, const mi_g2 *in, size_t n, mi_g2_affine *out);
 
+/* Bulk point (de)serialisation for G1 in the ZCash / IETF format the reference uses (src/g1.rs:358-431:
+ * to_compressed / to_uncompressed, from_*_unchecked, Valid::check = is_on_curve && is_torsion_free): the SRS-loading
+ * step that feeds set_bases.  `compressed`: 48-byte (1) or 96-byte (0) encodings.  `validate` = ark_serialize::Validate.
+ * status[i]: 0 ok, 1 malformed encoding (the reference would unwrap() a None), 2 not on the curve, 3 not in the
+ * prime-order subgroup (2 and 3 = Err(InvalidData) of check()); rejected points are written as all-zero. */
+int mi_g1_deserialize_batch(mi_ctx *ctx, const uint8_t *bytes, size_t n, int compressed, int validate,
+                            mi_g1_affine *out, uint8_t *status);
+int mi_g1_serialize_batch(mi_ctx *ctx, const mi_g1_affine *points, size_t n, int compressed, uint8_t *bytes);
+
 /* Deterministic fold of partial sums (one per GPU / rank), in index order: the "all-reduce under the curve
  * group law" that follows the RCCL all-gather in the multi-process harness.  Host only. */
 int mi_g1_sum(const mi_g1 *partials, size_t n, mi_g1 *out);

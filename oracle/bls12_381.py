@@ -323,6 +323,67 @@ def g2_uncompressed(p) -> bytes:
 
 
 # ----------------------------------------------------------------------------------------------
+# ZCash / IETF point encoding + validity for G1 (src/g1.rs:358-431): CanonicalSerialize / Valid / CanonicalDeserialize
+# delegate to blstrs to_compressed / to_uncompressed / from_*_unchecked / is_on_curve / is_torsion_free [ext].
+# Status codes of the batched restatement: 0 ok, 1 malformed encoding (flags, x >= p, no square root),
+# 2 not on the curve, 3 not in the prime-order subgroup.
+# ----------------------------------------------------------------------------------------------
+DESER_OK, DESER_BAD_ENCODING, DESER_NOT_ON_CURVE, DESER_NOT_IN_SUBGROUP = 0, 1, 2, 3
+
+
+def g1_compress(p) -> bytes:
+    if p is INF:
+        return bytes([0xC0]) + bytes(47)
+    x, y = p
+    b = bytearray(x.to_bytes(48, "big"))
+    b[0] |= 0x80
+    if y > (P - 1) // 2:
+        b[0] |= 0x20
+    return bytes(b)
+
+
+def g1_in_subgroup(p) -> bool:
+    return p is INF or scalar_mul(F1, p, R_ORDER) is INF
+
+
+def g1_deserialize(b: bytes, compressed: bool, validate: bool):
+    """Returns (point or INF or None, status)."""
+    size = 48 if compressed else 96
+    assert len(b) == size
+    c_flag, i_flag, s_flag = b[0] >> 7, (b[0] >> 6) & 1, (b[0] >> 5) & 1
+    if c_flag != (1 if compressed else 0):
+        return None, DESER_BAD_ENCODING
+    body = bytes([b[0] & 0x1F]) + b[1:]
+    if i_flag:
+        if any(body) or s_flag:
+            return None, DESER_BAD_ENCODING
+        return INF, DESER_OK
+    x = int.from_bytes(body[:48], "big")
+    if x >= P:
+        return None, DESER_BAD_ENCODING
+    rhs = (x * x * x + 4) % P
+    if compressed:
+        y = pow(rhs, (P + 1) // 4, P)
+        if y * y % P != rhs:
+            return None, DESER_BAD_ENCODING
+        if (y > (P - 1) // 2) != bool(s_flag):
+            y = P - y
+    else:
+        if s_flag:
+            return None, DESER_BAD_ENCODING
+        y = int.from_bytes(body[48:], "big")
+        if y >= P:
+            return None, DESER_BAD_ENCODING
+    pt = (x, y)
+    if validate:
+        if y * y % P != rhs:
+            return None, DESER_NOT_ON_CURVE
+        if not g1_in_subgroup(pt):
+            return None, DESER_NOT_IN_SUBGROUP
+    return pt, DESER_OK
+
+
+# ----------------------------------------------------------------------------------------------
 # deterministic input generators shared by tests / bench (BASELINE.md §3)
 # ----------------------------------------------------------------------------------------------
 _M64 = 0xFFFFFFFFFFFFFFFF

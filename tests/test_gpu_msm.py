@@ -309,3 +309,50 @@ def test_cpp_host_mirror_group_test(tmp_path, co, o):
     out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "g1 group_test OK" in out.stdout and "g2 group_test OK" in out.stdout
+
+
+def test_g1_deserialize_golden(ctx):
+    """Every encoding class of tests/golden (valid, infinity, not in subgroup, no square root, not on curve, x >= p,
+    bad flags) through mi_g1_deserialize_batch: status and decoded point."""
+    for case in _golden()["g1_encoding"]:
+        pts, st = ctx.g1_deserialize_batch(bytes.fromhex(case["bytes"]), case["compressed"], case["validate"])
+        assert st[0] == case["status"], case["name"]
+        assert pts == (bytes.fromhex(case["affine"]) if case["status"] == 0 else bytes(96)), case["name"]
+
+
+@pytest.mark.parametrize("compressed", [True, False])
+def test_g1_serialize_roundtrip_and_oracle(ctx, co, o, compressed):
+    """encode -> decode round trip on 3000 points (with infinity sprinkled in) and the encoder against the oracle's
+    to_compressed / to_uncompressed restatement (src/g1.rs:358-384)."""
+    n = 3000
+    raw = bytearray(co.gen_bases("g1", SEED_B + 40, n, 8))
+    for i in range(0, n, 97):
+        raw[96 * i:96 * (i + 1)] = bytes(96)
+    raw = bytes(raw)
+    enc = ctx.g1_serialize_batch(raw, compressed)
+    size = 48 if compressed else 96
+    for i in list(range(0, n, 131)) + [0, 97]:
+        pt = o.affine_from_bytes(o.F1, raw[96 * i:96 * (i + 1)])
+        want = o.g1_compress(pt) if compressed else o.g1_uncompressed(pt)
+        assert enc[size * i:size * (i + 1)] == want, i
+    dec, st = ctx.g1_deserialize_batch(enc, compressed, True)
+    assert st == bytes(n) and dec == raw
+    # flipping the sort flag of a compressed point yields the negated point
+    if compressed:
+        flipped = bytes([enc[48] ^ 0x20]) + enc[49:96]      # point 1 (point 0 was replaced by infinity)
+        dec1, st1 = ctx.g1_deserialize_batch(flipped, True, True)
+        assert st1 == b"\0"
+        assert o.affine_from_bytes(o.F1, dec1) == o.aff_neg(o.F1, o.affine_from_bytes(o.F1, raw[96:192]))
+        # and a sort flag on the infinity encoding is malformed
+        assert ctx.g1_deserialize_batch(bytes([enc[0] ^ 0x20]) + enc[1:48], True, True)[1] == b"\x01"
+
+
+def test_g1_deserialize_rejects_mixed_batch(ctx, co, o):
+    """A batch mixing valid points with each rejection class keeps per-element status (SRS loading must not abort)."""
+    g = _golden()["g1_encoding"]
+    comp = [c for c in g if c["compressed"] and c["validate"]]
+    blob = b"".join(bytes.fromhex(c["bytes"]) for c in comp)
+    pts, st = ctx.g1_deserialize_batch(blob, True, True)
+    assert list(st) == [c["status"] for c in comp]
+    for k, c in enumerate(comp):
+        assert pts[96 * k:96 * (k + 1)] == (bytes.fromhex(c["affine"]) if c["status"] == 0 else bytes(96))

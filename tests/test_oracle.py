@@ -73,3 +73,22 @@ def test_c_oracle_fold_and_sum(co, o):
     assert co.to_affine("g1", co.fold_windows("g1", wins, 5, c)) == o.affine_to_bytes(o.F1, want)
     want = o.scalar_mul(o.F1, o.G1_GEN, sum(ks) % o.R_ORDER)
     assert co.to_affine("g1", co.sum_jac("g1", wins, 5)) == o.affine_to_bytes(o.F1, want)
+
+
+def test_g1_encoding_oracle_vs_fixtures(o, golden):
+    """ZCash/IETF G1 encoding restatement (src/g1.rs:358-431) against the frozen fixtures and the published
+    compressed generator (97f1d3a7...c6bb)."""
+    assert o.g1_compress(o.G1_GEN).hex().startswith("97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905")
+    for case in golden["g1_encoding"]:
+        pt, st = o.g1_deserialize(bytes.fromhex(case["bytes"]), case["compressed"], case["validate"])
+        assert st == case["status"], case["name"]
+        if st == 0:
+            assert o.affine_to_bytes(o.F1, pt).hex() == case["affine"]
+            enc = o.g1_compress(pt) if case["compressed"] else o.g1_uncompressed(pt)
+            if case["name"].startswith(("valid", "infinity", "generator")):
+                assert enc == bytes.fromhex(case["bytes"])
+    # the endomorphism constant used by the GPU subgroup test: (beta x, y) = -[z^2] P on G1
+    beta = 0x5F19672FDF76CE51BA69C6076A0F77EADDB3A93BE6F89688DE17D813620A00022E01FFFFFFFEFFFE
+    z = 0xD201000000010000
+    q = o.scalar_mul(o.F1, o.G1_GEN, (z * z) % o.R_ORDER)
+    assert (beta * o.G1_X % o.P, o.G1_Y) == o.aff_neg(o.F1, q)
