@@ -61,6 +61,7 @@ Plan make_plan(size_t n, unsigned forced_c) {
         uint32_t lo_bits = std::min<uint32_t>(std::min<uint32_t>(8, c - 1), 31 - idx_bits);
         if (((1u << (c - 1)) >> lo_bits) > msmk::SORT_MAX_COUNTERS) continue;
         uint32_t nwin = (256 + c - 1) / c;
+        if ((uint64_t)n * nwin >= (1ull << 32)) continue;   // entry offsets are 32-bit
         double nb = (double)(1u << (c - 1));
         double cost = (double)n * nwin + 6.0 * nb * nwin;
         // The top window holds only 255 - c (nwin - 1) significant bits, so its n entries share 2^top_bits buckets;
@@ -520,7 +521,7 @@ void shard_range(size_t n, size_t g, size_t k, size_t& lo, size_t& hi) {
 template <class C>
 int set_bases_impl(mi_ctx* ctx, const void* bases, size_t n) {
     if (!ctx || (n && !bases)) return fail(ctx, MI_E_INVALID, "invalid argument");
-    if (n > 0x3fffffffull) return fail(ctx, MI_E_INVALID, "n exceeds 2^30-1 points");
+    if ((n + ctx->devs.size() - 1) / ctx->devs.size() > (1ull << 26)) return fail(ctx, MI_E_INVALID, "more than 2^26 points per device");
     std::lock_guard<std::mutex> lk(ctx->mu);
     return guarded(ctx, [&]() -> int {
         size_t g = ctx->devs.size();
@@ -546,7 +547,9 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
     using J = typename HostCurve<C>::J;
     const uint8_t* bases = static_cast<const uint8_t*>(bases_v);
     if (!ctx || !out || (n && !scalars) || fmt > 1) return fail(ctx, MI_E_INVALID, "invalid argument");
-    if (n > 0x3fffffffull) return fail(ctx, MI_E_INVALID, "n exceeds 2^30-1 points per call");
+    // 32-bit entry offsets: n * windows must stay below 2^32 on every device (2^26 points leave room for c >= 8)
+    if ((n + ctx->devs.size() - 1) / ctx->devs.size() > (1ull << 26))
+        return fail(ctx, MI_E_INVALID, "more than 2^26 points per device in one call: split the MSM and add the results (mi_g1_sum)");
     std::lock_guard<std::mutex> lk(ctx->mu);
     return guarded(ctx, [&]() -> int {
         size_t g = ctx->devs.size();

@@ -197,7 +197,25 @@ __device__ __forceinline__ void load_scalar(uint32_t (&s)[8], const uint32_t* sc
     const uint4* q = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
     uint4 a = q[0], b = q[1];
     s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
-    if (fmt == 1) fr_from_mont(s);
+    if (fmt == 1) {
+        fr_from_mont(s);
+    } else {
+        // canonical integers are expected below r, but any 256-bit value is accepted: subtract r up to twice
+        // (2^256 < 2.3 r) so the signed recoding never carries out of the top window
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++) {
+            uint32_t d[8];
+            uint64_t borrow = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint64_t v = (uint64_t)s[k] - fp28c::FR_MOD[k] - borrow;
+                d[k] = (uint32_t)v;
+                borrow = (v >> 32) & 1;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] = borrow ? s[k] : d[k];
+        }
+    }
 }
 
 // c-bit field starting at bit `off` of a 256-bit little-endian integer (zero beyond bit 255)

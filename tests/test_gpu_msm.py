@@ -356,3 +356,15 @@ def test_g1_deserialize_rejects_mixed_batch(ctx, co, o):
     assert list(st) == [c["status"] for c in comp]
     for k, c in enumerate(comp):
         assert pts[96 * k:96 * (k + 1)] == (bytes.fromhex(c["affine"]) if c["status"] == 0 else bytes(96))
+
+
+def test_g1_msm_unreduced_canonical_scalars(ctx, co, o, pkg):
+    """msm_bigint accepts any 256-bit integer: values >= r (up to 2^256 - 1) act as their residue mod r."""
+    n = 40
+    bases = co.gen_bases("g1", SEED_B + 50, n, 2)
+    rnd = random.Random(50)
+    vals = [(1 << 256) - 1, o.R_ORDER, o.R_ORDER + 1, 2 * o.R_ORDER + 5, (1 << 255) + 12345] + [rnd.randrange(1 << 256) for _ in range(n - 5)]
+    raw = b"".join(v.to_bytes(32, "little") for v in vals)
+    red = b"".join((v % o.R_ORDER).to_bytes(32, "little") for v in vals)
+    got = ctx.msm("g1", bases, raw, n, pkg.SCALAR_CANONICAL)
+    assert _canon(co, "g1", got) == co.dlog_expected("g1", red, SEED_B + 50, n)
