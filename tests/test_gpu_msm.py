@@ -368,3 +368,19 @@ def test_g1_msm_unreduced_canonical_scalars(ctx, co, o, pkg):
     red = b"".join((v % o.R_ORDER).to_bytes(32, "little") for v in vals)
     got = ctx.msm("g1", bases, raw, n, pkg.SCALAR_CANONICAL)
     assert _canon(co, "g1", got) == co.dlog_expected("g1", red, SEED_B + 50, n)
+
+
+def test_g1_msm_2_22_closed_form_and_mixed_skew(ctx, co, pkg):
+    """Scale check inside the suite (2^24 is exercised by bench.py's bit_exact flag): 2^22 points, uniform scalars with a
+    quarter of them replaced by small / repeated values, against the closed form."""
+    import numpy as np
+
+    n = 1 << 22
+    bases = co.gen_bases("g1", SEED_B + 60, n, 16)
+    a = np.frombuffer(co.gen_scalars(SEED_S + 60, n), dtype=np.uint8).reshape(n, 32).copy()
+    a[0:n // 8, 1:] = 0            # byte-sized scalars
+    a[n // 8:n // 4] = a[n // 8]   # one value repeated 2^19 times
+    scalars = a.tobytes()
+    ctx.set_bases("g1", bases, n)
+    got = ctx.msm("g1", None, scalars, n, pkg.SCALAR_CANONICAL)
+    assert _canon(co, "g1", got) == co.dlog_expected("g1", scalars, SEED_B + 60, n)
