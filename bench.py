@@ -46,6 +46,9 @@ def main() -> None:
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zero_one", "small64", "all_equal"],
                     help="scalar distribution (secondary robustness figures; the headline is uniform)")
+    ap.add_argument("--concurrency", type=int, default=1,
+                    help="host threads issuing MSM calls concurrently (each with its own context; the trait method is\n"
+                         "re-entrant, SURVEY 8b).  1 = blocking calls back to back (headline).")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device rehearses the N>1 path on a single-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (rehearsal only)")
@@ -128,18 +131,68 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     prof_acc = []
-    fence()
-    t0 = time.perf_counter()
-    result = b""
-    for _ in range(args.steps):
-        result = step()
+    if args.concurrency > 1 and world == 1:
+        # K steps issued from `concurrency` host threads, each with its own context and stream on the same GPU
+        import threading
+        ctxs = [ctx] + [pkg.Context([local_rank]) for _ in range(args.concurrency - 1)]
+        for c in ctxs[1:]:
+            c.set_bases(g, bases, n)
+            c.msm_device(g, d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)
+        results = [b""] * args.steps
+        def worker(t):
+            for k in range(t, args.steps, args.concurrency):
+                results[k] = ctxs[t].msm_device(g, d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)
+        fence()
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(args.concurrency)]
+        for x in th: x.start()
+        for x in th: x.join()
+        fence()
+        elapsed = time.perf_counter() - t0
+        result = results[-1]
+        # equal as curve points (the Jacobian representative depends on the order entries reached their bucket)
+        assert len({co.to_affine(g, r) for r in results}) == 1
         prof_acc.append(ctx.profile())
-    fence()
-    elapsed = time.perf_counter() - t0
+        for c in ctxs[1:]:
+            c.close()
+    else:
+        fence()
+        t0 = time.perf_counter()
+        result = b""
+        for _ in range(args.steps):
+            result = step()
+            prof_acc.append(ctx.profile())
+        fence()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    # ---- secondary figure (N = 1 only): the same K steps issued by TWO host threads, each with its own context (the
+    # trait method is re-entrant and arkworks calls it from rayon workers): one call's sort / reduce / host
+    # fold overlap the other's accumulate.  Not the headline value.
+    two_thread = None
+    if world == 1 and args.concurrency == 1:
+        import threading
+        ctx2 = pkg.Context([local_rank])
+        ctx2.set_bases(g, bases, n)
+        ctx2.msm_device(g, d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)
+        cs = [ctx, ctx2]
+        res2 = [b""] * args.steps
+        def worker(t):
+            for k in range(t, args.steps, 2):
+                res2[k] = cs[t].msm_device(g, d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)
+        fence()
+        t1 = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+        for x in th: x.start()
+        for x in th: x.join()
+        fence()
+        e2 = time.perf_counter() - t1
+        ok2 = len({co.to_affine(g, r) for r in res2 + [result]}) == 1
+        two_thread = {"value": n * args.steps / e2, "unit": "points/s", "ms_per_step": e2 / args.steps * 1e3, "same_result": ok2}
+        ctx2.close()
 
     # ---- parity: closed form over ALL ranks' inputs
     expected_parts = []
@@ -193,7 +246,7 @@ def main() -> None:
             "bit_exact": bit_exact,
             "config": {"workload": f"{g.upper()} MSM, 2^{args.log_n} random bases+scalars per GPU, bases resident, scalars in HBM",
                        "points_per_gpu": n, "total_points": total_points, "window_bits": p0["window_bits"],
-                       "num_windows": p0["num_windows"], "parallelism": f"base-set sharded x{world}", "scalar_dist": args.dist,
+                       "num_windows": p0["num_windows"], "parallelism": f"base-set sharded x{world}", "scalar_dist": args.dist, "host_threads_issuing": args.concurrency,
                        "field_repr": "14 x 28-bit limbs in u32, products accumulated with v_mad_u64_u32"},
             "roofline": {"bound": "hbm", "kernel": f"k_accumulate<{g.upper()}C>", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
@@ -208,6 +261,7 @@ def main() -> None:
             "phases_ms": {k: sum(p[k] for p in prof_acc) / len(prof_acc) for k in
                           ("digits_ms", "scan_ms", "scatter_ms", "accumulate_ms", "reduce_ms", "d2h_ms", "host_fold_ms", "total_ms")},
             "input_gen_s": gen_s,
+            "two_host_threads": two_thread,
         }
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
             best = 1e30
