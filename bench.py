@@ -49,6 +49,7 @@ def main() -> None:
     ap.add_argument("--concurrency", type=int, default=1,
                     help="host threads issuing MSM calls concurrently (each with its own context; the trait method is\n"
                          "re-entrant, SURVEY 8b).  1 = blocking calls back to back (headline).")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the two-host-thread secondary figure (profiling runs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device rehearses the N>1 path on a single-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (rehearsal only)")
@@ -173,7 +174,7 @@ def main() -> None:
     # trait method is re-entrant and arkworks calls it from rayon workers): one call's sort / reduce / host
     # fold overlap the other's accumulate.  Not the headline value.
     two_thread = None
-    if world == 1 and args.concurrency == 1:
+    if world == 1 and args.concurrency == 1 and not args.no_secondary:
         import threading
         ctx2 = pkg.Context([local_rank])
         ctx2.set_bases(g, bases, n)

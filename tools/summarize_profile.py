@@ -27,6 +27,6 @@ for k, v in out.items():
         v["hbm_bytes_per_launch_raw"] = (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
     if "GRBM_GUI_ACTIVE" in v:
         v["gpu_cycles_per_launch"] = v["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
-json.dump({"source": "rocprofv3 --pmc passes of `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline` (G1, 2^20, c=16)",
+json.dump({"source": "rocprofv3 --pmc passes of `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary` (G1, 2^20, c=16)",
            "kernels": out}, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
 print("wrote profiles/%s_kernel_stats.csv, profiles/%s_pmc_summary.json" % (tag, tag))
