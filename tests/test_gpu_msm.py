@@ -384,3 +384,45 @@ def test_g1_msm_2_22_closed_form_and_mixed_skew(ctx, co, pkg):
     ctx.set_bases("g1", bases, n)
     got = ctx.msm("g1", None, scalars, n, pkg.SCALAR_CANONICAL)
     assert _canon(co, "g1", got) == co.dlog_expected("g1", scalars, SEED_B + 60, n)
+
+
+def test_g1_g2_msm_fuzz_configs(ctx, co, o, pkg):
+    """Seeded fuzz over sizes, window sizes, scalar formats and scalar distributions (with infinity bases and repeated
+    bases mixed in), G1 and G2, each against the oracle's Pippenger on the same inputs."""
+    rnd = random.Random(2026)
+    pool_n = 4000
+    pools = {"g1": co.gen_bases("g1", SEED_B + 70, pool_n, 8), "g2": co.gen_bases("g2", SEED_B + 71, 1500, 8)}
+    for it in range(40):
+        group = "g1" if it % 4 else "g2"
+        aff = 96 if group == "g1" else 192
+        limit = pool_n if group == "g1" else 1500
+        n = rnd.choice([1, 2, 5, 31, 64, 65, 100, 257, 1000, rnd.randrange(1, limit)])
+        idx = [rnd.randrange(limit) for _ in range(n)]
+        if rnd.random() < 0.5:                      # repeated bases
+            idx = [idx[rnd.randrange(max(1, n // 4))] for _ in range(n)]
+        bases = bytearray(b"".join(pools[group][aff * i:aff * (i + 1)] for i in idx))
+        for k in range(n):
+            if rnd.random() < 0.05:
+                bases[aff * k:aff * (k + 1)] = bytes(aff)   # infinity
+        kind = rnd.choice(["uniform", "bits", "small", "equal", "edge"])
+        if kind == "uniform":
+            sc = [rnd.randrange(o.R_ORDER) for _ in range(n)]
+        elif kind == "bits":
+            sc = [rnd.randrange(2) for _ in range(n)]
+        elif kind == "small":
+            sc = [rnd.randrange(1 << rnd.choice([8, 16, 40, 64])) for _ in range(n)]
+        elif kind == "equal":
+            sc = [rnd.randrange(o.R_ORDER)] * n
+        else:
+            sc = [rnd.choice([0, 1, o.R_ORDER - 1, o.R_ORDER - 2, (1 << 255) - 19 if False else 2]) for _ in range(n)]
+        canon = b"".join(o.fr_to_canon_bytes(x) for x in sc)
+        fmt = rnd.choice([pkg.SCALAR_CANONICAL, pkg.SCALAR_MONTGOMERY])
+        data = canon if fmt == pkg.SCALAR_CANONICAL else co.fr_to_mont(canon)
+        c = rnd.choice([0, 0, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+        ctx.set_window_bits(c)
+        try:
+            got = ctx.msm(group, bytes(bases), data, n, fmt)
+        finally:
+            ctx.set_window_bits(0)
+        want = co.msm(group, bytes(bases), canon, n, 0, 4)
+        assert _canon(co, group, got) == _canon(co, group, want), (it, group, n, kind, c, fmt)
