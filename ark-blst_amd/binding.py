@@ -49,8 +49,9 @@ def load_library():
             getattr(L, f"mi_msm_{g}_device").argtypes = [vp, vp, sz, u, vp]
             getattr(L, f"mi_{g}_sum").argtypes = [vp, sz, vp]
             getattr(L, f"mi_{g}_normalize_batch").argtypes = [vp, vp, sz, vp]
-        L.mi_g1_deserialize_batch.argtypes = [vp, vp, sz, i, i, vp, vp]
-        L.mi_g1_serialize_batch.argtypes = [vp, vp, sz, i, vp]
+        for g in ("g1", "g2"):
+            getattr(L, f"mi_{g}_deserialize_batch").argtypes = [vp, vp, sz, i, i, vp, vp]
+            getattr(L, f"mi_{g}_serialize_batch").argtypes = [vp, vp, sz, i, vp]
         L.mi_msm_set_window_bits.argtypes = [vp, u]
         L.mi_msm_last_profile.argtypes = [vp, C.POINTER(Profile)]
         L.mi_msm_last_error.argtypes = [vp]
@@ -141,20 +142,29 @@ class Context:
         self._check(getattr(self._L, f"mi_{group}_normalize_batch")(self._h, jac, n, out), f"mi_{group}_normalize_batch")
         return out.raw
 
-    def g1_deserialize_batch(self, data: bytes, compressed: bool = True, validate: bool = True):
-        """CanonicalDeserialize for many G1 points: returns (packed blst affine points, status bytes)."""
-        size = 48 if compressed else 96
+    def deserialize_batch(self, group: str, data: bytes, compressed: bool = True, validate: bool = True):
+        """CanonicalDeserialize for many points: returns (packed blst affine points, status bytes)."""
+        unit = 48 if group == "g1" else 96
+        size = unit if compressed else 2 * unit
         n = len(data) // size
-        out = C.create_string_buffer(96 * n)
+        out = C.create_string_buffer(2 * unit * n)
         st = C.create_string_buffer(n)
-        self._check(self._L.mi_g1_deserialize_batch(self._h, data, n, int(compressed), int(validate), out, st), "mi_g1_deserialize_batch")
+        self._check(getattr(self._L, f"mi_{group}_deserialize_batch")(self._h, data, n, int(compressed), int(validate), out, st),
+                    f"mi_{group}_deserialize_batch")
         return out.raw, st.raw
 
-    def g1_serialize_batch(self, points: bytes, compressed: bool = True) -> bytes:
-        n = len(points) // 96
-        out = C.create_string_buffer((48 if compressed else 96) * n)
-        self._check(self._L.mi_g1_serialize_batch(self._h, points, n, int(compressed), out), "mi_g1_serialize_batch")
+    def serialize_batch(self, group: str, points: bytes, compressed: bool = True) -> bytes:
+        unit = 48 if group == "g1" else 96
+        n = len(points) // (2 * unit)
+        out = C.create_string_buffer((unit if compressed else 2 * unit) * n)
+        self._check(getattr(self._L, f"mi_{group}_serialize_batch")(self._h, points, n, int(compressed), out), f"mi_{group}_serialize_batch")
         return out.raw
+
+    def g1_deserialize_batch(self, data: bytes, compressed: bool = True, validate: bool = True):
+        return self.deserialize_batch("g1", data, compressed, validate)
+
+    def g1_serialize_batch(self, points: bytes, compressed: bool = True) -> bytes:
+        return self.serialize_batch("g1", points, compressed)
 
     def profile(self) -> dict:
         p = Profile()

@@ -604,6 +604,72 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
     });
 }
 
+// shared driver of the (de)serialisation entry points: `unit` = compressed size in bytes (48 G1, 96 G2)
+template <class KDe>
+int deserialize_impl(mi_ctx* ctx, KDe kernel, size_t unit, const uint8_t* bytes, size_t n, int compressed, int validate, void* out,
+                     uint8_t* status) {
+    if (!ctx || (n && (!bytes || !out || !status))) return fail(ctx, MI_E_INVALID, "invalid argument");
+    if (n == 0) return MI_OK;
+    if (n > 0x7fffffffull) return fail(ctx, MI_E_INVALID, "n too large");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return guarded(ctx, [&]() -> int {
+        DevState& d = ctx->devs[0];
+        HIP_TRY(hipSetDevice(d.dev));
+        size_t sz = compressed ? unit : 2 * unit, aff = 2 * unit;
+        DevBuf din, dout, dst;
+        try {
+            din.ensure(n * sz); dout.ensure(n * aff); dst.ensure(n);
+            HIP_TRY(hipEventRecord(d.ev[0], d.stream));
+            HIP_TRY(hipMemcpyAsync(din.p, bytes, n * sz, hipMemcpyHostToDevice, d.stream));
+            HIP_TRY(hipEventRecord(d.ev[1], d.stream));
+            hipLaunchKernelGGL(kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, d.stream, (const uint8_t*)din.p, (uint32_t)n,
+                               compressed ? 1 : 0, validate ? 1 : 0, (uint32_t*)dout.p, (uint8_t*)dst.p);
+            HIP_TRY(hipEventRecord(d.ev[2], d.stream));
+            HIP_TRY(hipMemcpyAsync(out, dout.p, n * aff, hipMemcpyDeviceToHost, d.stream));
+            HIP_TRY(hipMemcpyAsync(status, dst.p, n, hipMemcpyDeviceToHost, d.stream));
+            HIP_TRY(hipStreamSynchronize(d.stream));
+            HIP_TRY(hipGetLastError());
+            ctx->prof = mi_profile{};
+            ctx->prof.n = n;
+            ctx->prof.h2d_ms = ev_ms(d.ev[0], d.ev[1]);
+            ctx->prof.accumulate_ms = ev_ms(d.ev[1], d.ev[2]);
+        } catch (...) {
+            din.release(); dout.release(); dst.release();
+            throw;
+        }
+        din.release(); dout.release(); dst.release();
+        return MI_OK;
+    });
+}
+
+template <class KSer>
+int serialize_impl(mi_ctx* ctx, KSer kernel, size_t unit, const void* points, size_t n, int compressed, uint8_t* bytes) {
+    if (!ctx || (n && (!bytes || !points))) return fail(ctx, MI_E_INVALID, "invalid argument");
+    if (n == 0) return MI_OK;
+    if (n > 0x7fffffffull) return fail(ctx, MI_E_INVALID, "n too large");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return guarded(ctx, [&]() -> int {
+        DevState& d = ctx->devs[0];
+        HIP_TRY(hipSetDevice(d.dev));
+        size_t sz = compressed ? unit : 2 * unit, aff = 2 * unit;
+        DevBuf din, dout;
+        try {
+            din.ensure(n * aff); dout.ensure(n * sz);
+            HIP_TRY(hipMemcpyAsync(din.p, points, n * aff, hipMemcpyHostToDevice, d.stream));
+            hipLaunchKernelGGL(kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, d.stream, (const uint32_t*)din.p, (uint32_t)n,
+                               compressed ? 1 : 0, (uint8_t*)dout.p);
+            HIP_TRY(hipMemcpyAsync(bytes, dout.p, n * sz, hipMemcpyDeviceToHost, d.stream));
+            HIP_TRY(hipStreamSynchronize(d.stream));
+            HIP_TRY(hipGetLastError());
+        } catch (...) {
+            din.release(); dout.release();
+            throw;
+        }
+        din.release(); dout.release();
+        return MI_OK;
+    });
+}
+
 }  // namespace
 
 extern "C" {
@@ -689,65 +755,17 @@ int mi_g2_normalize_batch(mi_ctx* ctx, const mi_g2* in, size_t n, mi_g2_affine* 
 
 int mi_g1_deserialize_batch(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int validate, mi_g1_affine* out,
                             uint8_t* status) {
-    if (!ctx || (n && (!bytes || !out || !status))) return fail(ctx, MI_E_INVALID, "invalid argument");
-    if (n == 0) return MI_OK;
-    if (n > 0x7fffffffull) return fail(ctx, MI_E_INVALID, "n too large");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    return guarded(ctx, [&]() -> int {
-        DevState& d = ctx->devs[0];
-        HIP_TRY(hipSetDevice(d.dev));
-        size_t sz = compressed ? 48 : 96;
-        DevBuf din, dout, dst;
-        try {
-            din.ensure(n * sz); dout.ensure(n * 96); dst.ensure(n);
-            HIP_TRY(hipEventRecord(d.ev[0], d.stream));
-            HIP_TRY(hipMemcpyAsync(din.p, bytes, n * sz, hipMemcpyHostToDevice, d.stream));
-            HIP_TRY(hipEventRecord(d.ev[1], d.stream));
-            hipLaunchKernelGGL(msmk::k_deserialize_g1, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, d.stream, (const uint8_t*)din.p,
-                               (uint32_t)n, compressed ? 1 : 0, validate ? 1 : 0, (uint32_t*)dout.p, (uint8_t*)dst.p);
-            HIP_TRY(hipEventRecord(d.ev[2], d.stream));
-            HIP_TRY(hipMemcpyAsync(out, dout.p, n * 96, hipMemcpyDeviceToHost, d.stream));
-            HIP_TRY(hipMemcpyAsync(status, dst.p, n, hipMemcpyDeviceToHost, d.stream));
-            HIP_TRY(hipStreamSynchronize(d.stream));
-            HIP_TRY(hipGetLastError());
-            ctx->prof = mi_profile{};
-            ctx->prof.n = n;
-            ctx->prof.h2d_ms = ev_ms(d.ev[0], d.ev[1]);
-            ctx->prof.accumulate_ms = ev_ms(d.ev[1], d.ev[2]);
-        } catch (...) {
-            din.release(); dout.release(); dst.release();
-            throw;
-        }
-        din.release(); dout.release(); dst.release();
-        return MI_OK;
-    });
+    return deserialize_impl(ctx, msmk::k_deserialize_g1, 48, bytes, n, compressed, validate, out, status);
 }
-
 int mi_g1_serialize_batch(mi_ctx* ctx, const mi_g1_affine* points, size_t n, int compressed, uint8_t* bytes) {
-    if (!ctx || (n && (!bytes || !points))) return fail(ctx, MI_E_INVALID, "invalid argument");
-    if (n == 0) return MI_OK;
-    if (n > 0x7fffffffull) return fail(ctx, MI_E_INVALID, "n too large");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    return guarded(ctx, [&]() -> int {
-        DevState& d = ctx->devs[0];
-        HIP_TRY(hipSetDevice(d.dev));
-        size_t sz = compressed ? 48 : 96;
-        DevBuf din, dout;
-        try {
-            din.ensure(n * 96); dout.ensure(n * sz);
-            HIP_TRY(hipMemcpyAsync(din.p, points, n * 96, hipMemcpyHostToDevice, d.stream));
-            hipLaunchKernelGGL(msmk::k_serialize_g1, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, d.stream, (const uint32_t*)din.p,
-                               (uint32_t)n, compressed ? 1 : 0, (uint8_t*)dout.p);
-            HIP_TRY(hipMemcpyAsync(bytes, dout.p, n * sz, hipMemcpyDeviceToHost, d.stream));
-            HIP_TRY(hipStreamSynchronize(d.stream));
-            HIP_TRY(hipGetLastError());
-        } catch (...) {
-            din.release(); dout.release();
-            throw;
-        }
-        din.release(); dout.release();
-        return MI_OK;
-    });
+    return serialize_impl(ctx, msmk::k_serialize_g1, 48, points, n, compressed, bytes);
+}
+int mi_g2_deserialize_batch(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int validate, mi_g2_affine* out,
+                            uint8_t* status) {
+    return deserialize_impl(ctx, msmk::k_deserialize_g2, 96, bytes, n, compressed, validate, out, status);
+}
+int mi_g2_serialize_batch(mi_ctx* ctx, const mi_g2_affine* points, size_t n, int compressed, uint8_t* bytes) {
+    return serialize_impl(ctx, msmk::k_serialize_g2, 96, points, n, compressed, bytes);
 }
 
 int mi_g1_sum(const mi_g1* partials, size_t n, mi_g1* out) {

@@ -1073,6 +1073,161 @@ __global__ void __launch_bounds__(256) k_serialize_g1(const uint32_t* __restrict
     if (compressed) b[0] |= (uint8_t)(0x80 | (larger ? 0x20 : 0));
 }
 
+// ---------------------------------------------------------------------------------------------- G2 point decoding
+// Same for G2 (/root/reference/src/g2.rs:338-411): 96-byte compressed / 192-byte uncompressed, coordinates in Fp2
+// serialised c1 first; y^2 = x^3 + 4(1 + u).  Square root in Fp2 for p = 3 mod 4 (Adj, Rodriguez-Henriquez Alg. 9):
+// a1 = a^((p-3)/4), alpha = a1^2 a, x0 = a1 a; root = u x0 if alpha = -1 else (1 + alpha)^((p-1)/2) x0.
+// Subgroup test: psi(P) == [z] P (z < 0), psi(x, y) = (conj(x) PSI_X, conj(y) PSI_Y)  (M. Scott, eprint 2021/1130).
+using G2F = ec::Fp2Ops;
+__device__ __forceinline__ bool fp2_equal(const ec::Fp2& a, const ec::Fp2& b) { return fp_equal(a.c0, b.c0) && fp_equal(a.c1, b.c1); }
+__device__ __forceinline__ bool fp2_is_zero(const ec::Fp2& a) { return fp28::fp_is_zero_any(a.c0) && fp28::fp_is_zero_any(a.c1); }
+__device__ __forceinline__ ec::Fp2 fp2_conj(const ec::Fp2& a) { return ec::Fp2{a.c0, fp28::fp_neg<16>(a.c1)}; }
+
+__device__ __noinline__ ec::Fp2 fp2_pow(const ec::Fp2& a, const uint32_t (&e)[12], int top_bit) {
+    ec::Fp2 acc = a;
+#pragma unroll 1
+    for (int bit = top_bit - 1; bit >= 0; bit--) {
+        acc = G2F::sqr(acc);
+        if ((e[bit >> 5] >> (bit & 31)) & 1) acc = G2F::mul(acc, a);
+    }
+    return acc;
+}
+__device__ __noinline__ void g2_mul_z(ec::Proj<G2F>& r, const ec::Proj<G2F>& p) {
+    r = p;
+#pragma unroll 1
+    for (int bit = 62; bit >= 0; bit--) {
+        ec::Proj<G2F> c = r;
+        ec::proj_add<G2F>(r, c);
+        if ((fp28c::Z_ABS >> bit) & 1) ec::proj_add<G2F>(r, p);
+    }
+}
+__device__ __forceinline__ bool canon_gt_half(const Fp& c) {
+    bool larger = false, decided = false;
+#pragma unroll
+    for (int k = NL - 1; k >= 0; k--) {
+        if (!decided && c.l[k] != fp28c::HALF_P[k]) { larger = c.l[k] > fp28c::HALF_P[k]; decided = true; }
+    }
+    return larger;
+}
+__device__ __forceinline__ bool fp2_lex_largest(const ec::Fp2& y) {  // c1 first, then c0
+    Fp c1 = fp_to_canonical(y.c1);
+    uint32_t z = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) z |= c1.l[k];
+    if (z != 0) return canon_gt_half(c1);
+    return canon_gt_half(fp_to_canonical(y.c0));
+}
+
+__global__ void __launch_bounds__(256) k_deserialize_g2(const uint8_t* __restrict__ bytes, uint32_t n, int compressed, int validate,
+                                                        uint32_t* __restrict__ out_aff, uint8_t* __restrict__ status) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t size = compressed ? 96u : 192u;
+    const uint8_t* b = bytes + (size_t)i * size;
+    uint32_t* o = out_aff + (size_t)i * 48;
+    uint8_t b0 = b[0];
+    uint32_t c_flag = b0 >> 7, i_flag = (b0 >> 6) & 1, s_flag = (b0 >> 5) & 1;
+    uint32_t x1w[12], x0w[12], y1w[12], y0w[12];
+    be48_to_words(x1w, b, 0x1fffffffu);
+    be48_to_words(x0w, b + 48, 0xffffffffu);
+#pragma unroll
+    for (int k = 0; k < 12; k++) { y1w[k] = 0; y0w[k] = 0; }
+    if (!compressed) {
+        be48_to_words(y1w, b + 96, 0xffffffffu);
+        be48_to_words(y0w, b + 144, 0xffffffffu);
+    }
+    uint8_t st = 0;
+    bool is_inf = false;
+    if (c_flag != (uint32_t)(compressed ? 1 : 0)) st = 1;
+    if (st == 0 && i_flag) {
+        uint32_t any = s_flag;
+#pragma unroll
+        for (int k = 0; k < 12; k++) any |= x1w[k] | x0w[k] | y1w[k] | y0w[k];
+        if (any) st = 1;
+        is_inf = true;
+    }
+    if (st == 0 && !is_inf) {
+        bool ok = words_lt_p(x1w) && words_lt_p(x0w);
+        if (!compressed) ok = ok && words_lt_p(y1w) && words_lt_p(y0w) && !s_flag;
+        if (!ok) st = 1;
+    }
+    ec::Fp2 x = G2F::zero(), y = G2F::zero();
+    if (st == 0 && !is_inf) {
+        const Fp r2 = fp28::fp_const(fp28c::R2), four = fp28::fp_const(fp28c::FOUR);
+        x.c0 = fp28::fp_mul_call(fp28::fp_unpack384(x0w), r2);
+        x.c1 = fp28::fp_mul_call(fp28::fp_unpack384(x1w), r2);
+        ec::Fp2 rhs = G2F::add(G2F::mul(G2F::sqr(x), x), ec::Fp2{four, four});     // x^3 + 4(1 + u)   < 4p
+        if (compressed) {
+            ec::Fp2 a1 = fp2_pow(rhs, fp28c::EXP_P3_4_32, 378);                      // (p-3)/4 has its top bit at 378
+            ec::Fp2 x0 = G2F::mul(a1, rhs);
+            ec::Fp2 alpha = G2F::mul(a1, x0);
+            ec::Fp2 ap1 = G2F::add(alpha, G2F::one());
+            if (fp2_is_zero(ap1)) {
+                y = ec::Fp2{fp28::fp_neg<4>(x0.c1), x0.c0};                          // u * x0
+            } else {
+                ec::Fp2 bb = fp2_pow(ap1, fp28c::EXP_P1_2_32, 379);                  // (p-1)/2: top bit 379
+                y = G2F::mul(bb, x0);
+            }
+            if (!fp2_equal(G2F::sqr(y), rhs)) st = 1;                                // not a square: malformed
+            if (fp2_lex_largest(y) != (s_flag != 0)) y = G2F::neg<4>(y);
+        } else {
+            y.c0 = fp28::fp_mul_call(fp28::fp_unpack384(y0w), r2);
+            y.c1 = fp28::fp_mul_call(fp28::fp_unpack384(y1w), r2);
+            if (validate && !fp2_equal(G2F::sqr(y), rhs)) st = 2;
+        }
+        if (st == 0 && validate) {
+            ec::Proj<G2F> p1 = ec::proj_from_affine<G2F>(x, y), q;
+            g2_mul_z(q, p1);                                                          // [|z|] P
+            ec::Fp2 px = G2F::mul(fp2_conj(x), ec::Fp2{fp28::fp_zero(), fp28::fp_const(fp28c::PSI_X1)});
+            ec::Fp2 py = G2F::mul(fp2_conj(y), ec::Fp2{fp28::fp_const(fp28c::PSI_Y0), fp28::fp_const(fp28c::PSI_Y1)});
+            // psi(P) == [z] P = -[|z|] P :  X_q == px Z_q,  Y_q == -py Z_q,  Z_q != 0
+            bool ok = !fp2_is_zero(q.z);
+            ok = ok && fp2_equal(q.x, G2F::mul(px, q.z));
+            ok = ok && fp2_is_zero(G2F::add(q.y, G2F::mul(py, q.z)));
+            if (!ok) st = 3;
+        }
+    }
+    bool keep = st == 0 && !is_inf;
+    ElemIO<ec::Fp2>::to_raw(o, x, keep);
+    ElemIO<ec::Fp2>::to_raw(o + 24, y, keep);
+    status[i] = st;
+}
+
+__device__ __forceinline__ void words_to_be48(uint8_t* d, const uint32_t (&w)[12]) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        uint8_t* q = d + 44 - 4 * k;
+        q[0] = (uint8_t)(w[k] >> 24); q[1] = (uint8_t)(w[k] >> 16); q[2] = (uint8_t)(w[k] >> 8); q[3] = (uint8_t)w[k];
+    }
+}
+__global__ void __launch_bounds__(256) k_serialize_g2(const uint32_t* __restrict__ aff, uint32_t n, int compressed, uint8_t* __restrict__ bytes) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* q = aff + (size_t)i * 48;
+    const uint32_t size = compressed ? 96u : 192u;
+    uint8_t* b = bytes + (size_t)i * size;
+    uint32_t any = 0;
+#pragma unroll 4
+    for (int k = 0; k < 48; k++) any |= q[k];
+    for (uint32_t k = 0; k < size; k++) b[k] = 0;
+    if (any == 0) {
+        b[0] = compressed ? 0xC0 : 0x40;
+        return;
+    }
+    ec::Fp2 x, y;
+    ElemIO<ec::Fp2>::from_raw(x, q);
+    ElemIO<ec::Fp2>::from_raw(y, q + 24);
+    uint32_t w[12];
+    fp28::fp_pack384(w, fp_to_canonical(x.c1)); words_to_be48(b, w);
+    fp28::fp_pack384(w, fp_to_canonical(x.c0)); words_to_be48(b + 48, w);
+    if (!compressed) {
+        fp28::fp_pack384(w, fp_to_canonical(y.c1)); words_to_be48(b + 96, w);
+        fp28::fp_pack384(w, fp_to_canonical(y.c0)); words_to_be48(b + 144, w);
+    } else {
+        b[0] |= (uint8_t)(0x80 | (fp2_lex_largest(y) ? 0x20 : 0));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- field test hook
 __global__ void __launch_bounds__(256) k_test_fp_op(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
                                                     uint32_t* __restrict__ out, uint32_t n) {

@@ -118,6 +118,10 @@ int mi_g2_normalize_batch(mi_ctx *ctx, const mi_g2 *in, size_t n, mi_g2_affine *
 int mi_g1_deserialize_batch(mi_ctx *ctx, const uint8_t *bytes, size_t n, int compressed, int validate,
                             mi_g1_affine *out, uint8_t *status);
 int mi_g1_serialize_batch(mi_ctx *ctx, const mi_g1_affine *points, size_t n, int compressed, uint8_t *bytes);
+/* Same for G2 (src/g2.rs:338-411): 96-byte compressed / 192-byte uncompressed encodings, Fp2 coordinates c1 first. */
+int mi_g2_deserialize_batch(mi_ctx *ctx, const uint8_t *bytes, size_t n, int compressed, int validate,
+                            mi_g2_affine *out, uint8_t *status);
+int mi_g2_serialize_batch(mi_ctx *ctx, const mi_g2_affine *points, size_t n, int compressed, uint8_t *bytes);
 
 /* Deterministic fold of partial sums (one per GPU / rank), in index order: the "all-reduce under the curve
  * group law" that follows the RCCL all-gather in the multi-process harness.  Host only. */

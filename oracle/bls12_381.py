@@ -383,6 +383,91 @@ def g1_deserialize(b: bytes, compressed: bool, validate: bool):
     return pt, DESER_OK
 
 
+# ---- G2 (src/g2.rs:338-411): same format over Fp2, coordinates serialised c1 first; y^2 = x^3 + 4(1 + u)
+def fp2_pow(a, e):
+    r, b = (1, 0), a
+    while e:
+        if e & 1:
+            r = F2.mul(r, b)
+        b = F2.mul(b, b)
+        e >>= 1
+    return r
+
+
+def fp2_sqrt(a):
+    """Square root in Fp2 for p = 3 (mod 4) (Adj, Rodriguez-Henriquez, Alg. 9); None if a is not a square."""
+    if F2.is_zero(a):
+        return (0, 0)
+    a1 = fp2_pow(a, (P - 3) // 4)
+    alpha = F2.mul(a1, F2.mul(a1, a))
+    x0 = F2.mul(a1, a)
+    if alpha == (P - 1, 0):
+        x = ((-x0[1]) % P, x0[0])
+    else:
+        b = fp2_pow(F2.add((1, 0), alpha), (P - 1) // 2)
+        x = F2.mul(b, x0)
+    return x if F2.eq(F2.mul(x, x), a) else None
+
+
+def fp2_lex_largest(y) -> bool:
+    """y > -y in the ZCash ordering: compare c1 first, then c0."""
+    half = (P - 1) // 2
+    return y[1] > half or (y[1] == 0 and y[0] > half)
+
+
+def g2_compress(p) -> bytes:
+    if p is INF:
+        return bytes([0xC0]) + bytes(95)
+    (x0, x1), y = p
+    b = bytearray(x1.to_bytes(48, "big") + x0.to_bytes(48, "big"))
+    b[0] |= 0x80
+    if fp2_lex_largest(y):
+        b[0] |= 0x20
+    return bytes(b)
+
+
+def g2_in_subgroup(p) -> bool:
+    return p is INF or scalar_mul(F2, p, R_ORDER) is INF
+
+
+def g2_deserialize(b: bytes, compressed: bool, validate: bool):
+    size = 96 if compressed else 192
+    assert len(b) == size
+    c_flag, i_flag, s_flag = b[0] >> 7, (b[0] >> 6) & 1, (b[0] >> 5) & 1
+    if c_flag != (1 if compressed else 0):
+        return None, DESER_BAD_ENCODING
+    body = bytes([b[0] & 0x1F]) + b[1:]
+    if i_flag:
+        if any(body) or s_flag:
+            return None, DESER_BAD_ENCODING
+        return INF, DESER_OK
+    x1, x0 = int.from_bytes(body[:48], "big"), int.from_bytes(body[48:96], "big")
+    if x0 >= P or x1 >= P:
+        return None, DESER_BAD_ENCODING
+    x = (x0, x1)
+    rhs = F2.add(F2.mul(F2.mul(x, x), x), F2.b)
+    if compressed:
+        y = fp2_sqrt(rhs)
+        if y is None:
+            return None, DESER_BAD_ENCODING
+        if fp2_lex_largest(y) != bool(s_flag):
+            y = F2.neg(y)
+    else:
+        if s_flag:
+            return None, DESER_BAD_ENCODING
+        y1, y0 = int.from_bytes(body[96:144], "big"), int.from_bytes(body[144:192], "big")
+        if y0 >= P or y1 >= P:
+            return None, DESER_BAD_ENCODING
+        y = (y0, y1)
+    pt = (x, y)
+    if validate:
+        if not F2.eq(F2.mul(y, y), rhs):
+            return None, DESER_NOT_ON_CURVE
+        if not g2_in_subgroup(pt):
+            return None, DESER_NOT_IN_SUBGROUP
+    return pt, DESER_OK
+
+
 # ----------------------------------------------------------------------------------------------
 # deterministic input generators shared by tests / bench (BASELINE.md §3)
 # ----------------------------------------------------------------------------------------------

@@ -426,3 +426,25 @@ def test_g1_g2_msm_fuzz_configs(ctx, co, o, pkg):
             ctx.set_window_bits(0)
         want = co.msm(group, bytes(bases), canon, n, 0, 4)
         assert _canon(co, group, got) == _canon(co, group, want), (it, group, n, kind, c, fmt)
+
+
+def test_g2_deserialize_golden_and_roundtrip(ctx, co, o):
+    """G2 encodings (src/g2.rs:338-411): every fixture class, then encode -> decode of 1500 points in both forms and the
+    encoder against the oracle."""
+    for case in _golden()["g2_encoding"]:
+        pts, st = ctx.deserialize_batch("g2", bytes.fromhex(case["bytes"]), case["compressed"], case["validate"])
+        assert st[0] == case["status"], case["name"]
+        assert pts == (bytes.fromhex(case["affine"]) if case["status"] == 0 else bytes(192)), case["name"]
+    n = 1500
+    raw = bytearray(co.gen_bases("g2", SEED_B + 80, n, 8))
+    for i in range(5, n, 113):
+        raw[192 * i:192 * (i + 1)] = bytes(192)
+    raw = bytes(raw)
+    for compressed in (True, False):
+        enc = ctx.serialize_batch("g2", raw, compressed)
+        size = 96 if compressed else 192
+        for i in range(0, n, 97):
+            pt = o.affine_from_bytes(o.F2, raw[192 * i:192 * (i + 1)])
+            assert enc[size * i:size * (i + 1)] == (o.g2_compress(pt) if compressed else o.g2_uncompressed(pt)), i
+        dec, st = ctx.deserialize_batch("g2", enc, compressed, True)
+        assert st == bytes(n) and dec == raw

@@ -92,3 +92,19 @@ def test_g1_encoding_oracle_vs_fixtures(o, golden):
     z = 0xD201000000010000
     q = o.scalar_mul(o.F1, o.G1_GEN, (z * z) % o.R_ORDER)
     assert (beta * o.G1_X % o.P, o.G1_Y) == o.aff_neg(o.F1, q)
+
+
+def test_g2_encoding_oracle_vs_fixtures(o, golden):
+    assert o.g2_compress(o.G2_GEN).hex().startswith("93e02b6052719f607dacd3a088274f65596bd0d09920b61a")
+    for case in golden["g2_encoding"]:
+        pt, st = o.g2_deserialize(bytes.fromhex(case["bytes"]), case["compressed"], case["validate"])
+        assert st == case["status"], case["name"]
+        if st == 0:
+            assert o.affine_to_bytes(o.F2, pt).hex() == case["affine"]
+    # psi(P) = [z] P on G2 with the constants baked into the GPU subgroup test
+    cx = (0, 0x1A0111EA397FE699EC02408663D4DE85AA0D857D89759AD4897D29650FB85F9B409427EB4F49FFFD8BFD00000000AAAD)
+    cy = (0x135203E60180A68EE2E9C448D77A2CD91C3DEDD930B1CF60EF396489F61EB45E304466CF3E67FA0AF1EE7B04121BDEA2,
+          0x06AF0E0437FF400B6831E36D6BD17FFE48395DABC2D3435E77F76E17009241C5EE67992F72EC05F4C81084FBEDE3CC09)
+    x, y = o.G2_GEN
+    psi = (o.F2.mul((x[0], (-x[1]) % o.P), cx), o.F2.mul((y[0], (-y[1]) % o.P), cy))
+    assert psi == o.scalar_mul(o.F2, o.G2_GEN, (-0xD201000000010000) % o.R_ORDER)
