@@ -14,6 +14,7 @@ from .binding import (  # noqa: F401
     MsmError,
     SCALAR_CANONICAL,
     SCALAR_MONTGOMERY,
+    final_exponentiation,
     g1_sum,
     g2_sum,
     lib_path,

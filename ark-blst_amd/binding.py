@@ -7,6 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SCALAR_CANONICAL, SCALAR_MONTGOMERY = 0, 1
 G1_AFF, G1_JAC, G2_AFF, G2_JAC = 96, 144, 192, 288
+FP12 = 576
 
 
 class MsmError(RuntimeError):
@@ -52,6 +53,9 @@ def load_library():
         for g in ("g1", "g2"):
             getattr(L, f"mi_{g}_deserialize_batch").argtypes = [vp, vp, sz, i, i, vp, vp]
             getattr(L, f"mi_{g}_serialize_batch").argtypes = [vp, vp, sz, i, vp]
+        L.mi_multi_miller_loop.argtypes = [vp, vp, vp, sz, vp]
+        L.mi_multi_pairing.argtypes = [vp, vp, vp, sz, vp]
+        L.mi_final_exponentiation.argtypes = [vp, vp]
         L.mi_msm_set_window_bits.argtypes = [vp, u]
         L.mi_msm_last_profile.argtypes = [vp, C.POINTER(Profile)]
         L.mi_msm_last_error.argtypes = [vp]
@@ -166,6 +170,22 @@ class Context:
     def g1_serialize_batch(self, points: bytes, compressed: bool = True) -> bytes:
         return self.serialize_batch("g1", points, compressed)
 
+    def multi_miller_loop(self, g1_affine: bytes, g2_affine: bytes) -> bytes:
+        """Pairing::multi_miller_loop over packed blst_p1_affine / blst_p2_affine arrays -> blst_fp12 (576 B)."""
+        n = len(g1_affine) // G1_AFF
+        assert len(g1_affine) == n * G1_AFF and len(g2_affine) == n * G2_AFF, "one G2 point per G1 point"
+        out = C.create_string_buffer(FP12)
+        self._check(self._L.mi_multi_miller_loop(self._h, g1_affine, g2_affine, n, out), "mi_multi_miller_loop")
+        return out.raw
+
+    def multi_pairing(self, g1_affine: bytes, g2_affine: bytes) -> bytes:
+        """prod_i e(P_i, Q_i): Miller loops on the GPU, multiplication tree, final exponentiation."""
+        n = len(g1_affine) // G1_AFF
+        assert len(g1_affine) == n * G1_AFF and len(g2_affine) == n * G2_AFF, "one G2 point per G1 point"
+        out = C.create_string_buffer(FP12)
+        self._check(self._L.mi_multi_pairing(self._h, g1_affine, g2_affine, n, out), "mi_multi_pairing")
+        return out.raw
+
     def profile(self) -> dict:
         p = Profile()
         self._check(self._L.mi_msm_last_profile(self._h, C.byref(p)), "mi_msm_last_profile")
@@ -176,6 +196,16 @@ class Context:
         out = C.create_string_buffer(48 * n)
         self._check(self._L.mi_test_fp_op(self._h, op, a, b, out, n), "mi_test_fp_op")
         return out.raw
+
+
+def final_exponentiation(f: bytes) -> bytes:
+    """Pairing::final_exponentiation on one blst_fp12 (host tail; needs no device)."""
+    assert len(f) == FP12
+    out = C.create_string_buffer(FP12)
+    rc = load_library().mi_final_exponentiation(f, out)
+    if rc != 0:
+        raise MsmError(rc, "mi_final_exponentiation")
+    return out.raw
 
 
 def _sum(group: str, partials) -> bytes:

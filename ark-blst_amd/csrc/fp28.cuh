@@ -227,7 +227,7 @@ FP_HD Fp fp_mul4add(const Fp& a, const Fp& b, const Fp& c2, const Fp& d, const F
 #if defined(__HIP_DEVICE_COMPILE__)
 static __device__ __noinline__ Fp fp_mul_call(Fp a, Fp b) { return fp_mul(a, b); }
 #else
-FP_HD Fp fp_mul_call(const Fp& a, const Fp& b) { return fp_mul(a, b); }
+FP_HD_NOINLINE Fp fp_mul_call(const Fp& a, const Fp& b) { return fp_mul(a, b); }
 #endif
 
 // r = a^2 / 2^392 mod p (105 products instead of 196)
@@ -251,14 +251,14 @@ FP_HD Fp fp_sqr(const Fp& a) {
 #if defined(__HIP_DEVICE_COMPILE__)
 static __device__ __noinline__ Fp fp_mul2add_call(Fp a, Fp b, Fp c, Fp d) { return fp_mul2add(a, b, c, d); }
 #else
-FP_HD Fp fp_mul2add_call(const Fp& a, const Fp& b, const Fp& c, const Fp& d) { return fp_mul2add(a, b, c, d); }
+FP_HD_NOINLINE Fp fp_mul2add_call(const Fp& a, const Fp& b, const Fp& c, const Fp& d) { return fp_mul2add(a, b, c, d); }
 #endif
 
 // shared squaring instance (see fp_mul_call)
 #if defined(__HIP_DEVICE_COMPILE__)
 static __device__ __noinline__ Fp fp_sqr_call(Fp a) { return fp_sqr(a); }
 #else
-FP_HD Fp fp_sqr_call(const Fp& a) { return fp_sqr(a); }
+FP_HD_NOINLINE Fp fp_sqr_call(const Fp& a) { return fp_sqr(a); }
 #endif
 
 // Exact carry propagation of an N-form value that fits 392 bits: limbs -> [0, 2^28), l[13] holds the rest.

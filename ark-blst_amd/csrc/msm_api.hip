@@ -23,6 +23,7 @@
 #include "host_curve.hpp"
 #include "host_pool.hpp"
 #include "msm_kernels.cuh"
+#include "pairing_kernels.cuh"
 
 namespace {
 
@@ -670,6 +671,120 @@ int serialize_impl(mi_ctx* ctx, KSer kernel, size_t unit, const void* points, si
     });
 }
 
+
+// ------------------------------------------------------------------------------------------------ pairing
+using HT = pairing::Tower<pairing::PF2>;   // host instance of the generic tower (final exponentiation, last tree levels)
+
+HT::E12 fp12_from_raw(const mi_fp12* f) {
+    HT::E12 r;
+    ec::Fp2* c = &r.c0.c0;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(f);
+    for (int i = 0; i < 12; i++) {
+        uint32_t t[12];
+        memcpy(t, w + 12 * i, 48);
+        (i & 1 ? c[i >> 1].c1 : c[i >> 1].c0) = fp28::fp_from_blst(t);
+    }
+    return r;
+}
+void fp12_to_raw(mi_fp12* out, const HT::E12& a) {
+    const ec::Fp2* c = &a.c0.c0;
+    uint32_t* w = reinterpret_cast<uint32_t*>(out);
+    for (int i = 0; i < 12; i++) {
+        uint32_t t[12];
+        fp28::fp_to_blst(t, i & 1 ? c[i >> 1].c1 : c[i >> 1].c0);
+        memcpy(w + 12 * i, t, 48);
+    }
+}
+
+// Miller loops of one shard on one device, multiplied down to <= 64 values on the GPU and to one on the host
+HT::E12 device_miller(DevState& d, const mi_g1_affine* p, const mi_g2_affine* q, size_t n) {
+    HIP_TRY(hipSetDevice(d.dev));
+    hipStream_t s = d.stream;
+    DevBuf dp, dq, lvl[2], raw;
+    HT::E12 acc = HT::one12();
+    try {
+        dp.ensure(n * sizeof(mi_g1_affine));
+        dq.ensure(n * sizeof(mi_g2_affine));
+        size_t fp12_bytes = (size_t)msmk::FP12_WORDS * 4;
+        lvl[0].ensure(n * fp12_bytes);
+        lvl[1].ensure(((n + msmk::FP12_TREE_K - 1) / msmk::FP12_TREE_K) * fp12_bytes);
+        raw.ensure(64 * sizeof(mi_fp12));
+        HIP_TRY(hipEventRecord(d.ev[0], s));
+        HIP_TRY(hipMemcpyAsync(dp.p, p, n * sizeof(mi_g1_affine), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dq.p, q, n * sizeof(mi_g2_affine), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(d.ev[1], s));
+        hipLaunchKernelGGL(msmk::k_miller_loop, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, s, (const uint32_t*)dp.p, (const uint32_t*)dq.p,
+                           (uint32_t)n, (uint32_t*)lvl[0].p);
+        HIP_TRY(hipEventRecord(d.ev[2], s));
+        size_t m = n;
+        int cur = 0;
+        while (m > 64) {
+            size_t g = (m + msmk::FP12_TREE_K - 1) / msmk::FP12_TREE_K;
+            hipLaunchKernelGGL(msmk::k_fp12_prod, dim3((uint32_t)((g + 63) / 64)), dim3(64), 0, s, (const uint32_t*)lvl[cur].p, (uint32_t)m,
+                               (uint32_t*)lvl[cur ^ 1].p);
+            cur ^= 1;
+            m = g;
+        }
+        hipLaunchKernelGGL(msmk::k_fp12_to_raw, dim3(1), dim3(64), 0, s, (const uint32_t*)lvl[cur].p, (uint32_t)m, (uint32_t*)raw.p);
+        HIP_TRY(hipEventRecord(d.ev[3], s));
+        std::vector<mi_fp12> top(m);
+        HIP_TRY(hipMemcpyAsync(top.data(), raw.p, m * sizeof(mi_fp12), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipGetLastError());
+        for (size_t k = 0; k < m; k++) acc = HT::mul12(acc, fp12_from_raw(&top[k]));
+        d.prof = mi_profile{};
+        d.prof.n = n;
+        d.prof.h2d_ms = ev_ms(d.ev[0], d.ev[1]);
+        d.prof.accumulate_ms = ev_ms(d.ev[1], d.ev[2]);   // Miller loops
+        d.prof.reduce_ms = ev_ms(d.ev[2], d.ev[3]);       // multiplication tree
+    } catch (...) {
+        for (DevBuf* b : {&dp, &dq, &lvl[0], &lvl[1], &raw}) b->release();
+        throw;
+    }
+    for (DevBuf* b : {&dp, &dq, &lvl[0], &lvl[1], &raw}) b->release();
+    return acc;
+}
+
+int miller_impl(mi_ctx* ctx, const mi_g1_affine* p, const mi_g2_affine* q, size_t n, mi_fp12* out, bool final_exp) {
+    if (!ctx || !out || (n && (!p || !q))) return fail(ctx, MI_E_INVALID, "invalid argument");
+    if (n > 0x7fffffffull) return fail(ctx, MI_E_INVALID, "n too large");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return guarded(ctx, [&]() -> int {
+        size_t g = ctx->devs.size();
+        std::vector<HT::E12> part(g, HT::one12());
+        std::vector<std::string> errs(g);
+        auto work = [&](size_t k) {
+            try {
+                size_t lo, hi;
+                shard_range(n, g, k, lo, hi);
+                if (hi > lo) part[k] = device_miller(ctx->devs[k], p + lo, q + lo, hi - lo);
+            } catch (const HipFail& e) {
+                errs[k] = e.msg;
+            }
+        };
+        auto t0 = std::chrono::steady_clock::now();
+        if (g == 1 || n < 2 * g) {
+            for (size_t k = 0; k < g; k++) work(k);
+        } else {
+            std::vector<std::thread> th;
+            for (size_t k = 0; k < g; k++) th.emplace_back(work, k);
+            for (auto& t : th) t.join();
+        }
+        for (size_t k = 0; k < g; k++)
+            if (!errs[k].empty()) return fail(ctx, MI_E_HIP, errs[k]);
+        HT::E12 f = part[0];
+        for (size_t k = 1; k < g; k++) f = HT::mul12(f, part[k]);
+        auto t1 = std::chrono::steady_clock::now();
+        if (final_exp) f = HT::final_exp(f);
+        fp12_to_raw(out, f);
+        ctx->prof = ctx->devs[0].prof;
+        ctx->prof.n = n;
+        ctx->prof.host_fold_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+        ctx->prof.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return MI_OK;
+    });
+}
+
 }  // namespace
 
 extern "C" {
@@ -766,6 +881,18 @@ int mi_g2_deserialize_batch(mi_ctx* ctx, const uint8_t* bytes, size_t n, int com
 }
 int mi_g2_serialize_batch(mi_ctx* ctx, const mi_g2_affine* points, size_t n, int compressed, uint8_t* bytes) {
     return serialize_impl(ctx, msmk::k_serialize_g2, 96, points, n, compressed, bytes);
+}
+
+int mi_multi_miller_loop(mi_ctx* ctx, const mi_g1_affine* p, const mi_g2_affine* q, size_t n, mi_fp12* out) {
+    return miller_impl(ctx, p, q, n, out, false);
+}
+int mi_multi_pairing(mi_ctx* ctx, const mi_g1_affine* p, const mi_g2_affine* q, size_t n, mi_fp12* out) {
+    return miller_impl(ctx, p, q, n, out, true);
+}
+int mi_final_exponentiation(const mi_fp12* f, mi_fp12* out) {
+    if (!f || !out) return MI_E_INVALID;
+    fp12_to_raw(out, HT::final_exp(fp12_from_raw(f)));
+    return MI_OK;
 }
 
 int mi_g1_sum(const mi_g1* partials, size_t n, mi_g1* out) {

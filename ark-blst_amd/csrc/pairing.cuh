@@ -12,6 +12,10 @@
 // Tower (the reference's: src/fp2.rs, fp6.rs, fp12.rs):  Fp2 = Fp[u]/(u^2+1),  Fp6 = Fp2[v]/(v^3 - xi), xi = 1+u,
 // Fp12 = Fp6[w]/(w^2 - v).  Memory order of blst_fp12 = c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2 (each an Fp2).
 //
+// The Fp6 / Fp12 functions are out of line (FP_HD_NOINLINE): on the GPU their arguments travel through scratch, a few
+// percent of the ~10^4 instructions each of them executes, and the Miller-loop kernel stays a few KB of code around
+// the shared multiplier bodies instead of ~200 call sites' worth of register marshalling.
+//
 // Bound contract (units of p, per Fp component): every Fp6/Fp12 function takes components <= 4p and returns
 // components < 2p ("normalised": each component is the output of a Montgomery reduction).  Inside, Karatsuba sums
 // and differences grow to < 92p; they are brought back by one multiplication by the internal one (F2::norm).
@@ -87,7 +91,7 @@ struct Tower {
     }
 
     // Karatsuba over Fp2 (6 products).  Inputs <= 16p; RAW output: c0 < 28p, c1 < 16p, c2 < 12p.
-    static FP_HD E6 mul6_raw(const E6& a, const E6& b) {
+    static FP_HD_NOINLINE E6 mul6_raw(const E6& a, const E6& b) {
         E2 t0 = F2::mul(a.c0, b.c0), t1 = F2::mul(a.c1, b.c1), t2 = F2::mul(a.c2, b.c2);
         E2 s12 = F2::mul(F2::add(a.c1, a.c2), F2::add(b.c1, b.c2));
         E2 s01 = F2::mul(F2::add(a.c0, a.c1), F2::add(b.c0, b.c1));
@@ -104,7 +108,7 @@ struct Tower {
     static FP_HD E6 mul_v(const E6& a) { return E6{F2::template mul_xi<K>(a.c2), a.c0, a.c1}; }
 
     // (a0 + a1 w)(b0 + b1 w): 3 Fp6 products + 12 normalisations.  Inputs <= 4p, output < 2p.
-    static FP_HD E12 mul12(const E12& a, const E12& b) {
+    static FP_HD_NOINLINE E12 mul12(const E12& a, const E12& b) {
         E6 t0 = mul6_raw(a.c0, b.c0), t1 = mul6_raw(a.c1, b.c1);
         E6 m = mul6_raw(add6(a.c0, a.c1), add6(b.c0, b.c1));
         E12 r;
@@ -114,7 +118,7 @@ struct Tower {
         return r;
     }
     // complex squaring: 2 Fp6 products
-    static FP_HD E12 sqr12(const E12& a) {
+    static FP_HD_NOINLINE E12 sqr12(const E12& a) {
         E6 t = mul6_raw(a.c0, a.c1);
         E6 m = mul6_raw(add6(a.c0, a.c1), add6(a.c0, mul_v<8>(a.c1)));          // (a0 + a1)(a0 + v a1)
         E6 s = add6(t, mul_v<16>(t));                                            // t + v t               < 56p
@@ -124,7 +128,7 @@ struct Tower {
         return r;
     }
     // a * (d0 + d1 v), a <= 8p, d <= 8p.  RAW output < 8p
-    static FP_HD E6 mul6_by_01(const E6& a, const E2& d0, const E2& d1) {
+    static FP_HD_NOINLINE E6 mul6_by_01(const E6& a, const E2& d0, const E2& d1) {
         E6 r;
         r.c0 = F2::add(F2::mul(a.c0, d0), F2::template mul_xi<4>(F2::mul(a.c2, d1)));
         r.c1 = F2::mul2add(a.c0, d1, a.c1, d0);
@@ -132,11 +136,11 @@ struct Tower {
         return r;
     }
     // a * d1 v.  RAW output < 6p
-    static FP_HD E6 mul6_by_1(const E6& a, const E2& d1) {
+    static FP_HD_NOINLINE E6 mul6_by_1(const E6& a, const E2& d1) {
         return E6{F2::template mul_xi<4>(F2::mul(a.c2, d1)), F2::mul(a.c0, d1), F2::mul(a.c1, d1)};
     }
     // f * (c0 + c1 v + c4 v w): the sparse line of an M-type twist.  f <= 4p, c0 <= 6p, c1, c4 <= 2p; output < 2p
-    static FP_HD E12 mul_by_014(const E12& f, const E2& c0, const E2& c1, const E2& c4) {
+    static FP_HD_NOINLINE E12 mul_by_014(const E12& f, const E2& c0, const E2& c1, const E2& c4) {
         E6 t0 = mul6_by_01(f.c0, c0, c1);
         E6 t1 = mul6_by_1(f.c1, c4);
         E6 m = mul6_by_01(add6(f.c0, f.c1), c0, F2::add(c1, c4));
@@ -150,14 +154,14 @@ struct Tower {
         return norm6(E6{F2::template neg<4>(a.c0), F2::template neg<4>(a.c1), F2::template neg<4>(a.c2)});
     }
     // conjugation over Fp6 (w -> -w): the inverse on the cyclotomic subgroup
-    static FP_HD E12 conj12(const E12& a) {
+    static FP_HD_NOINLINE E12 conj12(const E12& a) {
         E12 r;
         r.c0 = a.c0;
         r.c1 = neg6n(a.c1);
         return r;
     }
     // 1/a in Fp6 (a <= 4p), output < 2p
-    static FP_HD E6 inv6(const E6& a) {
+    static FP_HD_NOINLINE E6 inv6(const E6& a) {
         E2 A = F2::template sub<8>(F2::sqr(a.c0), F2::template mul_xi<4>(F2::mul(a.c1, a.c2)));   // a0^2 - xi a1 a2      < 10p
         E2 B = F2::template sub<4>(F2::template mul_xi<4>(F2::sqr(a.c2)), F2::mul(a.c0, a.c1));   // xi a2^2 - a0 a1      < 10p
         E2 C = F2::template sub<4>(F2::sqr(a.c1), F2::mul(a.c0, a.c2));                           // a1^2 - a0 a2         < 6p
@@ -166,7 +170,7 @@ struct Tower {
         return E6{F2::mul(A, Fi), F2::mul(B, Fi), F2::mul(C, Fi)};
     }
     // 1/a in Fp12
-    static FP_HD E12 inv12(const E12& a) {
+    static FP_HD_NOINLINE E12 inv12(const E12& a) {
         E6 s0 = mul6_raw(a.c0, a.c0), s1 = mul6_raw(a.c1, a.c1);
         E6 vs = mul_v<16>(s1);                                                   // < 28p
         E6 D = norm6(E6{F2::template sub<32>(s0.c0, vs.c0), F2::template sub<32>(s0.c1, vs.c1), F2::template sub<32>(s0.c2, vs.c2)});
@@ -183,7 +187,7 @@ struct Tower {
         t.c1 = F2::fp_neg4(a.c1);
         return F2::norm2(t);
     }
-    static FP_HD E12 frob12(const E12& a) {
+    static FP_HD_NOINLINE E12 frob12(const E12& a) {
         E12 r;
         r.c0.c0 = conj2n(a.c0.c0);
         r.c0.c1 = F2::mul(conj2n(a.c0.c1), F2::frob_const(2));
@@ -200,7 +204,7 @@ struct Tower {
         typename F2::Fp nx, y;
     };
     // tangent line at T (scaled by 2YZ) evaluated at P, then T <- 2T
-    static FP_HD void line_dbl(PT& T, const G1Pt& p, E2& c0, E2& c1, E2& c4) {
+    static FP_HD_NOINLINE void line_dbl(PT& T, const G1Pt& p, E2& c0, E2& c1, E2& c4) {
         E2 y2 = F2::sqr(T.y), z2 = F2::sqr(T.z), x2 = F2::sqr(T.x);
         c0 = F2::template sub<4>(y2, F2::mul_b3(z2));                            // Y^2 - 3b' Z^2          < 6p
         c1 = F2::mul_fp(F2::mul3(x2), p.nx);                                     // -3 X^2 xP
@@ -209,7 +213,7 @@ struct Tower {
         ec::proj_add<F2>(T, c);
     }
     // line through T and Q (scaled by X - xQ Z) evaluated at P, then T <- T + Q
-    static FP_HD void line_add(PT& T, const E2& xq, const E2& yq, const G1Pt& p, E2& c0, E2& c1, E2& c4) {
+    static FP_HD_NOINLINE void line_add(PT& T, const E2& xq, const E2& yq, const G1Pt& p, E2& c0, E2& c1, E2& c4) {
         E2 N = F2::template sub<4>(T.y, F2::mul(yq, T.z));                       // < 10p
         E2 D = F2::template sub<4>(T.x, F2::mul(xq, T.z));
         c0 = F2::template sub<4>(F2::mul(N, xq), F2::mul(D, yq));                // N xQ - D yQ            < 6p
@@ -240,7 +244,7 @@ struct Tower {
 
     // ---------------------------------------------------------------------------------------- final exponentiation
     // x^|z| for x in the cyclotomic subgroup, then conjugated (z < 0): x^z.  half: x^(z/2)
-    static FP_HD E12 raise_to_z(const E12& x, bool half) {
+    static FP_HD_NOINLINE E12 raise_to_z(const E12& x, bool half) {
         uint64_t e = half ? (fp28c::Z_ABS >> 1) : fp28c::Z_ABS;
         int top = half ? 62 : 63;
         E12 r = x;

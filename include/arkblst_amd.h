@@ -40,6 +40,8 @@ typedef struct { mi_fp x, y, z; } mi_g1;
 typedef struct { mi_fp c[2]; } mi_fp2;
 typedef struct { mi_fp2 x, y; } mi_g2_affine;
 typedef struct { mi_fp2 x, y, z; } mi_g2;
+typedef struct { mi_fp2 c[3]; } mi_fp6;     /* blst_fp6:  c0 + c1 v + c2 v^2, v^3 = 1 + u            (src/fp6.rs)  */
+typedef struct { mi_fp6 c[2]; } mi_fp12;    /* blst_fp12: c0 + c1 w, w^2 = v; 576 B = the reference's Gt (src/fp12.rs) */
 
 typedef struct mi_ctx mi_ctx;
 
@@ -122,6 +124,19 @@ int mi_g1_serialize_batch(mi_ctx *ctx, const mi_g1_affine *points, size_t n, int
 int mi_g2_deserialize_batch(mi_ctx *ctx, const uint8_t *bytes, size_t n, int compressed, int validate,
                             mi_g2_affine *out, uint8_t *status);
 int mi_g2_serialize_batch(mi_ctx *ctx, const mi_g2_affine *points, size_t n, int compressed, uint8_t *bytes);
+
+/* Pairing (BASELINE config #5).  Replaces <Bls12 as Pairing>::multi_miller_loop (src/pairing.rs:49-74:
+ * a serial loop of blstrs::miller_loop_lines + blst_fp12_mul on one CPU thread) and final_exponentiation
+ * (src/pairing.rs:76-80).  One GPU lane per pair, then a multiplication tree; pairs are sharded over the context's
+ * devices.  A pair with p[i] or q[i] at infinity (all-zero) contributes 1, as pairing.rs:58-60.  n == 0 gives 1.
+ * q[i] are plain G2 affine points: the reference's G2Prepared (68 precomputed line coefficients, 19.6 KB per point) is
+ * not materialised, lines are computed on the fly.  The Miller value agrees with blst's up to factors from proper
+ * subfields, which the final exponentiation removes; compare Gt values, i.e. after mi_final_exponentiation.
+ * mi_final_exponentiation is the O(1) host tail (one Fp12 element): f^(3 (p^12-1)/r), blst's convention. */
+int mi_multi_miller_loop(mi_ctx *ctx, const mi_g1_affine *p, const mi_g2_affine *q, size_t n, mi_fp12 *out);
+int mi_final_exponentiation(const mi_fp12 *f, mi_fp12 *out);
+/* both steps: out = prod_i e(p[i], q[i])  (ark_ec::pairing::Pairing::multi_pairing) */
+int mi_multi_pairing(mi_ctx *ctx, const mi_g1_affine *p, const mi_g2_affine *q, size_t n, mi_fp12 *out);
 
 /* Deterministic fold of partial sums (one per GPU / rank), in index order: the "all-reduce under the curve
  * group law" that follows the RCCL all-gather in the multi-process harness.  Host only. */
