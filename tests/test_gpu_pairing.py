@@ -92,3 +92,12 @@ def test_product_cancels_at_size(ctx, co, o, pr, n):
     assert got == pr.fp12_to_bytes(pr.FP12_ONE)
     # and the product itself is not trivially 1
     assert ctx.multi_pairing(g1, g2) != got
+
+
+def test_golden_vectors(ctx):
+    import json
+    import os
+
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pairing_vectors.json")))
+    for c in gold["multi_pairing"]:
+        assert ctx.multi_pairing(bytes.fromhex(c["g1"]), bytes.fromhex(c["g2"])).hex() == c["gt"], c["name"]
