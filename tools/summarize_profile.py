@@ -11,6 +11,7 @@ import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
 tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+what = sys.argv[3] if len(sys.argv) > 3 else "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary` (G1, 2^20, c=16)"
 shutil.copy(glob.glob(f"{src}/stats/runc/*kernel_stats.csv")[0], f"profiles/{tag}_kernel_stats.csv")
 out = collections.defaultdict(dict)
 for name in ("fetch", "write", "sq"):
@@ -20,6 +21,7 @@ for name in ("fetch", "write", "sq"):
     for k, v in acc.items():
         for c, xs in v.items():
             out[k][c] = sum(xs) / len(xs)
+            out[k][c + "_max"] = max(xs)
             out[k]["launches"] = len(xs)
 for k, v in out.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
@@ -27,6 +29,6 @@ for k, v in out.items():
         v["hbm_bytes_per_launch_raw"] = (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
     if "GRBM_GUI_ACTIVE" in v:
         v["gpu_cycles_per_launch"] = v["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
-json.dump({"source": "rocprofv3 --pmc passes of `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary` (G1, 2^20, c=16)",
+json.dump({"source": "rocprofv3 --pmc passes of `" + what + " (means over all launches of a kernel in the run, warm-up launches included)",
            "kernels": out}, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
 print("wrote profiles/%s_kernel_stats.csv, profiles/%s_pmc_summary.json" % (tag, tag))
