@@ -700,7 +700,7 @@ void fp12_to_raw(mi_fp12* out, const HT::E12& a) {
 HT::E12 device_miller(DevState& d, const mi_g1_affine* p, const mi_g2_affine* q, size_t n) {
     HIP_TRY(hipSetDevice(d.dev));
     hipStream_t s = d.stream;
-    DevBuf dp, dq, lvl[2], raw;
+    DevBuf dp, dq, lvl[2], raw, dlines;
     HT::E12 acc = HT::one12();
     try {
         dp.ensure(n * sizeof(mi_g1_affine));
@@ -713,8 +713,23 @@ HT::E12 device_miller(DevState& d, const mi_g1_affine* p, const mi_g2_affine* q,
         HIP_TRY(hipMemcpyAsync(dp.p, p, n * sizeof(mi_g1_affine), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(dq.p, q, n * sizeof(mi_g2_affine), hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(d.ev[1], s));
-        hipLaunchKernelGGL(msmk::k_miller_loop, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, s, (const uint32_t*)dp.p, (const uint32_t*)dq.p,
-                           (uint32_t)n, (uint32_t*)lvl[0].p);
+        static const bool single_lane = getenv("MI_PAIRING_SINGLE_LANE") != nullptr;   // the first kernel, kept for cross-checks
+        if (single_lane) {
+            hipLaunchKernelGGL(msmk::k_miller_loop, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, s, (const uint32_t*)dp.p, (const uint32_t*)dq.p,
+                               (uint32_t)n, (uint32_t*)lvl[0].p);
+        } else {
+            // line coefficients of a batch of pairs (26 KB per pair), then six lanes per pair fold them into f
+            const size_t batch = std::min<size_t>(n, 1u << 17);
+            dlines.ensure(batch * msmk::MILLER_LINES * 3 * 32 * 4);
+            for (size_t lo = 0; lo < n; lo += batch) {
+                uint32_t m = (uint32_t)std::min(batch, n - lo);
+                hipLaunchKernelGGL(msmk::k_miller_lines, dim3((m + 63) / 64), dim3(64), 0, s,
+                                   (const uint32_t*)dp.p + lo * msmk::Geo<msmk::G1C>::RAW_AFF, (const uint32_t*)dq.p + lo * msmk::Geo<msmk::G2C>::RAW_AFF,
+                                   m, (uint32_t*)dlines.p);
+                hipLaunchKernelGGL(msmk::k_miller_accumulate, dim3((m + msmk::MILLER_GROUPS - 1) / msmk::MILLER_GROUPS), dim3(64), 0, s,
+                                   (const uint32_t*)dlines.p, m, (uint32_t*)lvl[0].p + lo * msmk::FP12_WORDS);
+            }
+        }
         HIP_TRY(hipEventRecord(d.ev[2], s));
         size_t m = n;
         int cur = 0;
@@ -738,10 +753,10 @@ HT::E12 device_miller(DevState& d, const mi_g1_affine* p, const mi_g2_affine* q,
         d.prof.accumulate_ms = ev_ms(d.ev[1], d.ev[2]);   // Miller loops
         d.prof.reduce_ms = ev_ms(d.ev[2], d.ev[3]);       // multiplication tree
     } catch (...) {
-        for (DevBuf* b : {&dp, &dq, &lvl[0], &lvl[1], &raw}) b->release();
+        for (DevBuf* b : {&dp, &dq, &lvl[0], &lvl[1], &raw, &dlines}) b->release();
         throw;
     }
-    for (DevBuf* b : {&dp, &dq, &lvl[0], &lvl[1], &raw}) b->release();
+    for (DevBuf* b : {&dp, &dq, &lvl[0], &lvl[1], &raw, &dlines}) b->release();
     return acc;
 }
 

@@ -54,6 +54,169 @@ __global__ void __launch_bounds__(64, 1) k_miller_loop(const uint32_t* __restric
     store_fp12(out + (size_t)i * FP12_WORDS, f);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Two-kernel Miller loop (the default).  The one-lane-per-pair kernel above keeps an Fp12 (168 words) plus its
+// Karatsuba temporaries per lane: 4 KB of scratch per lane, 120 GB of HBM traffic for 2^16 pairs
+// (profiles/r01_e_pairing_pmc_summary.json) — it is bound by scratch traffic, not by arithmetic.  Split instead:
+//   k_miller_lines       one lane per pair walks T = [.]Q in Fp2 only (state: 6 + 4 + 2 field elements) and writes the 68
+//                        evaluated line coefficients (c0, c1, c4) — what the reference keeps in a G2Prepared, already
+//                        multiplied by xP / yP.  Layout [line][pair][3] Fp2 slots of 32 words.
+//   k_miller_accumulate  SIX lanes per pair: lane k owns coefficient k of f in the flat basis f = sum f_k w^k
+//                        (Fp12 = Fp2[w]/(w^6 - xi); tower slot of w^k: c_{k&1}.c_{k>>1}).  The six coefficients of a
+//                        pair sit in LDS; a product h = f g is h_k = sum_i xi^[i>k] f_i g_{(k-i) mod 6}: every lane
+//                        accumulates its six Fp2 products into two sets of 64-bit columns and reduces ONCE per
+//                        component (12 products per reduction).  No scratch, ~200 registers, two waves per SIMD.
+//                        A line is sparse (w^0, w^2, w^3): three terms.
+// Ten pairs per wave (lanes 60..63 idle).  A pair with P or Q at infinity gets the lines (1, 0, 0): f stays 1.
+constexpr int MILLER_LINES = 68;          // 63 doublings + 5 additions for |z| = 0xd201000000010000
+constexpr int MILLER_GROUPS = 10;         // pairs per wave in k_miller_accumulate
+constexpr int LDS_COEFF_WORDS = 36;       // one Fp2 coefficient in LDS: 2 x 16 words + 4 words of padding (bank spread)
+
+__global__ void __launch_bounds__(64, 1) k_miller_lines(const uint32_t* __restrict__ g1_raw, const uint32_t* __restrict__ g2_raw, uint32_t n,
+                                                        uint32_t* __restrict__ lines) {
+    using F2 = pairing::PF2;
+    uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* pr = g1_raw + (size_t)i * Geo<G1C>::RAW_AFF;
+    const uint32_t* qr = g2_raw + (size_t)i * Geo<G2C>::RAW_AFF;
+    uint32_t anyp = 0, anyq = 0;
+#pragma unroll 4
+    for (int k = 0; k < Geo<G1C>::RAW_AFF; k++) anyp |= pr[k];
+#pragma unroll 4
+    for (int k = 0; k < Geo<G2C>::RAW_AFF; k++) anyq |= qr[k];
+    auto slot = [&](int line) { return lines + ((size_t)line * n + i) * 3 * 32; };
+    if (anyp == 0 || anyq == 0) {
+#pragma unroll 1
+        for (int l = 0; l < MILLER_LINES; l++) {
+            uint32_t* o = slot(l);
+            ElemIO<ec::Fp2>::store(o, F2::one());
+            ElemIO<ec::Fp2>::store(o + 32, F2::zero());
+            ElemIO<ec::Fp2>::store(o + 64, F2::zero());
+        }
+        return;
+    }
+    Fp x, y;
+    fp_from_raw(x, pr);
+    fp_from_raw(y, pr + 12);
+    PTower::G1Pt p{fp28::fp_neg<4>(x), y};
+    ec::Fp2 xq, yq;
+    ElemIO<ec::Fp2>::from_raw(xq, qr);
+    ElemIO<ec::Fp2>::from_raw(yq, qr + 24);
+    PTower::PT T = ec::proj_from_affine<F2>(xq, yq);
+    int line = 0;
+#pragma unroll 1
+    for (int b = 62; b >= 0; b--) {
+        ec::Fp2 c0, c1, c4;
+        PTower::line_dbl(T, p, c0, c1, c4);
+        uint32_t* o = slot(line++);
+        ElemIO<ec::Fp2>::store(o, F2::norm2(c0));
+        ElemIO<ec::Fp2>::store(o + 32, c1);
+        ElemIO<ec::Fp2>::store(o + 64, c4);
+        if ((fp28c::Z_ABS >> b) & 1) {
+            PTower::line_add(T, xq, yq, p, c0, c1, c4);
+            o = slot(line++);
+            ElemIO<ec::Fp2>::store(o, F2::norm2(c0));
+            ElemIO<ec::Fp2>::store(o + 32, c1);
+            ElemIO<ec::Fp2>::store(o + 64, c4);
+        }
+    }
+}
+
+// columns += a * b (196 multiply-adds, no carries: see fp28.cuh)
+__device__ __forceinline__ void fp_acc(uint64_t (&c)[2 * fp28::NL], const Fp& a, const Fp& b) {
+#pragma unroll
+    for (int i = 0; i < fp28::NL; i++) {
+#pragma unroll
+        for (int j = 0; j < fp28::NL; j++) c[i + j] += (uint64_t)a.l[i] * b.l[j];
+    }
+}
+__device__ __forceinline__ ec::Fp2 lds_load_fp2(const uint32_t* p) {
+    ec::Fp2 r;
+    load_fp16(r.c0, p);
+    load_fp16(r.c1, p + 16);
+    return r;
+}
+__device__ __forceinline__ void lds_store_fp2(uint32_t* p, const ec::Fp2& a) {
+    store_fp16(p, a.c0);
+    store_fp16(p + 16, a.c1);
+}
+// (c0, c1) += a * g * xi^[wrapped]   with a, g exact (< 2p): four products into the two column sets.
+// Bounds: xi a <= (6p, 4p) in N-form, 4p - g1 <= 4p; six such terms sum to <= 216 p^2 (limit 2520); 168 column terms of
+// < 2^56.01 plus the reduction's 2^59.9 stay below 2^64.
+__device__ __forceinline__ void fp2_acc_term(uint64_t (&c0)[2 * fp28::NL], uint64_t (&c1)[2 * fp28::NL], const ec::Fp2& a, bool wrapped,
+                                             const ec::Fp2& g) {
+    Fp xa0 = fp28::fp_sub<4>(a.c0, a.c1), xa1 = fp28::fp_add(a.c0, a.c1);
+    Fp a0 = fp28::fp_select(wrapped, a.c0, xa0), a1 = fp28::fp_select(wrapped, a.c1, xa1);
+    Fp ng1 = fp28::fp_neg<4>(g.c1);
+    fp_acc(c0, a0, g.c0);
+    fp_acc(c0, a1, ng1);
+    fp_acc(c1, a0, g.c1);
+    fp_acc(c1, a1, g.c0);
+}
+
+__global__ void __launch_bounds__(64, 2) k_miller_accumulate(const uint32_t* __restrict__ lines, uint32_t n, uint32_t* __restrict__ out) {
+    __shared__ uint32_t fs[(MILLER_GROUPS + 1) * 6 * LDS_COEFF_WORDS];   // + one dummy group for the idle lanes
+    const uint32_t lane = threadIdx.x;
+    const uint32_t grp = lane / 6, k = lane - grp * 6;                   // lanes 60..63: group 10 (dummy)
+    const uint32_t pair = blockIdx.x * MILLER_GROUPS + grp;
+    const bool valid = grp < MILLER_GROUPS && pair < n;
+    const uint32_t pair_c = valid ? pair : n - 1;                        // idle lanes read a real pair's lines, write nothing
+    uint32_t* fg = fs + grp * 6 * LDS_COEFF_WORDS;
+    ec::Fp2 own = k == 0 ? ec::Fp2Ops::one() : ec::Fp2Ops::zero();
+    lds_store_fp2(fg + k * LDS_COEFF_WORDS, own);
+    __syncthreads();
+    int line = 0;
+    // h_k = sum over the three non-zero line coefficients at w^0, w^2, w^3
+    auto mul_line = [&]() {
+        const uint32_t* lp = lines + ((size_t)line * n + pair_c) * 3 * 32;
+        line++;
+        uint64_t c0[2 * fp28::NL], c1[2 * fp28::NL];
+#pragma unroll
+        for (int t = 0; t < 2 * fp28::NL; t++) { c0[t] = 0; c1[t] = 0; }
+#pragma unroll 1
+        for (int t = 0; t < 3; t++) {
+            int pos = t == 0 ? 0 : t + 1;                                // 0, 2, 3
+            int j = (int)k - pos;
+            bool wrapped = j < 0;
+            if (wrapped) j += 6;
+            ec::Fp2 g;
+            ElemIO<ec::Fp2>::load(g, lp + 32 * t);
+            fp2_acc_term(c0, c1, lds_load_fp2(fg + j * LDS_COEFF_WORDS), wrapped, g);
+        }
+        own.c0 = fp28::fp_mont_reduce(c0);
+        own.c1 = fp28::fp_mont_reduce(c1);
+        __syncthreads();                                                 // every lane has read the old f
+        lds_store_fp2(fg + k * LDS_COEFF_WORDS, own);
+        __syncthreads();
+    };
+#pragma unroll 1
+    for (int b = 62; b >= 0; b--) {
+        {   // f <- f^2 : h_k = sum_i xi^[i > k] f_i f_{(k - i) mod 6}
+            uint64_t c0[2 * fp28::NL], c1[2 * fp28::NL];
+#pragma unroll
+            for (int t = 0; t < 2 * fp28::NL; t++) { c0[t] = 0; c1[t] = 0; }
+#pragma unroll 1
+            for (int i = 0; i < 6; i++) {
+                int j = (int)k - i;
+                bool wrapped = j < 0;
+                if (wrapped) j += 6;
+                fp2_acc_term(c0, c1, lds_load_fp2(fg + i * LDS_COEFF_WORDS), wrapped, lds_load_fp2(fg + j * LDS_COEFF_WORDS));
+            }
+            own.c0 = fp28::fp_mont_reduce(c0);
+            own.c1 = fp28::fp_mont_reduce(c1);
+            __syncthreads();
+            lds_store_fp2(fg + k * LDS_COEFF_WORDS, own);
+            __syncthreads();
+        }
+        mul_line();
+        if ((fp28c::Z_ABS >> b) & 1) mul_line();
+    }
+    // z < 0: conjugate (w -> -w: odd coefficients negated); flat w^k -> tower slot c_{k&1}.c_{k>>1}
+    if (k & 1) own = ec::Fp2Ops::neg<4>(own);
+    if (valid) ElemIO<ec::Fp2>::store(out + (size_t)pair * FP12_WORDS + ((k & 1) * 3 + (k >> 1)) * 32, own);
+}
+
 __global__ void __launch_bounds__(64, 1) k_fp12_prod(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
     uint32_t g = blockIdx.x * 64 + threadIdx.x;
     uint32_t lo = g * FP12_TREE_K;
