@@ -735,7 +735,7 @@ HT::E12 device_miller(DevState& d, const mi_g1_affine* p, const mi_g2_affine* q,
         int cur = 0;
         while (m > 64) {
             size_t g = (m + msmk::FP12_TREE_K - 1) / msmk::FP12_TREE_K;
-            hipLaunchKernelGGL(msmk::k_fp12_prod, dim3((uint32_t)((g + 63) / 64)), dim3(64), 0, s, (const uint32_t*)lvl[cur].p, (uint32_t)m,
+            hipLaunchKernelGGL(msmk::k_fp12_prod, dim3((uint32_t)((g + msmk::MILLER_GROUPS - 1) / msmk::MILLER_GROUPS)), dim3(64), 0, s, (const uint32_t*)lvl[cur].p, (uint32_t)m,
                                (uint32_t*)lvl[cur ^ 1].p);
             cur ^= 1;
             m = g;

@@ -141,12 +141,13 @@ __device__ __forceinline__ void lds_store_fp2(uint32_t* p, const ec::Fp2& a) {
     store_fp16(p, a.c0);
     store_fp16(p + 16, a.c1);
 }
-// (c0, c1) += a * g * xi^[wrapped]   with a, g exact (< 2p): four products into the two column sets.
-// Bounds: xi a <= (6p, 4p) in N-form, 4p - g1 <= 4p; six such terms sum to <= 216 p^2 (limit 2520); 168 column terms of
-// < 2^56.01 plus the reduction's 2^59.9 stay below 2^64.
+// (c0, c1) += a * g * xi^[wrapped]   with a <= 4p (an exact coefficient or twice one), g exact (< 2p): four products
+// into the two column sets.  Bounds: xi a <= (12p, 8p) in N-form, 4p - g1 <= 4p: a term adds <= 56 p^2 to a component,
+// at most six terms per reduction (limit 2520 p^2); <= 168 column terms of < 2^56.01 plus the reduction's 2^59.9 stay
+// below 2^64.
 __device__ __forceinline__ void fp2_acc_term(uint64_t (&c0)[2 * fp28::NL], uint64_t (&c1)[2 * fp28::NL], const ec::Fp2& a, bool wrapped,
                                              const ec::Fp2& g) {
-    Fp xa0 = fp28::fp_sub<4>(a.c0, a.c1), xa1 = fp28::fp_add(a.c0, a.c1);
+    Fp xa0 = fp28::fp_sub<8>(a.c0, a.c1), xa1 = fp28::fp_add(a.c0, a.c1);
     Fp a0 = fp28::fp_select(wrapped, a.c0, xa0), a1 = fp28::fp_select(wrapped, a.c1, xa1);
     Fp ng1 = fp28::fp_neg<4>(g.c1);
     fp_acc(c0, a0, g.c0);
@@ -167,6 +168,12 @@ __global__ void __launch_bounds__(64, 2) k_miller_accumulate(const uint32_t* __r
     lds_store_fp2(fg + k * LDS_COEFF_WORDS, own);
     __syncthreads();
     int line = 0;
+    // squaring terms of this lane: the i <= j of the pairs i + j = k (mod 6): four of them for even k, three for odd k
+    uint32_t sq_tab = 0, sq_cnt = 0;
+    for (uint32_t i = 0; i < 6; i++) {
+        uint32_t j = (k + 6 - i) % 6;
+        if (i <= j) sq_tab |= i << (3 * sq_cnt++);
+    }
     // h_k = sum over the three non-zero line coefficients at w^0, w^2, w^3
     auto mul_line = [&]() {
         const uint32_t* lp = lines + ((size_t)line * n + pair_c) * 3 * 32;
@@ -192,16 +199,20 @@ __global__ void __launch_bounds__(64, 2) k_miller_accumulate(const uint32_t* __r
     };
 #pragma unroll 1
     for (int b = 62; b >= 0; b--) {
-        {   // f <- f^2 : h_k = sum_i xi^[i > k] f_i f_{(k - i) mod 6}
+        {   // f <- f^2 : h_k = sum over unordered {i, j}, i + j = k (mod 6), of (2 - [i == j]) xi^[i + j >= 6] f_i f_j
             uint64_t c0[2 * fp28::NL], c1[2 * fp28::NL];
 #pragma unroll
             for (int t = 0; t < 2 * fp28::NL; t++) { c0[t] = 0; c1[t] = 0; }
 #pragma unroll 1
-            for (int i = 0; i < 6; i++) {
-                int j = (int)k - i;
-                bool wrapped = j < 0;
-                if (wrapped) j += 6;
-                fp2_acc_term(c0, c1, lds_load_fp2(fg + i * LDS_COEFF_WORDS), wrapped, lds_load_fp2(fg + j * LDS_COEFF_WORDS));
+            for (uint32_t t = 0; t < 4; t++) {
+                uint32_t i = (sq_tab >> (3 * t)) & 7u;
+                int j = (int)k - (int)i;
+                if (j < 0) j += 6;
+                ec::Fp2 a = lds_load_fp2(fg + i * LDS_COEFF_WORDS);
+                ec::Fp2 a2 = ec::Fp2Ops::add(a, a);
+                a = ec::Fp2Ops::select((int)i != j, a, a2);
+                a = ec::Fp2Ops::select(t >= sq_cnt, a, ec::Fp2Ops::zero());          // odd k has three terms only
+                fp2_acc_term(c0, c1, a, i + (uint32_t)j >= 6, lds_load_fp2(fg + j * LDS_COEFF_WORDS));
             }
             own.c0 = fp28::fp_mont_reduce(c0);
             own.c1 = fp28::fp_mont_reduce(c1);
@@ -213,19 +224,52 @@ __global__ void __launch_bounds__(64, 2) k_miller_accumulate(const uint32_t* __r
         if ((fp28c::Z_ABS >> b) & 1) mul_line();
     }
     // z < 0: conjugate (w -> -w: odd coefficients negated); flat w^k -> tower slot c_{k&1}.c_{k>>1}
-    if (k & 1) own = ec::Fp2Ops::neg<4>(own);
+    if (k & 1) own = pairing::PF2::norm2(ec::Fp2Ops::neg<4>(own));       // exact again: the tree takes coefficients < 2p
     if (valid) ElemIO<ec::Fp2>::store(out + (size_t)pair * FP12_WORDS + ((k & 1) * 3 + (k >> 1)) * 32, own);
 }
 
-__global__ void __launch_bounds__(64, 1) k_fp12_prod(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
-    uint32_t g = blockIdx.x * 64 + threadIdx.x;
-    uint32_t lo = g * FP12_TREE_K;
-    if (lo >= n) return;
-    uint32_t hi = lo + FP12_TREE_K < n ? lo + FP12_TREE_K : n;
-    PTower::E12 acc = load_fp12(in + (size_t)lo * FP12_WORDS);
+// One level of the multiplication tree, six lanes per output: out[g] = prod in[g*K .. g*K+K).  Same scheme as
+// k_miller_accumulate: the running product's coefficients in LDS, the factor's coefficients read from HBM.
+__global__ void __launch_bounds__(64, 2) k_fp12_prod(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+    __shared__ uint32_t fs[(MILLER_GROUPS + 1) * 6 * LDS_COEFF_WORDS];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t grp = lane / 6, k = lane - grp * 6;
+    const uint32_t g = blockIdx.x * MILLER_GROUPS + grp;
+    const uint32_t groups = (n + FP12_TREE_K - 1) / FP12_TREE_K;
+    const bool valid = grp < MILLER_GROUPS && g < groups;
+    const uint32_t gc = valid ? g : groups - 1;
+    const uint32_t lo = gc * FP12_TREE_K, hi = lo + FP12_TREE_K < n ? lo + FP12_TREE_K : n;
+    auto slot = [](uint32_t coeff) { return ((coeff & 1u) * 3u + (coeff >> 1)) * 32u; };   // flat w^coeff -> tower slot
+    uint32_t* fg = fs + grp * 6 * LDS_COEFF_WORDS;
+    ec::Fp2 own;
+    ElemIO<ec::Fp2>::load(own, in + (size_t)lo * FP12_WORDS + slot(k));
+    lds_store_fp2(fg + k * LDS_COEFF_WORDS, own);
+    __syncthreads();
 #pragma unroll 1
-    for (uint32_t k = lo + 1; k < hi; k++) acc = PTower::mul12(acc, load_fp12(in + (size_t)k * FP12_WORDS));
-    store_fp12(out + (size_t)g * FP12_WORDS, acc);
+    for (uint32_t e = 1; e < FP12_TREE_K; e++) {
+        // every group runs all steps (barriers are block-wide); a group that is out of elements multiplies by in[hi-1]
+        // again and discards the result
+        const bool live = lo + e < hi;
+        const uint32_t* gp = in + (size_t)(live ? lo + e : hi - 1) * FP12_WORDS;
+        uint64_t c0[2 * fp28::NL], c1[2 * fp28::NL];
+#pragma unroll
+        for (int t = 0; t < 2 * fp28::NL; t++) { c0[t] = 0; c1[t] = 0; }
+#pragma unroll 1
+        for (int i = 0; i < 6; i++) {
+            int j = (int)k - i;
+            bool wrapped = j < 0;
+            if (wrapped) j += 6;
+            ec::Fp2 gj;
+            ElemIO<ec::Fp2>::load(gj, gp + slot((uint32_t)j));
+            fp2_acc_term(c0, c1, lds_load_fp2(fg + i * LDS_COEFF_WORDS), wrapped, gj);
+        }
+        ec::Fp2 r{fp28::fp_mont_reduce(c0), fp28::fp_mont_reduce(c1)};
+        own = ec::Fp2Ops::select(live, own, r);
+        __syncthreads();
+        lds_store_fp2(fg + k * LDS_COEFF_WORDS, own);
+        __syncthreads();
+    }
+    if (valid) ElemIO<ec::Fp2>::store(out + (size_t)g * FP12_WORDS + slot(k), own);
 }
 
 __global__ void __launch_bounds__(64) k_fp12_to_raw(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ raw) {
