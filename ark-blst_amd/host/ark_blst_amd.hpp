@@ -136,4 +136,31 @@ struct G2Projective {
     }
 };
 
+// impl Pairing for Bls12 (/root/reference/src/pairing.rs:37-81): TargetField = Fp12, G1Prepared = G1Affine; G2 points are
+// taken as plain affine points (the reference's G2Prepared is 68 precomputed lines; they are computed on the GPU instead).
+using Fp12 = mi_fp12;
+struct Bls12 {
+    // fn multi_miller_loop(a: impl IntoIterator<G1Prepared>, b: impl IntoIterator<G2Prepared>) -> MillerLoopOutput
+    // zip semantics: the shorter side decides (src/pairing.rs:55)
+    static Fp12 multi_miller_loop(const std::vector<G1Affine>& a, const std::vector<G2Affine>& b) {
+        Fp12 out;
+        int rc = mi_multi_miller_loop(context(), a.data(), b.data(), std::min(a.size(), b.size()), &out);
+        if (rc != MI_OK) throw std::runtime_error(std::string("multi_miller_loop: ") + mi_msm_last_error(context()));
+        return out;
+    }
+    // fn final_exponentiation(f: MillerLoopOutput) -> Option<PairingOutput>: always Some (src/pairing.rs:76-80)
+    static Fp12 final_exponentiation(const Fp12& f) {
+        Fp12 out;
+        mi_final_exponentiation(&f, &out);
+        return out;
+    }
+    static Fp12 multi_pairing(const std::vector<G1Affine>& a, const std::vector<G2Affine>& b) {
+        Fp12 out;
+        int rc = mi_multi_pairing(context(), a.data(), b.data(), std::min(a.size(), b.size()), &out);
+        if (rc != MI_OK) throw std::runtime_error(std::string("multi_pairing: ") + mi_msm_last_error(context()));
+        return out;
+    }
+    static Fp12 pairing(const G1Affine& p, const G2Affine& q) { return multi_pairing({p}, {q}); }
+};
+
 }  // namespace ark_blst

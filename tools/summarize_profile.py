@@ -3,6 +3,7 @@
 and per-kernel means of the PMC passes with the HBM traffic corrected as MI355X_MICROARCH.md §HBM prescribes
 (FETCH_SIZE and WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane reads -> doubled)."""
 import collections
+import os
 import csv
 import glob
 import json
@@ -12,11 +13,15 @@ import sys
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
 tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 what = sys.argv[3] if len(sys.argv) > 3 else "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary` (G1, 2^20, c=16)"
-shutil.copy(glob.glob(f"{src}/stats/runc/*kernel_stats.csv")[0], f"profiles/{tag}_kernel_stats.csv")
+def newest(pattern):   # gpurun merges runs into the same directory: take the latest file
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+shutil.copy(newest(f"{src}/stats/runc/*kernel_stats.csv"), f"profiles/{tag}_kernel_stats.csv")
 out = collections.defaultdict(dict)
 for name in ("fetch", "write", "sq"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(glob.glob(f"{src}/{name}/runc/*counter_collection.csv")[0])):
+    for r in csv.DictReader(open(newest(f"{src}/{name}/runc/*counter_collection.csv"))):
         acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         for c, xs in v.items():
