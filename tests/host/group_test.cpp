@@ -51,9 +51,30 @@ static int run(const std::string& dir, const char* tag) {
     return 0;
 }
 
+// the reference's pairing test (/root/reference/src/pairing.rs:92-101): e(s G1, G2) == e(G1, s G2)
+static int run_pairing(const std::string& dir) {
+    auto sp = read_vec<G1Affine>(dir + "/pair_sP.bin"), p = read_vec<G1Affine>(dir + "/pair_P.bin");
+    auto q = read_vec<G2Affine>(dir + "/pair_Q.bin"), sq = read_vec<G2Affine>(dir + "/pair_sQ.bin");
+    CHECK(sp.size() == 1 && p.size() == 1 && q.size() == 1 && sq.size() == 1);
+    Fp12 left = Bls12::pairing(sp[0], q[0]);
+    Fp12 right = Bls12::pairing(p[0], sq[0]);
+    CHECK(std::memcmp(&left, &right, sizeof left) == 0);
+    Fp12 plain = Bls12::pairing(p[0], q[0]);
+    CHECK(std::memcmp(&left, &plain, sizeof left) != 0);
+    // multi_miller_loop + final_exponentiation == multi_pairing; e(sP, Q) e(-(sP)... ) handled in the Python suite
+    std::vector<G1Affine> a{sp[0], p[0]};
+    std::vector<G2Affine> b{q[0], sq[0]};
+    Fp12 two = Bls12::final_exponentiation(Bls12::multi_miller_loop(a, b));
+    Fp12 two2 = Bls12::multi_pairing(a, b);
+    CHECK(std::memcmp(&two, &two2, sizeof two) == 0);
+    std::printf("pairing test OK\n");
+    return 0;
+}
+
 int main(int argc, char** argv) {
     std::string dir = argc > 1 ? argv[1] : ".";
     if (run<G1Projective, G1Affine>(dir, "g1")) return 1;
     if (run<G2Projective, G2Affine>(dir, "g2")) return 1;
+    if (run_pairing(dir)) return 1;
     return 0;
 }

@@ -306,9 +306,14 @@ def test_cpp_host_mirror_group_test(tmp_path, co, o):
         (tmp_path / f"{group}_scalars_canon.bin").write_bytes(canon)
         (tmp_path / f"{group}_scalars_mont.bin").write_bytes(co.fr_to_mont(canon))
         (tmp_path / f"{group}_expected_affine.bin").write_bytes(co.dlog_expected(group, canon, SEED_B + 30, n))
+    s = 0x6A09E667F3BCC908B2FB1366EA957D3E3ADEC17512775099DA2F590B0667322A % o.R_ORDER
+    (tmp_path / "pair_P.bin").write_bytes(o.affine_to_bytes(o.F1, o.G1_GEN))
+    (tmp_path / "pair_Q.bin").write_bytes(o.affine_to_bytes(o.F2, o.G2_GEN))
+    (tmp_path / "pair_sP.bin").write_bytes(o.affine_to_bytes(o.F1, o.scalar_mul(o.F1, o.G1_GEN, s)))
+    (tmp_path / "pair_sQ.bin").write_bytes(o.affine_to_bytes(o.F2, o.scalar_mul(o.F2, o.G2_GEN, s)))
     out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "g1 group_test OK" in out.stdout and "g2 group_test OK" in out.stdout
+    assert "g1 group_test OK" in out.stdout and "g2 group_test OK" in out.stdout and "pairing test OK" in out.stdout
 
 
 def test_g1_deserialize_golden(ctx):

@@ -101,3 +101,13 @@ def test_golden_vectors(ctx):
     gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pairing_vectors.json")))
     for c in gold["multi_pairing"]:
         assert ctx.multi_pairing(bytes.fromhex(c["g1"]), bytes.fromhex(c["g2"])).hex() == c["gt"], c["name"]
+
+
+def test_pairs_sharded_over_devices(pkg, ctx, co):
+    """a context with several devices shards the pairs and multiplies the per-device products (here: device 0 twice)"""
+    n = 131
+    g1 = co.gen_bases("g1", SEED_P + 5, n, 2)
+    g2 = co.gen_bases("g2", SEED_Q + 5, n, 2)
+    with pkg.Context([0, 0, 0]) as c3:
+        assert c3.multi_pairing(g1, g2) == ctx.multi_pairing(g1, g2)
+        assert c3.multi_pairing(g1[:96], g2[:192]) == ctx.multi_pairing(g1[:96], g2[:192])
