@@ -719,7 +719,8 @@ HT::E12 device_miller(DevState& d, const mi_g1_affine* p, const mi_g2_affine* q,
                                (uint32_t)n, (uint32_t*)lvl[0].p);
         } else {
             // line coefficients of a batch of pairs (26 KB per pair), then six lanes per pair fold them into f
-            const size_t batch = std::min<size_t>(n, 1u << 17);
+            static const size_t batch_cap = getenv("MI_PAIRING_BATCH") ? std::max(1, atoi(getenv("MI_PAIRING_BATCH"))) : (1u << 17);   // test hook
+            const size_t batch = std::min<size_t>(n, batch_cap);
             dlines.ensure(batch * msmk::MILLER_LINES * 3 * 32 * 4);
             for (size_t lo = 0; lo < n; lo += batch) {
                 uint32_t m = (uint32_t)std::min(batch, n - lo);

@@ -195,6 +195,34 @@ def main() -> None:
         two_thread = {"value": n * args.steps / e2, "unit": "points/s", "ms_per_step": e2 / args.steps * 1e3, "same_result": ok2}
         ctx2.close()
 
+    # ---- secondary figure (N = 1 only): the pairing row (BASELINE config #5): 2^16 G1 x G2 pairs through
+    # mi_multi_pairing; parity = prod e(P_i, Q_i) e(-P_i, Q_i) == 1 at full size (tools/bench_pairing.py has the oracle check)
+    pairing = None
+    if world == 1 and args.concurrency == 1 and not args.no_secondary:
+        try:
+            from oracle import pairing as pr_oracle, bls12_381 as o
+            half = 1 << 15
+            p1 = co.gen_bases("g1", seed_b + 101, half, ncpu)
+            q2 = co.gen_bases("g2", seed_b + 102, half, ncpu)
+            neg = bytearray(p1)
+            for i in range(half):   # -P: y -> p - y (Montgomery form, y != 0)
+                y = int.from_bytes(p1[96 * i + 48:96 * i + 96], "little")
+                neg[96 * i + 48:96 * i + 96] = (o.P - y).to_bytes(48, "little")
+            P_all, Q_all = p1 + bytes(neg), q2 + q2
+            ctx.multi_pairing(P_all[:96 * 64], Q_all[:192 * 64])
+            best = 1e30
+            for _ in range(3):
+                t1 = time.perf_counter()
+                gt = ctx.multi_pairing(P_all, Q_all)
+                best = min(best, time.perf_counter() - t1)
+            pp = ctx.profile()
+            pairing = {"metric": "pairs/s, batched Miller loop + final exponentiation (host buffers in, Gt out)", "value": 2 * half / best,
+                       "n_pairs": 2 * half, "ms": best * 1e3, "miller_kernels_ms": pp["accumulate_ms"], "fp12_tree_ms": pp["reduce_ms"],
+                       "h2d_ms": pp["h2d_ms"], "host_tail_ms": pp["host_fold_ms"],
+                       "product_cancels_to_one": gt == pr_oracle.fp12_to_bytes(pr_oracle.FP12_ONE)}
+        except Exception as e:   # never let a secondary figure break the headline line
+            pairing = {"error": repr(e)}
+
     # ---- parity: closed form over ALL ranks' inputs
     expected_parts = []
     mine_expected = co.dlog_expected(g, scalars, seed_b, n)          # affine bytes of this rank's shard
@@ -263,6 +291,7 @@ def main() -> None:
                           ("digits_ms", "scan_ms", "scatter_ms", "accumulate_ms", "reduce_ms", "d2h_ms", "host_fold_ms", "total_ms")},
             "input_gen_s": gen_s,
             "two_host_threads": two_thread,
+            "pairing_2p16": pairing,
         }
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
             best = 1e30

@@ -111,3 +111,31 @@ def test_pairs_sharded_over_devices(pkg, ctx, co):
     with pkg.Context([0, 0, 0]) as c3:
         assert c3.multi_pairing(g1, g2) == ctx.multi_pairing(g1, g2)
         assert c3.multi_pairing(g1[:96], g2[:192]) == ctx.multi_pairing(g1[:96], g2[:192])
+
+
+def test_line_buffer_batches(co):
+    """more pairs than one line-buffer batch (2^17 in production; forced to 100 here through the test hook): a child
+    process, because the library reads MI_PAIRING_BATCH once"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "from oracle import coracle as co\n"
+        "pkg = ge.load_package()\n"
+        "g1 = co.gen_bases('g1', 77, 257, 2); g2 = co.gen_bases('g2', 78, 257, 2)\n"
+        "with pkg.Context([0]) as c: print(c.multi_pairing(g1, g2).hex())\n" % root)
+    env = dict(os.environ)
+    outs = []
+    for batch in ("100", None):
+        if batch:
+            env["MI_PAIRING_BATCH"] = batch
+        else:
+            env.pop("MI_PAIRING_BATCH", None)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and len(outs[0]) == 1152
