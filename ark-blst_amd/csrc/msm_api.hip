@@ -724,7 +724,7 @@ HT::E12 device_miller(DevState& d, const mi_g1_affine* p, const mi_g2_affine* q,
             dlines.ensure(batch * msmk::MILLER_LINES * 3 * 32 * 4);
             for (size_t lo = 0; lo < n; lo += batch) {
                 uint32_t m = (uint32_t)std::min(batch, n - lo);
-                hipLaunchKernelGGL(msmk::k_miller_lines, dim3((m + 63) / 64), dim3(64), 0, s,
+                hipLaunchKernelGGL(msmk::k_miller_lines2, dim3((2 * m + 63) / 64), dim3(64), 0, s,
                                    (const uint32_t*)dp.p + lo * msmk::Geo<msmk::G1C>::RAW_AFF, (const uint32_t*)dq.p + lo * msmk::Geo<msmk::G2C>::RAW_AFF,
                                    m, (uint32_t*)dlines.p);
                 hipLaunchKernelGGL(msmk::k_miller_accumulate, dim3((m + msmk::MILLER_GROUPS - 1) / msmk::MILLER_GROUPS), dim3(64), 0, s,

@@ -123,6 +123,98 @@ __global__ void __launch_bounds__(64, 1) k_miller_lines(const uint32_t* __restri
     }
 }
 
+
+// Fp2 arithmetic split over a LANE PAIR: the even lane holds c0 and the odd lane c1 of every Fp2 value; a product
+// exchanges the partner's components by DPP (quad_perm [1,0,3,2]) and each lane does ONE fused two-product reduction:
+//   even: a0 b0 + a1 (32p - b1)        odd: a0 b1 + a1 b0
+// Same static interface as pairing::PF2, so the generic line functions of pairing.cuh run on it unchanged (the value
+// bounds checked by tests/host/pairing_bounds.cpp are per component and carry over).  Halves the registers and the
+// dependent chain per lane: k_miller_lines runs two waves per SIMD instead of one lone wave.
+struct CoopF2 {
+    using E = Fp;
+    using Fp = fp28::Fp;
+    static __device__ __forceinline__ bool hi() { return (threadIdx.x & 1u) != 0; }
+    static __device__ __forceinline__ Fp partner(const Fp& a) {
+        Fp r;
+#pragma unroll
+        for (int k = 0; k < fp28::NL; k++) r.l[k] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.l[k], 0xB1, 0xF, 0xF, true);
+        return r;
+    }
+    static __device__ __forceinline__ E zero() { return fp28::fp_zero(); }
+    static __device__ __forceinline__ E one() { return fp28::fp_select(hi(), fp28::fp_one(), fp28::fp_zero()); }
+    static __device__ __forceinline__ E mul(const E& a, const E& b) {
+        Fp pa = partner(a), pb = partner(b);
+        Fp x = fp28::fp_select(hi(), a, pa);                       // a0
+        Fp z = fp28::fp_select(hi(), pa, a);                       // a1
+        Fp w = fp28::fp_select(hi(), fp28::fp_neg<32>(pb), pb);    // even: 32p - b1, odd: b0
+        return fp28::fp_mul2add_call(x, b, z, w);
+    }
+    static __device__ __forceinline__ E sqr(const E& a) {          // (a0 + a1)(a0 - a1) | (2 a0) a1
+        Fp pa = partner(a);
+        Fp u = fp28::fp_select(hi(), fp28::fp_add(a, pa), fp28::fp_add(pa, pa));
+        Fp v = fp28::fp_select(hi(), fp28::fp_sub<32>(a, pa), a);
+        return fp28::fp_mul_call(u, v);
+    }
+    static __device__ __forceinline__ E mul2add(const E& a, const E& b, const E& c, const E& d) { return fp28::fp_add(mul(a, b), mul(c, d)); }
+    static __device__ __forceinline__ E add(const E& a, const E& b) { return fp28::fp_add(a, b); }
+    template <int K>
+    static __device__ __forceinline__ E sub(const E& a, const E& b) { return fp28::fp_sub<K>(a, b); }
+    template <int K>
+    static __device__ __forceinline__ E neg(const E& a) { return fp28::fp_neg<K>(a); }
+    static __device__ __forceinline__ E mul3(const E& a) { return fp28::fp_mul_small<3>(a); }
+    static __device__ __forceinline__ E mul_b3(const E& a) { return mul(a, fp28::fp_const(fp28::TWELVE)); }   // b3 = 12 + 12u
+    static __device__ __forceinline__ E mul_fp(const E& a, const Fp& s) { return fp28::fp_mul_call(a, s); }
+    static __device__ __forceinline__ E norm2(const E& a) { return fp28::fp_mul_call(a, fp28::fp_one()); }
+    static __device__ __forceinline__ E dbl(const E& a) { return fp28::fp_add(a, a); }
+    static __device__ __forceinline__ Fp fp_neg4(const Fp& a) { return fp28::fp_neg<4>(a); }
+    static __device__ __forceinline__ E select(bool take_b, const E& a, const E& b) { return fp28::fp_select(take_b, a, b); }
+};
+using CTower = pairing::Tower<CoopF2>;
+
+// Two lanes per pair (see CoopF2).  Lines of a pair with P or Q at infinity are overwritten with (1, 0, 0) at store time,
+// so every lane runs the same instruction stream (the DPP exchange needs both lanes of a pair anyway).
+__global__ void __launch_bounds__(64, 2) k_miller_lines2(const uint32_t* __restrict__ g1_raw, const uint32_t* __restrict__ g2_raw, uint32_t n,
+                                                         uint32_t* __restrict__ lines) {
+    const uint32_t h = threadIdx.x & 1u;
+    const uint32_t pair = (blockIdx.x * 64 + threadIdx.x) >> 1;
+    const bool valid = pair < n;
+    const uint32_t i = valid ? pair : n - 1;
+    const uint32_t* pr = g1_raw + (size_t)i * Geo<G1C>::RAW_AFF;
+    const uint32_t* qr = g2_raw + (size_t)i * Geo<G2C>::RAW_AFF;
+    uint32_t anyp = 0, anyq = 0;
+#pragma unroll 4
+    for (int k = 0; k < Geo<G1C>::RAW_AFF; k++) anyp |= pr[k];
+#pragma unroll 4
+    for (int k = 0; k < Geo<G2C>::RAW_AFF; k++) anyq |= qr[k];
+    const bool inf = anyp == 0 || anyq == 0;
+    Fp x, y, xq, yq;
+    fp_from_raw(x, pr);
+    fp_from_raw(y, pr + 12);
+    fp_from_raw(xq, qr + 12 * h);              // this lane's component of x_Q, y_Q
+    fp_from_raw(yq, qr + 24 + 12 * h);
+    CTower::G1Pt p{fp28::fp_neg<4>(x), y};
+    CTower::PT T = ec::proj_from_affine<CoopF2>(xq, yq);
+    const Fp id = CoopF2::one();               // component of the Fp2 one
+    auto put = [&](int line, const Fp& c0, const Fp& c1, const Fp& c4) {
+        if (!valid) return;
+        uint32_t* o = lines + ((size_t)line * n + pair) * 3 * 32 + 16 * h;
+        store_fp16(o, fp28::fp_select(inf, CoopF2::norm2(c0), id));
+        store_fp16(o + 32, fp28::fp_select(inf, c1, fp28::fp_zero()));
+        store_fp16(o + 64, fp28::fp_select(inf, c4, fp28::fp_zero()));
+    };
+    int line = 0;
+#pragma unroll 1
+    for (int b = 62; b >= 0; b--) {
+        Fp c0, c1, c4;
+        CTower::line_dbl(T, p, c0, c1, c4);
+        put(line++, c0, c1, c4);
+        if ((fp28c::Z_ABS >> b) & 1) {
+            CTower::line_add(T, xq, yq, p, c0, c1, c4);
+            put(line++, c0, c1, c4);
+        }
+    }
+}
+
 // columns += a * b (196 multiply-adds, no carries: see fp28.cuh)
 __device__ __forceinline__ void fp_acc(uint64_t (&c)[2 * fp28::NL], const Fp& a, const Fp& b) {
 #pragma unroll
