@@ -206,7 +206,7 @@ struct Tower {
     // tangent line at T (scaled by 2YZ) evaluated at P, then T <- 2T by the exception-free doubling of
     // Renes-Costello-Batina 2016, Alg. 9 (a = 0), which shares Y^2, Z^2, b3 Z^2 and Y Z with the line: 3 S + 7 M.
     // T <= 6p in, T < 4p out.
-    static FP_HD_NOINLINE void line_dbl(PT& T, const G1Pt& p, E2& c0, E2& c1, E2& c4) {
+    static FP_HD void line_dbl(PT& T, const G1Pt& p, E2& c0, E2& c1, E2& c4) {
         E2 t0 = F2::sqr(T.y);                                                    // Y^2
         E2 t1 = F2::mul(T.y, T.z);                                               // Y Z
         E2 t2 = F2::mul_b3(F2::sqr(T.z));                                        // b3 Z^2 = 3b' Z^2
@@ -223,7 +223,7 @@ struct Tower {
         T.x = F2::dbl(F2::mul(d, xy));
     }
     // line through T and Q (scaled by X - xQ Z) evaluated at P, then T <- T + Q
-    static FP_HD_NOINLINE void line_add(PT& T, const E2& xq, const E2& yq, const G1Pt& p, E2& c0, E2& c1, E2& c4) {
+    static FP_HD void line_add(PT& T, const E2& xq, const E2& yq, const G1Pt& p, E2& c0, E2& c1, E2& c4) {
         E2 N = F2::template sub<4>(T.y, F2::mul(yq, T.z));                       // < 10p
         E2 D = F2::template sub<4>(T.x, F2::mul(xq, T.z));
         c0 = F2::template sub<4>(F2::mul(N, xq), F2::mul(D, yq));                // N xQ - D yQ            < 6p

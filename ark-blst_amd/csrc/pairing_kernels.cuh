@@ -147,13 +147,13 @@ struct CoopF2 {
         Fp x = fp28::fp_select(hi(), a, pa);                       // a0
         Fp z = fp28::fp_select(hi(), pa, a);                       // a1
         Fp w = fp28::fp_select(hi(), fp28::fp_neg<32>(pb), pb);    // even: 32p - b1, odd: b0
-        return fp28::fp_mul2add_call(x, b, z, w);
+        return fp28::fp_mul2add(x, b, z, w);
     }
     static __device__ __forceinline__ E sqr(const E& a) {          // (a0 + a1)(a0 - a1) | (2 a0) a1
         Fp pa = partner(a);
         Fp u = fp28::fp_select(hi(), fp28::fp_add(a, pa), fp28::fp_add(pa, pa));
         Fp v = fp28::fp_select(hi(), fp28::fp_sub<32>(a, pa), a);
-        return fp28::fp_mul_call(u, v);
+        return fp28::fp_mul(u, v);
     }
     static __device__ __forceinline__ E mul2add(const E& a, const E& b, const E& c, const E& d) { return fp28::fp_add(mul(a, b), mul(c, d)); }
     static __device__ __forceinline__ E add(const E& a, const E& b) { return fp28::fp_add(a, b); }
@@ -163,8 +163,8 @@ struct CoopF2 {
     static __device__ __forceinline__ E neg(const E& a) { return fp28::fp_neg<K>(a); }
     static __device__ __forceinline__ E mul3(const E& a) { return fp28::fp_mul_small<3>(a); }
     static __device__ __forceinline__ E mul_b3(const E& a) { return mul(a, fp28::fp_const(fp28::TWELVE)); }   // b3 = 12 + 12u
-    static __device__ __forceinline__ E mul_fp(const E& a, const Fp& s) { return fp28::fp_mul_call(a, s); }
-    static __device__ __forceinline__ E norm2(const E& a) { return fp28::fp_mul_call(a, fp28::fp_one()); }
+    static __device__ __forceinline__ E mul_fp(const E& a, const Fp& s) { return fp28::fp_mul(a, s); }
+    static __device__ __forceinline__ E norm2(const E& a) { return fp28::fp_mul(a, fp28::fp_one()); }
     static __device__ __forceinline__ E dbl(const E& a) { return fp28::fp_add(a, a); }
     static __device__ __forceinline__ Fp fp_neg4(const Fp& a) { return fp28::fp_neg<4>(a); }
     static __device__ __forceinline__ E select(bool take_b, const E& a, const E& b) { return fp28::fp_select(take_b, a, b); }
