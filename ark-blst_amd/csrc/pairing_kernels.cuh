@@ -59,9 +59,10 @@ __global__ void __launch_bounds__(64, 1) k_miller_loop(const uint32_t* __restric
 // Two-kernel Miller loop (the default).  The one-lane-per-pair kernel above keeps an Fp12 (168 words) plus its
 // Karatsuba temporaries per lane: 4 KB of scratch per lane, 120 GB of HBM traffic for 2^16 pairs
 // (profiles/r01_e_pairing_pmc_summary.json) — it is bound by scratch traffic, not by arithmetic.  Split instead:
-//   k_miller_lines       one lane per pair walks T = [.]Q in Fp2 only (state: 6 + 4 + 2 field elements) and writes the 68
-//                        evaluated line coefficients (c0, c1, c4) — what the reference keeps in a G2Prepared, already
-//                        multiplied by xP / yP.  Layout [line][pair][3] Fp2 slots of 32 words.
+//   k_miller_lines2      TWO lanes per pair walk T = [.]Q in Fp2 only (state: 6 + 4 + 2 field elements, one Fp2 component
+//                        per lane, see CoopF2) and write the 68 evaluated line coefficients (c0, c1, c4) — what the
+//                        reference keeps in a G2Prepared, already multiplied by xP / yP.  Layout [line][pair][3] Fp2
+//                        slots of 32 words.
 //   k_miller_accumulate  SIX lanes per pair: lane k owns coefficient k of f in the flat basis f = sum f_k w^k
 //                        (Fp12 = Fp2[w]/(w^6 - xi); tower slot of w^k: c_{k&1}.c_{k>>1}).  The six coefficients of a
 //                        pair sit in LDS; a product h = f g is h_k = sum_i xi^[i>k] f_i g_{(k-i) mod 6}: every lane
@@ -73,63 +74,13 @@ constexpr int MILLER_LINES = 68;          // 63 doublings + 5 additions for |z| 
 constexpr int MILLER_GROUPS = 10;         // pairs per wave in k_miller_accumulate
 constexpr int LDS_COEFF_WORDS = 36;       // one Fp2 coefficient in LDS: 2 x 16 words + 4 words of padding (bank spread)
 
-__global__ void __launch_bounds__(64, 1) k_miller_lines(const uint32_t* __restrict__ g1_raw, const uint32_t* __restrict__ g2_raw, uint32_t n,
-                                                        uint32_t* __restrict__ lines) {
-    using F2 = pairing::PF2;
-    uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t* pr = g1_raw + (size_t)i * Geo<G1C>::RAW_AFF;
-    const uint32_t* qr = g2_raw + (size_t)i * Geo<G2C>::RAW_AFF;
-    uint32_t anyp = 0, anyq = 0;
-#pragma unroll 4
-    for (int k = 0; k < Geo<G1C>::RAW_AFF; k++) anyp |= pr[k];
-#pragma unroll 4
-    for (int k = 0; k < Geo<G2C>::RAW_AFF; k++) anyq |= qr[k];
-    auto slot = [&](int line) { return lines + ((size_t)line * n + i) * 3 * 32; };
-    if (anyp == 0 || anyq == 0) {
-#pragma unroll 1
-        for (int l = 0; l < MILLER_LINES; l++) {
-            uint32_t* o = slot(l);
-            ElemIO<ec::Fp2>::store(o, F2::one());
-            ElemIO<ec::Fp2>::store(o + 32, F2::zero());
-            ElemIO<ec::Fp2>::store(o + 64, F2::zero());
-        }
-        return;
-    }
-    Fp x, y;
-    fp_from_raw(x, pr);
-    fp_from_raw(y, pr + 12);
-    PTower::G1Pt p{fp28::fp_neg<4>(x), y};
-    ec::Fp2 xq, yq;
-    ElemIO<ec::Fp2>::from_raw(xq, qr);
-    ElemIO<ec::Fp2>::from_raw(yq, qr + 24);
-    PTower::PT T = ec::proj_from_affine<F2>(xq, yq);
-    int line = 0;
-#pragma unroll 1
-    for (int b = 62; b >= 0; b--) {
-        ec::Fp2 c0, c1, c4;
-        PTower::line_dbl(T, p, c0, c1, c4);
-        uint32_t* o = slot(line++);
-        ElemIO<ec::Fp2>::store(o, F2::norm2(c0));
-        ElemIO<ec::Fp2>::store(o + 32, c1);
-        ElemIO<ec::Fp2>::store(o + 64, c4);
-        if ((fp28c::Z_ABS >> b) & 1) {
-            PTower::line_add(T, xq, yq, p, c0, c1, c4);
-            o = slot(line++);
-            ElemIO<ec::Fp2>::store(o, F2::norm2(c0));
-            ElemIO<ec::Fp2>::store(o + 32, c1);
-            ElemIO<ec::Fp2>::store(o + 64, c4);
-        }
-    }
-}
-
-
 // Fp2 arithmetic split over a LANE PAIR: the even lane holds c0 and the odd lane c1 of every Fp2 value; a product
 // exchanges the partner's components by DPP (quad_perm [1,0,3,2]) and each lane does ONE fused two-product reduction:
 //   even: a0 b0 + a1 (32p - b1)        odd: a0 b1 + a1 b0
 // Same static interface as pairing::PF2, so the generic line functions of pairing.cuh run on it unchanged (the value
 // bounds checked by tests/host/pairing_bounds.cpp are per component and carry over).  Halves the registers and the
-// dependent chain per lane: k_miller_lines runs two waves per SIMD instead of one lone wave.
+// dependent chain per lane.  The multiplier is inlined here: through the shared out-of-line bodies the values that live
+// across the calls spill (measured 12.5 vs 14.5 ms for the whole Miller phase at 2^16 pairs).
 struct CoopF2 {
     using E = Fp;
     using Fp = fp28::Fp;
