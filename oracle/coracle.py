@@ -148,3 +148,42 @@ def fr_to_mont(a: bytes) -> bytes:
     out = C.create_string_buffer(32 * n)
     lib().orc_fr_to_mont(a, out, n)
     return out.raw
+
+
+# ---- pairing (oracle/pairing_oracle.c) -------------------------------------------------------------------------
+_PLIB = None
+
+
+def plib():
+    global _PLIB
+    if _PLIB is None:
+        path = os.path.join(_HERE, "libpairing_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_multi_miller_loop.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_char_p]
+        L.orc_fp12_pow.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p]
+        L.orc_fp12_mul.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+        _PLIB = L
+    return _PLIB
+
+
+def multi_miller_loop(g1: bytes, g2: bytes, nthreads: int = 1) -> bytes:
+    n = len(g1) // G1_AFF
+    assert len(g1) == n * G1_AFF and len(g2) == n * G2_AFF
+    out = C.create_string_buffer(576)
+    plib().orc_multi_miller_loop(g1, g2, n, nthreads, out)
+    return out.raw
+
+
+def final_exponentiation(f: bytes) -> bytes:
+    from . import pairing as pr   # the exponent 3 (p^12 - 1) / r as an integer
+
+    e = pr.FINAL_EXP.to_bytes((pr.FINAL_EXP.bit_length() + 7) // 8, "little")
+    out = C.create_string_buffer(576)
+    plib().orc_fp12_pow(f, e, len(e), out)
+    return out.raw
+
+
+def multi_pairing(g1: bytes, g2: bytes, nthreads: int = 1) -> bytes:
+    return final_exponentiation(multi_miller_loop(g1, g2, nthreads))

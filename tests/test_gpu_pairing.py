@@ -41,6 +41,14 @@ def test_multi_pairing_vs_oracle(ctx, co, o, pr, n):
     assert got == pr.fp12_to_bytes(want)
 
 
+@pytest.mark.parametrize("n", [63, 700])
+def test_multi_pairing_vs_c_oracle(ctx, co, n):
+    """hundreds of random pairs, bit-exact against the C restatement of the textbook algorithm (oracle/pairing_oracle.c)"""
+    g1 = co.gen_bases("g1", SEED_P + 9, n, 8)
+    g2 = co.gen_bases("g2", SEED_Q + 9, n, 8)
+    assert ctx.multi_pairing(g1, g2) == co.multi_pairing(g1, g2, 8)
+
+
 def test_miller_then_final_exp_equals_multi_pairing(ctx, co, pkg):
     n = 7
     g1 = co.gen_bases("g1", SEED_P + 1, n, 1)

@@ -48,6 +48,19 @@ def test_oracle_reproduces_golden(pr, o, gold):
         assert pr.fp12_to_bytes(pr.final_exponentiation(pr.multi_miller_loop(ps, qs))).hex() == c["gt"], c["name"]
 
 
+def test_c_oracle_vs_python_oracle_and_golden(co, pr, o, gold):
+    """oracle/pairing_oracle.c (fast checker + timed CPU baseline) against oracle/pairing.py and the frozen vectors"""
+    for c in gold["multi_pairing"]:
+        assert co.multi_pairing(bytes.fromhex(c["g1"]), bytes.fromhex(c["g2"]), 2).hex() == c["gt"], c["name"]
+    g = gold["final_exponentiation"]
+    assert co.final_exponentiation(bytes.fromhex(g["f"])).hex() == g["out"]
+    g1 = co.gen_bases("g1", 31, 3, 1)
+    g2 = co.gen_bases("g2", 32, 3, 1)
+    ps = [o.affine_from_bytes(o.F1, g1[96 * i:96 * i + 96]) for i in range(3)]
+    qs = [o.affine_from_bytes(o.F2, g2[192 * i:192 * i + 192]) for i in range(3)]
+    assert co.multi_miller_loop(g1, g2, 3) == pr.fp12_to_bytes(pr.multi_miller_loop(ps, qs))   # same algorithm: equal before the exponentiation too
+
+
 def test_lazy_reduction_bounds_of_shipped_code():
     exe = os.path.join(HERE, "host", "pairing_bounds")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(HERE, "host", "pairing_bounds.cpp")])

@@ -38,9 +38,19 @@ with pkg.Context([0]) as ctx:
     qs = [o.affine_from_bytes(o.F2, g2[192 * i:192 * i + 192]) for i in range(3)]
     exact = sample == pr.fp12_to_bytes(pr.final_exponentiation(pr.multi_miller_loop(ps, qs)))
     assert exact
+    # 1024 random pairs against the C oracle, which is also the timed CPU baseline ("port")
+    m = min(1024, half)
+    ncpu = min(16, len(os.sched_getaffinity(0)))
+    t0 = time.perf_counter(); cpu_gt = co.multi_pairing(g1[:96 * m], g2[:192 * m], ncpu); cpu_s = time.perf_counter() - t0
+    exact_c = ctx.multi_pairing(g1[:96 * m], g2[:192 * m]) == cpu_gt
+    assert exact_c
 wall, prof = best
 print(json.dumps({"metric": "pairs_per_second", "value": n / wall, "unit": "pairs/s", "n_pairs": n, "ms": wall * 1e3,
                   "phases_ms": {"h2d": prof["h2d_ms"], "miller_loops": prof["accumulate_ms"], "fp12_tree": prof["reduce_ms"],
                                 "host_tail_and_final_exp": prof["host_fold_ms"]},
                   "miller_loops_per_s_kernel": n / (prof["accumulate_ms"] * 1e-3),
-                  "bit_exact_sample_vs_oracle": exact, "cancellation_at_full_size": True, "data": "synthetic"}))
+                  "bit_exact_sample_vs_oracle": exact, "bit_exact_1024_pairs_vs_c_oracle": exact_c, "cancellation_at_full_size": True,
+                  "cpu_baseline": {"value": m / cpu_s, "unit": "pairs/s", "cores": ncpu, "kind": "port",
+                                   "sample": f"{m} pairs incl. one final exponentiation; textbook affine Miller loop in portable C "
+                                             "(oracle/pairing_oracle.c), an order of magnitude slower per core than assembly libraries"},
+                  "data": "synthetic"}))
