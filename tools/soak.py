@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Time-boxed randomized parity soak on one MI355X: MSM (G1/G2) and multi-pairing through the C ABI against the C
+oracles, over random sizes, window sizes, scalar formats/distributions, repeated / opposite / infinity bases.
+Prints a progress line every ~20 s and a final JSON summary; exits non-zero on the first mismatch.
+    python tools/soak.py [seconds=300] [seed=1]
+"""
+import json, os, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge
+from oracle import coracle as co, bls12_381 as o
+pkg = ge.load_package()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rnd = random.Random(seed)
+ncpu = min(16, len(os.sched_getaffinity(0)))
+POOL = {"g1": 60000, "g2": 20000}
+pools = {g: co.gen_bases(g, 900 + seed + i, POOL[g], ncpu) for i, g in enumerate(("g1", "g2"))}
+AFF = {"g1": 96, "g2": 192}
+
+
+def neg_point(g, blob):
+    F = o.F1 if g == "g1" else o.F2
+    return o.affine_to_bytes(F, o.aff_neg(F, o.affine_from_bytes(F, blob)))
+
+
+stats = {"msm_g1": 0, "msm_g2": 0, "pairing": 0, "points": 0, "pairs": 0}
+t0 = last = time.time()
+with pkg.Context([0]) as ctx:
+    while time.time() - t0 < budget:
+        r = rnd.random()
+        if r < 0.15:
+            n = rnd.choice([1, 2, 9, 10, 11, 63, 64, 65, rnd.randrange(1, 3000)])
+            i1 = [rnd.randrange(POOL["g1"]) for _ in range(n)]
+            i2 = [rnd.randrange(POOL["g2"]) for _ in range(n)]
+            g1 = bytearray(b"".join(pools["g1"][96 * i:96 * i + 96] for i in i1))
+            g2 = bytearray(b"".join(pools["g2"][192 * i:192 * i + 192] for i in i2))
+            for k in range(n):
+                if rnd.random() < 0.03: g1[96 * k:96 * k + 96] = bytes(96)
+                if rnd.random() < 0.03: g2[192 * k:192 * k + 192] = bytes(192)
+            got = ctx.multi_pairing(bytes(g1), bytes(g2))
+            want = co.multi_pairing(bytes(g1), bytes(g2), ncpu)
+            if got != want:
+                print("PAIRING MISMATCH", seed, n); sys.exit(1)
+            stats["pairing"] += 1; stats["pairs"] += n
+        else:
+            g = "g2" if r < 0.4 else "g1"
+            aff, lim = AFF[g], POOL[g]
+            n = rnd.choice([1, 2, 3, 64, 65, 1000, rnd.randrange(1, 2000), rnd.randrange(1, lim), rnd.randrange(1, lim)])
+            idx = [rnd.randrange(lim) for _ in range(n)]
+            if rnd.random() < 0.4:
+                idx = [idx[rnd.randrange(max(1, n // rnd.choice([2, 4, 50])))] for _ in range(n)]
+            bases = bytearray(b"".join(pools[g][aff * i:aff * (i + 1)] for i in idx))
+            for k in range(min(n, 50)):
+                q = rnd.random()
+                j = rnd.randrange(n)
+                if q < 0.3: bases[aff * j:aff * (j + 1)] = bytes(aff)
+                elif q < 0.6: bases[aff * j:aff * (j + 1)] = neg_point(g, bytes(bases[aff * rnd.randrange(n):][:aff]) or bytes(aff)) if any(bases[aff * j:aff * (j + 1)]) else bytes(aff)
+            kind = rnd.choice(["uniform", "uniform", "bits", "small", "equal", "edge", "fewvalues"])
+            if kind == "uniform": sc = [rnd.randrange(o.R_ORDER) for _ in range(n)]
+            elif kind == "bits": sc = [rnd.randrange(2) for _ in range(n)]
+            elif kind == "small": sc = [rnd.randrange(1 << rnd.choice([8, 16, 40, 64, 128])) for _ in range(n)]
+            elif kind == "equal": sc = [rnd.randrange(o.R_ORDER)] * n
+            elif kind == "fewvalues":
+                vals = [rnd.randrange(o.R_ORDER) for _ in range(rnd.choice([2, 3, 8]))]
+                sc = [rnd.choice(vals) for _ in range(n)]
+            else: sc = [rnd.choice([0, 1, 2, o.R_ORDER - 1, o.R_ORDER - 2, (o.R_ORDER - 1) // 2, 1 << 254]) for _ in range(n)]
+            canon = b"".join(o.fr_to_canon_bytes(x) for x in sc)
+            fmt = rnd.choice([pkg.SCALAR_CANONICAL, pkg.SCALAR_MONTGOMERY])
+            data = canon if fmt == pkg.SCALAR_CANONICAL else co.fr_to_mont(canon)
+            c = rnd.choice([0, 0, 0, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+            ctx.set_window_bits(c)
+            try:
+                got = ctx.msm(g, bytes(bases), data, n, fmt)
+            finally:
+                ctx.set_window_bits(0)
+            want = co.msm(g, bytes(bases), canon, n, 0, ncpu)
+            if co.to_affine(g, got) != co.to_affine(g, want):
+                print("MSM MISMATCH", seed, g, n, kind, c, fmt); sys.exit(1)
+            stats["msm_" + g] += 1; stats["points"] += n
+        if time.time() - last > 20:
+            last = time.time()
+            print("soak", round(last - t0), "s", stats, flush=True)
+stats.update({"seconds": round(time.time() - t0, 1), "seed": seed, "mismatches": 0})
+print(json.dumps(stats))
