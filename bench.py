@@ -113,14 +113,23 @@ def main() -> None:
     cdev = "cuda" if on_gpu else "cpu"
     gather = torch.empty(world * jac_bytes, dtype=torch.uint8, device=cdev) if world > 1 else None
     mine_dev = torch.empty(jac_bytes, dtype=torch.uint8, device=cdev) if world > 1 else None
+    # staging buffers for the exchange: pinned on a GPU box (no pageable-copy synchronisation per step)
+    mine_host = torch.empty(jac_bytes, dtype=torch.uint8) if world > 1 else None
+    gather_host = torch.empty(world * jac_bytes, dtype=torch.uint8) if world > 1 else None
+    if world > 1 and on_gpu:
+        mine_host, gather_host = mine_host.pin_memory(), gather_host.pin_memory()
 
     def step() -> bytes:
         part = ctx.msm_device(g, d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)
         if world == 1:
             return part
-        mine_dev.copy_(torch.frombuffer(bytearray(part), dtype=torch.uint8))
+        mine_host.numpy()[:] = memoryview(part)
+        mine_dev.copy_(mine_host, non_blocking=True)
         dist.all_gather_into_tensor(gather, mine_dev)       # RCCL over xGMI: N x 144 B (latency-bound)
-        allp = gather.cpu().numpy().tobytes()               # one D2H copy of the N partials
+        gather_host.copy_(gather, non_blocking=True)        # one D2H copy of the N partials
+        if on_gpu:
+            torch.cuda.current_stream().synchronize()
+        allp = gather_host.numpy().tobytes()
         # all-reduce under the curve group law: fold in rank order on every rank (identical result everywhere)
         return (pkg.g1_sum if g == "g1" else pkg.g2_sum)([allp[k * jac_bytes:(k + 1) * jac_bytes] for k in range(world)])
 
