@@ -21,8 +21,11 @@
  *
  * Error model: 0 = success, negative = MI_E_* (mi_msm_strerror).  The reference maps every GPU failure to
  * Err(0) (src/g1.rs:628-630) and panics on length mismatch (src/gpu.rs:131); here the caller passes one n.
- * Thread safety: a context serialises concurrent calls internally (rayon callers are safe); result is
- * deterministic (as a curve point) for identical inputs and independent of the number of devices.
+ * Thread safety: every entry point may be called from any thread.  A context runs up to TWO MSM calls at a time (two
+ * lanes per device: stream + scratch each, resident bases shared), so concurrent callers — arkworks calls the trait method
+ * from rayon workers — overlap one call's sort / reduce / host tail with the other's bucket accumulation (+15-19 % points/s
+ * at 2^20); further callers wait.  set_bases, normalize, (de)serialize, pairing and set_window_bits take the context
+ * exclusively.  Results are deterministic (as curve points) for identical inputs and independent of the number of devices.
  */
 #ifndef ARKBLST_AMD_H
 #define ARKBLST_AMD_H

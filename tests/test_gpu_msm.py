@@ -453,3 +453,36 @@ def test_g2_deserialize_golden_and_roundtrip(ctx, co, o):
             assert enc[size * i:size * (i + 1)] == (o.g2_compress(pt) if compressed else o.g2_uncompressed(pt)), i
         dec, st = ctx.deserialize_batch("g2", enc, compressed, True)
         assert st == bytes(n) and dec == raw
+
+
+def test_concurrent_calls_on_one_context(ctx, co, pkg):
+    """a context runs two MSM calls at a time (two lanes sharing the resident bases): results from four host threads,
+    each with its own scalars, interleaved with calls that need the context exclusively"""
+    import threading
+
+    n = 20000
+    bases = co.gen_bases("g1", SEED_B + 90, n, 8)
+    ctx.set_bases("g1", bases, n)
+    scal = [co.gen_scalars(SEED_S + 90 + t, n) for t in range(4)]
+    want = [co.dlog_expected("g1", s, SEED_B + 90, n) for s in scal]
+    errs = []
+
+    def worker(t):
+        try:
+            for it in range(6):
+                got = ctx.msm("g1", None, scal[t], n, pkg.SCALAR_CANONICAL)
+                if co.to_affine("g1", got) != want[t]:
+                    errs.append((t, it, "mismatch"))
+                if t == 3 and it % 2 == 0:   # exclusive entry points in between
+                    jac = ctx.msm("g1", bases[:96 * 50], scal[t][:32 * 50], 50, pkg.SCALAR_CANONICAL)
+                    if ctx.normalize_batch("g1", jac) != co.to_affine("g1", jac):
+                        errs.append((t, it, "normalize"))
+        except Exception as e:   # noqa: BLE001
+            errs.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
