@@ -49,6 +49,7 @@ def load_library():
             getattr(L, f"mi_msm_{g}").argtypes = [vp, vp, vp, sz, u, vp]
             getattr(L, f"mi_msm_{g}_device").argtypes = [vp, vp, sz, u, vp]
             getattr(L, f"mi_{g}_sum").argtypes = [vp, sz, vp]
+            getattr(L, f"mi_msm_{g}_batch").argtypes = [vp, C.POINTER(C.c_char_p), sz, sz, u, vp]
             getattr(L, f"mi_{g}_normalize_batch").argtypes = [vp, vp, sz, vp]
         for g in ("g1", "g2"):
             getattr(L, f"mi_{g}_deserialize_batch").argtypes = [vp, vp, sz, i, i, vp, vp]
@@ -131,6 +132,15 @@ class Context:
         ps, ks = _buf(scalars)
         self._check(getattr(self._L, f"mi_msm_{group}")(self._h, pb, ps, n, scalar_fmt, out), f"mi_msm_{group}")
         return out.raw
+
+    def msm_batch(self, group: str, scalar_vectors, n: int, scalar_fmt: int = SCALAR_CANONICAL):
+        """k MSMs over the resident base set in one call (two in flight on the context's lanes) -> list of Jacobian bytes."""
+        k = len(scalar_vectors)
+        size = G1_JAC if group == "g1" else G2_JAC
+        out = C.create_string_buffer(size * max(k, 1))
+        arr = (C.c_char_p * max(k, 1))(*[bytes(v) for v in scalar_vectors])
+        self._check(getattr(self._L, f"mi_msm_{group}_batch")(self._h, arr, k, n, scalar_fmt, out), f"mi_msm_{group}_batch")
+        return [out.raw[size * j:size * (j + 1)] for j in range(k)]
 
     def msm_device(self, group: str, d_scalars_ptr: int, n: int, scalar_fmt: int = SCALAR_CANONICAL) -> bytes:
         out = C.create_string_buffer(G1_JAC if group == "g1" else G2_JAC)

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <condition_variable>
 #include <chrono>
 #include <cstdarg>
@@ -664,6 +665,33 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
     });
 }
 
+// k MSMs over the resident base set, two in flight (one per lane): the calling thread and one helper pull jobs
+template <class C, class Out>
+int msm_batch_impl(mi_ctx* ctx, const uint8_t* const* scalars, size_t k, size_t n, unsigned fmt, Out* out) {
+    if (!ctx || (k && (!scalars || !out))) return fail(ctx, MI_E_INVALID, "invalid argument");
+    for (size_t j = 0; j < k; j++)
+        if (n && !scalars[j]) return fail(ctx, MI_E_INVALID, "null scalar vector");
+    std::atomic<size_t> next{0};
+    std::atomic<int> first_err{MI_OK};
+    auto worker = [&]() {
+        for (;;) {
+            size_t j = next.fetch_add(1);
+            if (j >= k || first_err.load() != MI_OK) break;
+            int rc = msm_impl<C>(ctx, nullptr, scalars[j], false, n, fmt, &out[j]);
+            int ok = MI_OK;
+            if (rc != MI_OK) first_err.compare_exchange_strong(ok, rc);
+        }
+    };
+    if (k > 1) {
+        std::thread helper(worker);
+        worker();
+        helper.join();
+    } else {
+        worker();
+    }
+    return first_err.load();
+}
+
 // shared driver of the (de)serialisation entry points: `unit` = compressed size in bytes (48 G1, 96 G2)
 template <class KDe>
 int deserialize_impl(mi_ctx* ctx, KDe kernel, size_t unit, const uint8_t* bytes, size_t n, int compressed, int validate, void* out,
@@ -939,6 +967,13 @@ int mi_msm_g1_device(mi_ctx* ctx, const void* d_scalars, size_t n, unsigned scal
 }
 int mi_msm_g2_device(mi_ctx* ctx, const void* d_scalars, size_t n, unsigned scalar_fmt, mi_g2* out) {
     return msm_impl<msmk::G2C>(ctx, nullptr, static_cast<const uint8_t*>(d_scalars), true, n, scalar_fmt, out);
+}
+
+int mi_msm_g1_batch(mi_ctx* ctx, const uint8_t* const* scalars, size_t k, size_t n, unsigned scalar_fmt, mi_g1* out) {
+    return msm_batch_impl<msmk::G1C>(ctx, scalars, k, n, scalar_fmt, out);
+}
+int mi_msm_g2_batch(mi_ctx* ctx, const uint8_t* const* scalars, size_t k, size_t n, unsigned scalar_fmt, mi_g2* out) {
+    return msm_batch_impl<msmk::G2C>(ctx, scalars, k, n, scalar_fmt, out);
 }
 
 int mi_g1_normalize_batch(mi_ctx* ctx, const mi_g1* in, size_t n, mi_g1_affine* out) {

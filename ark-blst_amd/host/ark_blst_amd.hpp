@@ -74,6 +74,19 @@ struct G1Projective {
         return rc == MI_OK ? Result<G1Projective>::Ok(out) : Result<G1Projective>::Err(0);
     }
     // fn msm_bigint(bases, bigints) — the form the reference's GPU impl builds first (src/g1.rs:624-627)
+    // k commitments over the resident SRS in one call (set with mi_msm_g1_set_bases): two run at a time on the context
+    static std::vector<G1Projective> msm_batch(const std::vector<std::vector<Scalar>>& polys) {
+        std::vector<const uint8_t*> ptrs;
+        size_t n = polys.empty() ? 0 : polys[0].size();
+        for (auto& v : polys) {
+            if (v.size() != n) throw std::runtime_error("msm_batch: scalar vectors of different length");
+            ptrs.push_back(reinterpret_cast<const uint8_t*>(v.data()));
+        }
+        std::vector<G1Projective> out(polys.size());
+        int rc = mi_msm_g1_batch(context(), ptrs.data(), ptrs.size(), n, MI_SCALAR_MONTGOMERY, reinterpret_cast<mi_g1*>(out.data()));
+        if (rc != MI_OK) throw std::runtime_error(std::string("msm_batch: ") + mi_msm_last_error(context()));
+        return out;
+    }
     static Result<G1Projective> msm_bigint(const std::vector<G1Affine>& bases, const std::vector<BigInteger256>& bigints) {
         if (bases.size() != bigints.size()) return Result<G1Projective>::Err(std::min(bases.size(), bigints.size()));
         G1Projective out;

@@ -108,6 +108,13 @@ int mi_msm_g2(mi_ctx *ctx, const mi_g2_affine *bases, const uint8_t *scalars, si
 int mi_msm_g1_device(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g1 *out);
 int mi_msm_g2_device(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g2 *out);
 
+/* k MSMs over the resident base set in one call: out[j] = sum_i scalars[j][i] * B_i, i < n (host scalar vectors, all in
+ * scalar_fmt).  Two run at a time on the context's lanes, so the sort / reduce / host tail of one overlap the bucket
+ * accumulation of the other — the shape of a KZG prover committing to many polynomials over one SRS (the reference would
+ * call msm once per polynomial and re-upload the bases each time, src/gpu.rs:149).  Stops at the first error. */
+int mi_msm_g1_batch(mi_ctx *ctx, const uint8_t *const *scalars, size_t k, size_t n, unsigned scalar_fmt, mi_g1 *out);
+int mi_msm_g2_batch(mi_ctx *ctx, const uint8_t *const *scalars, size_t k, size_t n, unsigned scalar_fmt, mi_g2 *out);
+
 /* Jacobian -> affine for n points with one field inversion (product tree on the GPU).  Replaces
  * CurveGroup::normalize_batch = blstrs::G{1,2}Projective::batch_normalize (src/g1.rs:537-543, src/g2.rs:517-523), the step
  * arkworks provers run right before an MSM (ScalarMul::batch_convert_to_mul_base, src/g1.rs:597-599).  Infinity inputs

@@ -486,3 +486,21 @@ def test_concurrent_calls_on_one_context(ctx, co, pkg):
     for x in th:
         x.join()
     assert not errs, errs
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_msm_batch_over_resident_bases(ctx, co, pkg, group):
+    """mi_msm_g{1,2}_batch: k scalar vectors over one resident base set, two in flight; every result against the closed form"""
+    n = 6000 if group == "g1" else 2500
+    bases = co.gen_bases(group, SEED_B + 95, n, 8)
+    ctx.set_bases(group, bases, n)
+    vecs = [co.gen_scalars(SEED_S + 95 + j, n) for j in range(5)]
+    got = ctx.msm_batch(group, vecs, n, pkg.SCALAR_CANONICAL)
+    assert len(got) == 5
+    for j in range(5):
+        assert co.to_affine(group, got[j]) == co.dlog_expected(group, vecs[j], SEED_B + 95, n)
+    assert ctx.msm_batch(group, [], n) == []
+    one = ctx.msm_batch(group, vecs[:1], n, pkg.SCALAR_CANONICAL)
+    assert co.to_affine(group, one[0]) == co.to_affine(group, got[0])
+    mont = ctx.msm_batch(group, [co.fr_to_mont(v) for v in vecs[:2]], n, pkg.SCALAR_MONTGOMERY)
+    assert [co.to_affine(group, x) for x in mont] == [co.to_affine(group, x) for x in got[:2]]
