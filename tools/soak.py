@@ -29,7 +29,21 @@ t0 = last = time.time()
 with pkg.Context([0]) as ctx:
     while time.time() - t0 < budget:
         r = rnd.random()
-        if r < 0.15:
+        if r < 0.04:   # batch entry point over a resident base set (two MSMs in flight on the context's lanes)
+            g = rnd.choice(["g1", "g1", "g2"])
+            aff, lim = AFF[g], POOL[g]
+            n = rnd.randrange(1, lim)
+            start = rnd.randrange(0, lim - n + 1)
+            bases = pools[g][aff * start:aff * (start + n)]
+            ctx.set_bases(g, bases, n)
+            k = rnd.randrange(1, 5)
+            vecs = [b"".join(o.fr_to_canon_bytes(rnd.randrange(o.R_ORDER)) for _ in range(n)) for _ in range(k)]
+            got = ctx.msm_batch(g, vecs, n, pkg.SCALAR_CANONICAL)
+            for v, x in zip(vecs, got):
+                if co.to_affine(g, x) != co.to_affine(g, co.msm(g, bases, v, n, 0, ncpu)):
+                    print("BATCH MISMATCH", seed, g, n, k); sys.exit(1)
+            stats["batch"] = stats.get("batch", 0) + 1; stats["points"] += n * k
+        elif r < 0.15:
             n = rnd.choice([1, 2, 9, 10, 11, 63, 64, 65, rnd.randrange(1, 3000)])
             i1 = [rnd.randrange(POOL["g1"]) for _ in range(n)]
             i2 = [rnd.randrange(POOL["g2"]) for _ in range(n)]
