@@ -414,8 +414,15 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
         hipLaunchKernelGGL(msmk::k_merge<C>, dim3((nlist + 255) / 256), dim3(256), 0, s, (uint32_t*)d.partial.p,
                            (const uint32_t*)d.item_bucket.p, (const uint32_t*)d.woff.p, (const uint32_t*)d.merge_list.p, nlist, dd);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 4], s));
-    hipLaunchKernelGGL(msmk::k_reduce<C>, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
-                       (const uint32_t*)d.woff.p, (uint32_t*)d.pairs.p, pl.logL);
+    static const bool g2_one_lane = getenv("MI_G2_REDUCE_ONE_LANE") != nullptr;   // A/B hook: the generic kernel for G2
+    if (std::is_same<C, msmk::G2C>::value && !g2_one_lane) {
+        // two lanes per logical lane: a chunk of 64 << logL buckets = 32 logical lanes x 2^(logL+1) buckets
+        hipLaunchKernelGGL(msmk::k_reduce_g2_coop, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
+                           (const uint32_t*)d.woff.p, (uint32_t*)d.pairs.p, pl.logL + 1);
+    } else {
+        hipLaunchKernelGGL(msmk::k_reduce<C>, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
+                           (const uint32_t*)d.woff.p, (uint32_t*)d.pairs.p, pl.logL);
+    }
     HIP_TRY(hipEventRecord(d.ev[ev0 + 5], s));
     HIP_TRY(hipMemcpyAsync(d.h_pairs, d.pairs.p, pl.nchunks * pair_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(d.ev[ev0 + 6], s));
