@@ -51,8 +51,13 @@ struct Plan {
     uint64_t nbuckets, nchunks;
 };
 
-// Window size: minimise (mixed adds in accumulate) + (full adds in reduce, ~1.4x the cost each), subject to
-// enough buckets to fill 256 CUs.  Plays the role of calc_window_size (/root/reference/src/gpu.rs:218-223).
+// Window size c by a time model of the pipeline on one MI355X (microseconds; constants measured on G1):
+//   accumulate  max(throughput: N W mixed additions at 7.1e9 /s,  latency: one lane walks an item of T entries at 11 us each)
+//   merge       one ~60 us launch per binary-tree level when the short top window overfills its buckets
+//   reduce      a latency chain of 2L + 13 + log2 L complete additions of 17 us per wave, one wave per SIMD per round
+//   sort        N W entries at 4.1e10 /s;  schedule ~ buckets / 1e4;  host tail ~ 100 + 0.16 per chunk pair
+// Plays the role of calc_window_size (/root/reference/src/gpu.rs:218-223).  G2 costs ~3x more in accumulate and reduce
+// alike, which leaves the optimum where it is.
 Plan make_plan(size_t n, unsigned forced_c) {
     Plan best{};
     double best_cost = 1e300;
@@ -64,34 +69,40 @@ Plan make_plan(size_t n, unsigned forced_c) {
         // window must fit the LDS counter array
         uint32_t lo_bits = std::min<uint32_t>(std::min<uint32_t>(8, c - 1), 31 - idx_bits);
         if (((1u << (c - 1)) >> lo_bits) > msmk::SORT_MAX_COUNTERS) continue;
-        uint32_t nwin = (256 + c - 1) / c;
-        if ((uint64_t)n * nwin >= (1ull << 32)) continue;   // entry offsets are 32-bit
-        double nb = (double)(1u << (c - 1));
-        double cost = (double)n * nwin + 6.0 * nb * nwin;
-        // The top window holds only 255 - c (nwin - 1) significant bits, so its n entries share 2^top_bits buckets;
-        // buckets beyond T entries are split and merged by a binary tree: ~0.1 ms (~6e5 addition-times) per level.
-        int top_bits = std::max(0, std::min<int>(255 - (int)c * ((int)nwin - 1), (int)c - 1));
-        double per_bucket = (double)n / (double)(1u << top_bits), mean = std::max(1.0, (double)n / nb);
-        for (double x = per_bucket; x > 2.0 * mean; x *= 0.5) cost += 6e5;
+        Plan p{};
+        p.c = c;
+        p.lo_bits = lo_bits;
+        p.nwin = (256 + c - 1) / c;
+        if ((uint64_t)n * p.nwin >= (1ull << 32)) continue;   // entry offsets are 32-bit
+        p.nb = 1u << (c - 1);
+        p.nbuckets = (uint64_t)p.nb * p.nwin;
+        // reduce geometry: the smallest L = 2^logL buckets per lane that still gives every wave its own SIMD (<= 1024
+        // chunks of 64 L buckets), capped at L = 64: at 2^20 points (c = 16) that is L = 8
+        p.logL = 0;
+        while (p.logL < 6 && p.logL < c - 7 && (p.nbuckets >> (6 + p.logL)) > 1024) p.logL++;
+        p.chunks_per_win = p.nb >> (6 + p.logL);
+        p.nchunks = (uint64_t)p.chunks_per_win * p.nwin;
+        // work-item size: twice the mean bucket load (uniform scalars then never split), at least 32 entries
+        double mean = (double)n / p.nb;
+        p.logT = 5;
+        while ((double)(1u << p.logT) < 2.0 * mean && p.logT < 20) p.logT++;
+        const double T = (double)(1u << p.logT), entries = (double)n * p.nwin;
+        // The top window holds only 255 - c (nwin - 1) significant bits: its n entries share 2^top_bits buckets, and
+        // buckets beyond T entries are split and merged by a binary tree
+        int top_bits = std::max(0, std::min<int>(255 - (int)c * ((int)p.nwin - 1), (int)c - 1));
+        double per_bucket = (double)n / (double)(1u << top_bits);
+        int merge_levels = 0;
+        for (double x = per_bucket; x > T; x *= 0.5) merge_levels++;
+        const double item_len = std::min(T, std::max(mean, std::min(per_bucket, T)));   // entries a lane walks serially
+        const double rounds = (double)((p.nchunks + 1023) / 1024);
+        double cost = std::max(entries / 7100.0, item_len * 11.0) + merge_levels * 60.0 +
+                      rounds * (2.0 * (1u << p.logL) + 13.0 + p.logL) * 17.0 + entries / 41000.0 + (double)p.nbuckets / 1e4 + 100.0 +
+                      0.16 * (double)p.nchunks;
         if (cost < best_cost) {
             best_cost = cost;
-            best.c = c;
-            best.nwin = nwin;
-            best.lo_bits = lo_bits;
+            best = p;
         }
     }
-    best.nb = 1u << (best.c - 1);
-    // 8 buckets per lane, one reduce wave per SIMD: measured best of L in {2,4,8} x {1,2} waves/SIMD (tools/ab_reduce.sh)
-    best.logL = std::min<uint32_t>(3, best.c - 7);
-    // many buckets (large n): more buckets per lane keep the chunk count (reduce waves, host pairs) near 4096
-    while (best.logL < 6 && best.logL < best.c - 7 && (((uint64_t)(1u << (best.c - 1)) * best.nwin) >> (6 + best.logL)) > 4096) best.logL++;
-    best.chunks_per_win = best.nb >> (6 + best.logL);
-    best.nbuckets = (uint64_t)best.nb * best.nwin;
-    best.nchunks = (uint64_t)best.chunks_per_win * best.nwin;
-    // work-item size: twice the mean bucket load (uniform scalars then never split), at least 32 entries
-    double mean = (double)n / best.nb;
-    best.logT = 5;
-    while ((double)(1u << best.logT) < 2.0 * mean && best.logT < 20) best.logT++;
     return best;
 }
 
