@@ -844,25 +844,33 @@ HT::E12 device_miller(DevState& d, const mi_g1_affine* p, const mi_g2_affine* q,
         HIP_TRY(hipMemcpyAsync(dq.p, q, n * sizeof(mi_g2_affine), hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(d.ev[1], s));
         static const bool single_lane = getenv("MI_PAIRING_SINGLE_LANE") != nullptr;   // the first kernel, kept for cross-checks
+        uint32_t share = 1;
+        size_t nvals = 0;   // Fp12 values the Miller kernels leave in lvl[0]
         if (single_lane) {
             hipLaunchKernelGGL(msmk::k_miller_loop, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, s, (const uint32_t*)dp.p, (const uint32_t*)dq.p,
                                (uint32_t)n, (uint32_t*)lvl[0].p);
         } else {
-            // line coefficients of a batch of pairs (26 KB per pair), then six lanes per pair fold them into f
+            // line coefficients of a batch of pairs (26 KB per pair), then six lanes per accumulator fold them into f.
+            // share = pairs per accumulator (one squaring per step for all of them): as many as still leave ~1600 waves
             static const size_t batch_cap = getenv("MI_PAIRING_BATCH") ? std::max(1, atoi(getenv("MI_PAIRING_BATCH"))) : (1u << 17);   // test hook
             const size_t batch = std::min<size_t>(n, batch_cap);
+            share = (uint32_t)std::min<size_t>(8, std::max<size_t>(1, n >> 14));
+            if (const char* e = getenv("MI_PAIRING_SHARE")) share = (uint32_t)std::max(1, atoi(e));   // test hook
+            while (share > 1 && batch % share) share >>= 1;   // accumulators must not straddle line batches
             dlines.ensure(batch * msmk::MILLER_LINES * 3 * 32 * 4);
             for (size_t lo = 0; lo < n; lo += batch) {
-                uint32_t m = (uint32_t)std::min(batch, n - lo);
-                hipLaunchKernelGGL(msmk::k_miller_lines2, dim3((2 * m + 63) / 64), dim3(64), 0, s,
+                uint32_t mm = (uint32_t)std::min(batch, n - lo);
+                uint32_t groups = (mm + share - 1) / share;
+                hipLaunchKernelGGL(msmk::k_miller_lines2, dim3((2 * mm + 63) / 64), dim3(64), 0, s,
                                    (const uint32_t*)dp.p + lo * msmk::Geo<msmk::G1C>::RAW_AFF, (const uint32_t*)dq.p + lo * msmk::Geo<msmk::G2C>::RAW_AFF,
-                                   m, (uint32_t*)dlines.p);
-                hipLaunchKernelGGL(msmk::k_miller_accumulate, dim3((m + msmk::MILLER_GROUPS - 1) / msmk::MILLER_GROUPS), dim3(64), 0, s,
-                                   (const uint32_t*)dlines.p, m, (uint32_t*)lvl[0].p + lo * msmk::FP12_WORDS);
+                                   mm, (uint32_t*)dlines.p);
+                hipLaunchKernelGGL(msmk::k_miller_accumulate, dim3((groups + msmk::MILLER_GROUPS - 1) / msmk::MILLER_GROUPS), dim3(64), 0, s,
+                                   (const uint32_t*)dlines.p, mm, share, (uint32_t*)lvl[0].p + nvals * msmk::FP12_WORDS);
+                nvals += groups;
             }
         }
         HIP_TRY(hipEventRecord(d.ev[2], s));
-        size_t m = n;
+        size_t m = single_lane ? n : nvals;
         int cur = 0;
         while (m > 4) {   // a host Fp12 product costs ~13 us, a tree level ~50 us
             size_t g = (m + msmk::FP12_TREE_K - 1) / msmk::FP12_TREE_K;

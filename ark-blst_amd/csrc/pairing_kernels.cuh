@@ -69,7 +69,8 @@ __global__ void __launch_bounds__(64, 1) k_miller_loop(const uint32_t* __restric
 //                        accumulates its six Fp2 products into two sets of 64-bit columns and reduces ONCE per
 //                        component (12 products per reduction).  No scratch, ~200 registers, two waves per SIMD.
 //                        A line is sparse (w^0, w^2, w^3): three terms.
-// Ten pairs per wave (lanes 60..63 idle).  A pair with P or Q at infinity gets the lines (1, 0, 0): f stays 1.
+// Ten accumulators per wave (lanes 60..63 idle), each folding m consecutive pairs with ONE squaring per step.  A pair with P
+// or Q at infinity gets the lines (1, 0, 0): f stays 1.
 constexpr int MILLER_LINES = 68;          // 63 doublings + 5 additions for |z| = 0xd201000000010000
 constexpr int MILLER_GROUPS = 10;         // pairs per wave in k_miller_accumulate
 constexpr int LDS_COEFF_WORDS = 36;       // one Fp2 coefficient in LDS: 2 x 16 words + 4 words of padding (bank spread)
@@ -153,13 +154,17 @@ __device__ __forceinline__ void fp2_acc_term(uint64_t (&c0)[2 * fp28::NL], uint6
     fp_acc(c1, a1, g.c0);
 }
 
-__global__ void __launch_bounds__(64, 2) k_miller_accumulate(const uint32_t* __restrict__ lines, uint32_t n, uint32_t* __restrict__ out) {
+// `m` consecutive pairs share one accumulator: f <- f^2 * l_1 * ... * l_m per step (the multi-Miller-loop trick: one squaring
+// for m pairs, as blst's miller_loop_n does); out[g] = product of the Miller values of pairs [g m, g m + m).
+__global__ void __launch_bounds__(64, 2) k_miller_accumulate(const uint32_t* __restrict__ lines, uint32_t n, uint32_t m,
+                                                             uint32_t* __restrict__ out) {
     __shared__ uint32_t fs[(MILLER_GROUPS + 1) * 6 * LDS_COEFF_WORDS];   // + one dummy group for the idle lanes
     const uint32_t lane = threadIdx.x;
     const uint32_t grp = lane / 6, k = lane - grp * 6;                   // lanes 60..63: group 10 (dummy)
-    const uint32_t pair = blockIdx.x * MILLER_GROUPS + grp;
-    const bool valid = grp < MILLER_GROUPS && pair < n;
-    const uint32_t pair_c = valid ? pair : n - 1;                        // idle lanes read a real pair's lines, write nothing
+    const uint32_t ngroups = (n + m - 1) / m;
+    const uint32_t g_idx = blockIdx.x * MILLER_GROUPS + grp;
+    const bool valid = grp < MILLER_GROUPS && g_idx < ngroups;
+    const uint32_t first = (valid ? g_idx : ngroups - 1) * m;            // idle lanes shadow a real group, write nothing
     uint32_t* fg = fs + grp * 6 * LDS_COEFF_WORDS;
     ec::Fp2 own = k == 0 ? ec::Fp2Ops::one() : ec::Fp2Ops::zero();
     lds_store_fp2(fg + k * LDS_COEFF_WORDS, own);
@@ -172,27 +177,31 @@ __global__ void __launch_bounds__(64, 2) k_miller_accumulate(const uint32_t* __r
         if (i <= j) sq_tab |= i << (3 * sq_cnt++);
     }
     // h_k = sum over the three non-zero line coefficients at w^0, w^2, w^3
-    auto mul_line = [&]() {
-        const uint32_t* lp = lines + ((size_t)line * n + pair_c) * 3 * 32;
-        line++;
-        uint64_t c0[2 * fp28::NL], c1[2 * fp28::NL];
-#pragma unroll
-        for (int t = 0; t < 2 * fp28::NL; t++) { c0[t] = 0; c1[t] = 0; }
+    auto mul_line = [&]() {   // f <- f * (line `line` of pair first + q) for q < m; a pair beyond n multiplies by one
 #pragma unroll 1
-        for (int t = 0; t < 3; t++) {
-            int pos = t == 0 ? 0 : t + 1;                                // 0, 2, 3
-            int j = (int)k - pos;
-            bool wrapped = j < 0;
-            if (wrapped) j += 6;
-            ec::Fp2 g;
-            ElemIO<ec::Fp2>::load(g, lp + 32 * t);
-            fp2_acc_term(c0, c1, lds_load_fp2(fg + j * LDS_COEFF_WORDS), wrapped, g);
+        for (uint32_t q = 0; q < m; q++) {
+            const bool live = first + q < n;
+            const uint32_t* lp = lines + ((size_t)line * n + (live ? first + q : n - 1)) * 3 * 32;
+            uint64_t c0[2 * fp28::NL], c1[2 * fp28::NL];
+#pragma unroll
+            for (int t = 0; t < 2 * fp28::NL; t++) { c0[t] = 0; c1[t] = 0; }
+#pragma unroll 1
+            for (int t = 0; t < 3; t++) {
+                int pos = t == 0 ? 0 : t + 1;                            // 0, 2, 3
+                int j = (int)k - pos;
+                bool wrapped = j < 0;
+                if (wrapped) j += 6;
+                ec::Fp2 g;
+                ElemIO<ec::Fp2>::load(g, lp + 32 * t);
+                fp2_acc_term(c0, c1, lds_load_fp2(fg + j * LDS_COEFF_WORDS), wrapped, g);
+            }
+            ec::Fp2 r{fp28::fp_mont_reduce(c0), fp28::fp_mont_reduce(c1)};
+            own = ec::Fp2Ops::select(live, own, r);
+            __syncthreads();                                             // every lane has read the old f
+            lds_store_fp2(fg + k * LDS_COEFF_WORDS, own);
+            __syncthreads();
         }
-        own.c0 = fp28::fp_mont_reduce(c0);
-        own.c1 = fp28::fp_mont_reduce(c1);
-        __syncthreads();                                                 // every lane has read the old f
-        lds_store_fp2(fg + k * LDS_COEFF_WORDS, own);
-        __syncthreads();
+        line++;
     };
 #pragma unroll 1
     for (int b = 62; b >= 0; b--) {
@@ -222,7 +231,7 @@ __global__ void __launch_bounds__(64, 2) k_miller_accumulate(const uint32_t* __r
     }
     // z < 0: conjugate (w -> -w: odd coefficients negated); flat w^k -> tower slot c_{k&1}.c_{k>>1}
     if (k & 1) own = pairing::PF2::norm2(ec::Fp2Ops::neg<4>(own));       // exact again: the tree takes coefficients < 2p
-    if (valid) ElemIO<ec::Fp2>::store(out + (size_t)pair * FP12_WORDS + ((k & 1) * 3 + (k >> 1)) * 32, own);
+    if (valid) ElemIO<ec::Fp2>::store(out + (size_t)g_idx * FP12_WORDS + ((k & 1) * 3 + (k >> 1)) * 32, own);
 }
 
 // One level of the multiplication tree, six lanes per output: out[g] = prod in[g*K .. g*K+K).  Same scheme as

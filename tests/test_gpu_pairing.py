@@ -147,3 +147,23 @@ def test_line_buffer_batches(co):
         assert r.returncode == 0, r.stderr
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1] and len(outs[0]) == 1152
+
+
+@pytest.mark.parametrize("share", [2, 3, 8])
+def test_shared_squaring_accumulators(ctx, co, share):
+    """m pairs per accumulator (one Fp12 squaring per Miller step for all of them; production picks m = n / 2^14, capped
+    at 8): forced through the test hook on sizes that do and do not divide by m, with infinity pairs, against the C oracle"""
+    import os
+
+    for n in (1, share, share + 1, 997):
+        g1 = bytearray(co.gen_bases("g1", SEED_P + 11, n, 8))
+        g2 = bytearray(co.gen_bases("g2", SEED_Q + 11, n, 8))
+        if n > 10:
+            g1[96 * 5:96 * 6] = bytes(96)
+            g2[192 * (n - 1):192 * n] = bytes(192)
+        os.environ["MI_PAIRING_SHARE"] = str(share)
+        try:
+            got = ctx.multi_pairing(bytes(g1), bytes(g2))
+        finally:
+            del os.environ["MI_PAIRING_SHARE"]
+        assert got == co.multi_pairing(bytes(g1), bytes(g2), 8), (share, n)
