@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(64, 2) k_miller_lines2(const uint32_t* __restr
     auto put = [&](int line, const Fp& c0, const Fp& c1, const Fp& c4) {
         if (!valid) return;
         uint32_t* o = lines + ((size_t)line * n + pair) * 3 * 32 + 16 * h;
-        store_fp16(o, fp28::fp_select(inf, CoopF2::norm2(c0), id));
+        store_fp16(o, fp28::fp_select(inf, c0, id));              // c0 < 6p in N-form: the accumulate kernel allows for it
         store_fp16(o + 32, fp28::fp_select(inf, c1, fp28::fp_zero()));
         store_fp16(o + 64, fp28::fp_select(inf, c4, fp28::fp_zero()));
     };
@@ -143,11 +143,14 @@ __device__ __forceinline__ void lds_store_fp2(uint32_t* p, const ec::Fp2& a) {
 // into the two column sets.  Bounds: xi a <= (12p, 8p) in N-form, 4p - g1 <= 4p: a term adds <= 56 p^2 to a component,
 // at most six terms per reduction (limit 2520 p^2); <= 168 column terms of < 2^56.01 plus the reduction's 2^59.9 stay
 // below 2^64.
+// GK = 4: g exact (< 2p); GK = 8: g <= 6p in N-form (a line's c0 as the line kernel leaves it): a term then adds
+// <= 12 * 6 + 8 * 8 = 136 p^2, three line terms per reduction.
+template <int GK = 4>
 __device__ __forceinline__ void fp2_acc_term(uint64_t (&c0)[2 * fp28::NL], uint64_t (&c1)[2 * fp28::NL], const ec::Fp2& a, bool wrapped,
                                              const ec::Fp2& g) {
     Fp xa0 = fp28::fp_sub<8>(a.c0, a.c1), xa1 = fp28::fp_add(a.c0, a.c1);
     Fp a0 = fp28::fp_select(wrapped, a.c0, xa0), a1 = fp28::fp_select(wrapped, a.c1, xa1);
-    Fp ng1 = fp28::fp_neg<4>(g.c1);
+    Fp ng1 = fp28::fp_neg<GK>(g.c1);
     fp_acc(c0, a0, g.c0);
     fp_acc(c0, a1, ng1);
     fp_acc(c1, a0, g.c1);
@@ -193,7 +196,7 @@ __global__ void __launch_bounds__(64, 2) k_miller_accumulate(const uint32_t* __r
                 if (wrapped) j += 6;
                 ec::Fp2 g;
                 ElemIO<ec::Fp2>::load(g, lp + 32 * t);
-                fp2_acc_term(c0, c1, lds_load_fp2(fg + j * LDS_COEFF_WORDS), wrapped, g);
+                fp2_acc_term<8>(c0, c1, lds_load_fp2(fg + j * LDS_COEFF_WORDS), wrapped, g);
             }
             ec::Fp2 r{fp28::fp_mont_reduce(c0), fp28::fp_mont_reduce(c1)};
             own = ec::Fp2Ops::select(live, own, r);
