@@ -207,18 +207,19 @@ struct Tower {
     // Renes-Costello-Batina 2016, Alg. 9 (a = 0), which shares Y^2, Z^2, b3 Z^2 and Y Z with the line: 3 S + 7 M.
     // T <= 6p in, T < 4p out.
     static FP_HD void line_dbl(PT& T, const G1Pt& p, E2& c0, E2& c1, E2& c4) {
+        // ordered so that values die early (the two-lane line kernel inlines this with the multiplier: register pressure)
         E2 t0 = F2::sqr(T.y);                                                    // Y^2
         E2 t1 = F2::mul(T.y, T.z);                                               // Y Z
         E2 t2 = F2::mul_b3(F2::sqr(T.z));                                        // b3 Z^2 = 3b' Z^2
         c0 = F2::template sub<4>(t0, t2);                                        // Y^2 - 3b' Z^2          < 6p
-        c1 = F2::mul_fp(F2::mul3(F2::sqr(T.x)), p.nx);                           // -3 X^2 xP
         c4 = F2::mul_fp(F2::dbl(t1), p.y);                                       // 2 Y Z yP
-        E2 z8 = F2::dbl(F2::dbl(F2::dbl(t0)));                                   // 8 Y^2                  < 16p
-        E2 x3 = F2::mul(t2, z8);
-        E2 y3 = F2::add(t0, t2);                                                 // Y^2 + b3 Z^2           < 4p
+        c1 = F2::mul_fp(F2::mul3(F2::sqr(T.x)), p.nx);                           // -3 X^2 xP
         E2 xy = F2::mul(T.x, T.y);
+        E2 z8 = F2::dbl(F2::dbl(F2::dbl(t0)));                                   // 8 Y^2                  < 16p
         T.z = F2::mul(t1, z8);                                                   // 8 Y^3 Z
+        E2 x3 = F2::mul(t2, z8);
         E2 d = F2::template sub<8>(t0, F2::add(F2::add(t2, t2), t2));            // Y^2 - 3 b3 Z^2         < 10p
+        E2 y3 = F2::add(t0, t2);                                                 // Y^2 + b3 Z^2           < 4p
         T.y = F2::add(x3, F2::mul(d, y3));
         T.x = F2::dbl(F2::mul(d, xy));
     }
