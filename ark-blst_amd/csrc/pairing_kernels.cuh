@@ -1,10 +1,13 @@
 // GPU side of `Bls12::multi_miller_loop` (/root/reference/src/pairing.rs:49-74): the reference walks the pairs one
 // after the other on one CPU thread (blstrs::miller_loop_lines, then blst_fp12_mul into a running product); the pairs
-// are independent, so here every pair is one lane and the running product is a multiplication tree.
-//   k_miller_loop   one lane per (P, Q): f_{z,Q}(P) by the generic loop of pairing.cuh; a pair with P or Q at infinity
-//                   contributes 1 (pairing.rs:58-60)
-//   k_fp12_prod     one tree level: out[g] = prod in[g*K .. g*K+K)
-//   k_fp12_to_raw   internal form -> the reference's blst_fp12 (12 x blst_fp, Montgomery R = 2^384)
+// are independent, so here the work is spread by data shape:
+//   k_miller_lines2      two lanes per pair: the G2 point walk in Fp2 and the 68 evaluated lines (default path)
+//   k_miller_accumulate  six lanes per accumulator: f <- f^2 * l_1 ... l_m per step for m pairs, coefficients in LDS
+//   k_fp12_prod          one multiplication-tree level, six lanes per output: out[g] = prod in[g*K .. g*K+K)
+//   k_fp12_to_raw        internal form -> the reference's blst_fp12 (12 x blst_fp, Montgomery R = 2^384)
+//   k_miller_loop        the first version, one lane per pair for the whole loop (generic pairing.cuh code; 4 KB of
+//                        scratch per lane) — kept behind MI_PAIRING_SINGLE_LANE=1 as a second implementation to cross-check
+// A pair with P or Q at infinity contributes 1 (pairing.rs:58-60).
 // Device form of an Fp12: 12 slots of 16 words (14 limbs used), order c0.c0.c0, c0.c0.c1, c0.c1.c0, ... as blst_fp12.
 #pragma once
 #include "msm_kernels.cuh"
