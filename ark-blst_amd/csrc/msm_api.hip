@@ -277,8 +277,23 @@ J host_fold(mi_ctx* ctx, const J* pairs, const Plan& pl) {
     std::unique_lock<std::mutex> pool_lock(ctx->pool_mu, std::defer_lock);
     const bool use_pool = work >= 128 && ctx->pool && ctx->devs.size() == 1;
     if (use_pool) pool_lock.lock();   // the other lane's fold (~0.3 ms) may be running
+    // multi-device context: every device thread folds its own pairs; it may take a few helper threads of its own (the
+    // shared pool runs one loop at a time and would serialise the devices)
+    const unsigned helpers = !use_pool && work >= 512 && ctx->devs.size() > 1
+                                 ? std::min<unsigned>(4, std::max<unsigned>(1, std::thread::hardware_concurrency() / (unsigned)ctx->devs.size()))
+                                 : 1;
     if (use_pool) {
         ctx->pool->parallel_for(pl.nwin * parts, do_part);
+    } else if (helpers > 1) {
+        std::atomic<uint32_t> next{0};
+        const uint32_t units = pl.nwin * parts;
+        auto loop = [&]() {
+            for (uint32_t u = next.fetch_add(1); u < units; u = next.fetch_add(1)) do_part(u);
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < helpers; t++) th.emplace_back(loop);
+        loop();
+        for (auto& t : th) t.join();
     } else {
         for (uint32_t u = 0; u < pl.nwin * parts; u++) do_part(u);
     }
