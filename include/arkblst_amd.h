@@ -137,8 +137,9 @@ int mi_g2_serialize_batch(mi_ctx *ctx, const mi_g2_affine *points, size_t n, int
 
 /* Pairing (BASELINE config #5).  Replaces <Bls12 as Pairing>::multi_miller_loop (src/pairing.rs:49-74:
  * a serial loop of blstrs::miller_loop_lines + blst_fp12_mul on one CPU thread) and final_exponentiation
- * (src/pairing.rs:76-80).  One GPU lane per pair, then a multiplication tree; pairs are sharded over the context's
- * devices.  A pair with p[i] or q[i] at infinity (all-zero) contributes 1, as pairing.rs:58-60.  n == 0 gives 1.
+ * (src/pairing.rs:76-80).  On the GPU: two lanes per pair compute the 68 line evaluations, six lanes per accumulator
+ * fold them into f (several pairs share one accumulator and its squarings), then a multiplication tree; pairs are sharded
+ * over the context's devices.  A pair with p[i] or q[i] at infinity (all-zero) contributes 1, as pairing.rs:58-60.  n == 0 gives 1.
  * q[i] are plain G2 affine points: the reference's G2Prepared (68 precomputed line coefficients, 19.6 KB per point) is
  * not materialised, lines are computed on the fly.  The Miller value agrees with blst's up to factors from proper
  * subfields, which the final exponentiation removes; compare Gt values, i.e. after mi_final_exponentiation.
