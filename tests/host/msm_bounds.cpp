@@ -1,0 +1,110 @@
+// Machine check of the lazy-reduction bookkeeping of the MSM formulas in ark-blst_amd/csrc/ec.cuh ON THE REAL CODE:
+// xyzz_madd (the accumulate hot loop, including its carry-free "lazy" linear operations), xyzz_to_proj and the
+// complete proj_add are instantiated with a field class that carries, instead of a value, a VALUE bound (multiples of
+// p) and a LIMB bound (largest 32-bit limb), and enforces the contracts of fp28.cuh at every call:
+//   product (one reduction)   sum a_i b_i < 2^392 / p (2520 p^2);  14 * sum la_i lb_i < 2^64 - 2^60;   output exact, < 2p
+//   squaring                  as product, and limb < 2^31 (the doubled operand)
+//   fp_add / fp_sub<K>        limb sums < 2^32; subtrahend limbs <= 2^28 + 64 and value <= (K-1) p;   output N-form
+//   lazy add / sub            the same without the carry pass: limbs add up
+//   fp_sub8_lazy_wide         subtrahend limbs <= 3 * 2^28 + 64, value <= 7p
+// The formulas are iterated to a fixed point from the kernel's initial state.  Complements tools/bounds_check.py (a
+// transcript of the formulas); test helper only — not part of the shipped library.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include "../../ark-blst_amd/csrc/ec.cuh"
+
+static const double LIMIT = 2520.0, TWO28 = 268435456.0, TWO32 = 4294967296.0;
+static const double EXACT = TWO28 - 1, NFORM = TWO28 + 15, SPREAD_LO = TWO28 + 64, SPREAD_HI = 2 * TWO28 + 68;
+static const double COLMAX = 18446744073709551616.0 - 1152921504606846976.0;   // 2^64 - 2^60
+static double g_max_prod = 0, g_max_col = 0, g_max_limb = 0;
+
+static void fail(const char* what, double v, double lim) {
+    fprintf(stderr, "BOUND VIOLATION: %s: %.6g > %.6g\n", what, v, lim);
+    exit(1);
+}
+struct BFp {
+    double v, l;   // value bound in units of p, limb bound
+};
+static BFp reduce(double prod, double col) {
+    if (prod >= LIMIT) fail("product value", prod, LIMIT);
+    if (14.0 * col >= COLMAX) fail("column sum", 14.0 * col, COLMAX);
+    g_max_prod = std::max(g_max_prod, prod);
+    g_max_col = std::max(g_max_col, 14.0 * col);
+    return {2.0, EXACT};
+}
+static double limb(double l) {
+    if (l >= TWO32) fail("limb overflow", l, TWO32);
+    g_max_limb = std::max(g_max_limb, l);
+    return l;
+}
+static void need_subtrahend(const BFp& b, int K, double lo) {
+    if (b.v > K - 1) fail("subtrahend value", b.v, K - 1);
+    if (b.l > lo) fail("subtrahend limb", b.l, lo);
+}
+
+struct BoundFp {
+    using E = BFp;
+    static constexpr int B3 = 12;
+    static E zero() { return {0, 0}; }
+    static E one() { return {1, EXACT}; }
+    static E mul(const E& a, const E& b) { return reduce(a.v * b.v, a.l * b.l); }
+    static E sqr(const E& a) {
+        if (a.l >= TWO32 / 2) fail("squaring operand limb", a.l, TWO32 / 2);
+        return reduce(a.v * a.v, a.l * a.l);
+    }
+    static E mul2add(const E& a, const E& b, const E& c, const E& d) { return reduce(a.v * b.v + c.v * d.v, a.l * b.l + c.l * d.l); }
+    static E add(const E& a, const E& b) { limb(a.l + b.l); return {a.v + b.v, NFORM}; }
+    template <int K> static E sub(const E& a, const E& b) { need_subtrahend(b, K, SPREAD_LO); limb(a.l + SPREAD_HI); return {a.v + K, NFORM}; }
+    template <int K> static E neg(const E& a) { return sub<K>(zero(), a); }
+    static E mul3(const E& a) { limb(3 * a.l); return {3 * a.v, NFORM}; }
+    static E mul_b3(const E& a) { limb(12 * a.l); return {12 * a.v, NFORM}; }
+    static bool is_zero_2p(const E& a) { if (a.v > 2) fail("is_zero_2p operand", a.v, 2); return false; }
+    static E select(bool, const E& a, const E& b) { return {std::max(a.v, b.v), std::max(a.l, b.l)}; }
+    static bool limbs_all_zero(const E&) { return false; }
+    // the hot loop's carry-free operations (FpOpsInline)
+    static E add_l(const E& a, const E& b) { return {a.v + b.v, limb(a.l + b.l)}; }
+    template <int K> static E sub_l(const E& a, const E& b) { need_subtrahend(b, K, SPREAD_LO); return {a.v + K, limb(a.l + SPREAD_HI)}; }
+    template <int K> static E neg_l(const E& a) { return sub_l<K>(zero(), a); }
+    static E sub8_wide(const E& a, const E& b) { need_subtrahend(b, 8, 3 * TWO28 + 64); return {a.v + 8, limb(a.l + 4 * TWO28 + 68)}; }
+    static E norm(const E& a) { limb(a.l); return {a.v, NFORM}; }
+};
+
+static BFp mx(const BFp& a, const BFp& b) { return {std::max(a.v, b.v), std::max(a.l, b.l)}; }
+
+int main() {
+    using F = BoundFp;
+    // --- accumulate hot loop (k_accumulate): x2 exact < 2p (ingest output), y2 = y or its lazy negation 4p - y
+    BFp x2{2, EXACT}, y2 = mx(BFp{2, EXACT}, F::neg_l<4>(BFp{2, EXACT}));
+    ec::Xyzz<F> acc;
+    acc.x = x2; acc.y = F::norm(y2); acc.zz = F::one(); acc.zzz = F::one();      // the kernel's first-point initialisation
+    ec::Xyzz<F> inv = acc;
+    for (int it = 0; it < 64; it++) {
+        ec::Xyzz<F> a = inv;
+        ec::xyzz_madd<F>(a, x2, y2);
+        ec::Xyzz<F> nx{mx(inv.x, a.x), mx(inv.y, a.y), mx(inv.zz, a.zz), mx(inv.zzz, a.zzz)};
+        bool same = nx.x.v == inv.x.v && nx.y.v == inv.y.v && nx.x.l == inv.x.l && nx.y.l == inv.y.l && nx.zz.v == inv.zz.v && nx.zzz.v == inv.zzz.v;
+        inv = nx;
+        if (same) break;
+        if (it == 63) fail("madd invariant did not converge", it, 63);
+    }
+    printf("xyzz_madd invariant: X < %.0fp (limb %.3g), Y < %.0fp, ZZ < %.0fp, ZZZ < %.0fp\n", inv.x.v, inv.x.l, inv.y.v, inv.zz.v, inv.zzz.v);
+    // --- bucket leaves the hot loop: XYZZ -> projective, then the complete additions of merge / reduce / cold path
+    ec::Proj<F> pj = ec::xyzz_to_proj<F>(inv);
+    ec::Proj<F> q = ec::proj_from_affine<F>(x2, F::neg<4>(BFp{2, EXACT}));
+    ec::Proj<F> pinv{mx(pj.x, q.x), mx(pj.y, q.y), mx(pj.z, q.z)};
+    for (int it = 0; it < 64; it++) {
+        ec::Proj<F> a = pinv;
+        ec::proj_add<F>(a, pinv);
+        ec::Proj<F> nx{mx(pinv.x, a.x), mx(pinv.y, a.y), mx(pinv.z, a.z)};
+        bool same = nx.x.v == pinv.x.v && nx.y.v == pinv.y.v && nx.z.v == pinv.z.v;
+        pinv = nx;
+        if (same) break;
+        if (it == 63) fail("proj_add invariant did not converge", it, 63);
+    }
+    printf("proj_add invariant: X < %.0fp, Y < %.0fp, Z < %.0fp\n", pinv.x.v, pinv.y.v, pinv.z.v);
+    printf("msm bounds OK: largest product %.0f p^2 (limit %.0f), largest column sum 2^%.2f (limit 2^%.2f), largest limb 2^%.2f\n",
+           g_max_prod, LIMIT, std::log2(g_max_col), std::log2(COLMAX), std::log2(g_max_limb));
+    return 0;
+}

@@ -22,6 +22,15 @@ def test_bounds_checker():
     subprocess.check_call(["python3", os.path.join(HERE, "..", "tools", "bounds_check.py")])
 
 
+def test_bounds_machine_checked_on_the_real_formulas():
+    """ec.cuh's xyzz_madd / xyzz_to_proj / proj_add instantiated with a field class that carries value and limb bounds and
+    enforces fp28.cuh's contracts at every call, iterated to a fixed point (tests/host/msm_bounds.cpp)"""
+    exe = os.path.join(HERE, "host", "msm_bounds")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(HERE, "host", "msm_bounds.cpp")])
+    out = subprocess.check_output([exe]).decode()
+    assert "msm bounds OK" in out
+
+
 def test_field_ops(h28, co, o):
     rnd = random.Random(1)
     n = 3000
