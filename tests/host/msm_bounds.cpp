@@ -73,6 +73,91 @@ struct BoundFp {
 
 static BFp mx(const BFp& a, const BFp& b) { return {std::max(a.v, b.v), std::max(a.l, b.l)}; }
 
+// G2: ec::Fp2OpsT builds an Fp2 product from fused two- (four-) product reductions of Fp and normalises after every
+// linear operation, so limbs are always N-form and only VALUE bounds matter.  This mirrors its formulas component-wise:
+//   c0 = a0 b0 + a1 (32p - b1)     needs b1 <= 31p          c1 = a0 b1 + a1 b0
+// INLINE = the hot loop's variant (mul2add is ONE reduction of four products per component).
+struct B2 {
+    double c0, c1;
+};
+static double red2(double prod) {
+    if (prod >= LIMIT) fail("Fp2 product value", prod, LIMIT);
+    g_max_prod = std::max(g_max_prod, prod);
+    return 2.0;
+}
+static double val(double v) {
+    if (v >= LIMIT) fail("value does not fit 2^392", v, LIMIT);
+    return v;
+}
+template <bool INLINE>
+struct BoundFp2 {
+    using E = B2;
+    static E zero() { return {0, 0}; }
+    static E one() { return {1, 0}; }
+    static double fsub(int K, double a, double b) {
+        if (b > K - 1) fail("Fp2 subtrahend value", b, K - 1);
+        return val(a + K);
+    }
+    static E mul(const E& a, const E& b) {
+        if (b.c1 > 31) fail("Fp2 mul: b.c1", b.c1, 31);
+        return {red2(a.c0 * b.c0 + a.c1 * 32.0), red2(a.c0 * b.c1 + a.c1 * b.c0)};
+    }
+    static E sqr(const E& a) { return {red2((a.c0 + a.c1) * fsub(32, a.c0, a.c1)), red2(2 * a.c0 * a.c1)}; }
+    static E mul2add(const E& a, const E& b, const E& c, const E& d) {
+        if (b.c1 > 31 || d.c1 > 31) fail("Fp2 mul2add: c1", std::max(b.c1, d.c1), 31);
+        if (INLINE)
+            return {red2(a.c0 * b.c0 + a.c1 * 32.0 + c.c0 * d.c0 + c.c1 * 32.0), red2(a.c0 * b.c1 + a.c1 * b.c0 + c.c0 * d.c1 + c.c1 * d.c0)};
+        return {val(red2(a.c0 * b.c0 + a.c1 * 32.0) + red2(c.c0 * d.c0 + c.c1 * 32.0)),
+                val(red2(a.c0 * b.c1 + a.c1 * b.c0) + red2(c.c0 * d.c1 + c.c1 * d.c0))};
+    }
+    static E add(const E& a, const E& b) { return {val(a.c0 + b.c0), val(a.c1 + b.c1)}; }
+    template <int K> static E sub(const E& a, const E& b) { return {fsub(K, a.c0, b.c0), fsub(K, a.c1, b.c1)}; }
+    template <int K> static E neg(const E& a) { return sub<K>(zero(), a); }
+    static E add_l(const E& a, const E& b) { return add(a, b); }
+    template <int K> static E sub_l(const E& a, const E& b) { return sub<K>(a, b); }
+    template <int K> static E neg_l(const E& a) { return neg<K>(a); }
+    static E sub8_wide(const E& a, const E& b) { return sub<8>(a, b); }
+    static E norm(const E& a) { return a; }
+    static E mul3(const E& a) { return {val(3 * a.c0), val(3 * a.c1)}; }
+    static E mul_b3(const E& a) { return mul(a, E{1, 1}); }   // by the constant (12, 12), each component < p
+    static bool is_zero_2p(const E& a) { if (a.c0 > 2 || a.c1 > 2) fail("is_zero_2p operand", std::max(a.c0, a.c1), 2); return false; }
+    static E select(bool, const E& a, const E& b) { return {std::max(a.c0, b.c0), std::max(a.c1, b.c1)}; }
+    static bool limbs_all_zero(const E&) { return false; }
+};
+static B2 mx(const B2& a, const B2& b) { return {std::max(a.c0, b.c0), std::max(a.c1, b.c1)}; }
+static bool same(const B2& a, const B2& b) { return a.c0 == b.c0 && a.c1 == b.c1; }
+
+template <class FA, class F>
+static void check_g2(const char* tag) {
+    B2 x2{2, 2}, y2 = mx(B2{2, 2}, FA::template neg_l<4>(B2{2, 2}));
+    ec::Xyzz<FA> inv;
+    inv.x = x2; inv.y = FA::norm(y2); inv.zz = FA::one(); inv.zzz = FA::one();
+    for (int it = 0;; it++) {
+        ec::Xyzz<FA> a = inv;
+        ec::xyzz_madd<FA>(a, x2, y2);
+        ec::Xyzz<FA> nx{mx(inv.x, a.x), mx(inv.y, a.y), mx(inv.zz, a.zz), mx(inv.zzz, a.zzz)};
+        bool fix = same(nx.x, inv.x) && same(nx.y, inv.y) && same(nx.zz, inv.zz) && same(nx.zzz, inv.zzz);
+        inv = nx;
+        if (fix) break;
+        if (it == 63) fail("G2 madd invariant did not converge", it, 63);
+    }
+    ec::Xyzz<F> as_f{inv.x, inv.y, inv.zz, inv.zzz};
+    ec::Proj<F> pj = ec::xyzz_to_proj<F>(as_f);
+    ec::Proj<F> q = ec::proj_from_affine<F>(x2, F::template neg<4>(B2{2, 2}));
+    ec::Proj<F> pinv{mx(pj.x, q.x), mx(pj.y, q.y), mx(pj.z, q.z)};
+    for (int it = 0;; it++) {
+        ec::Proj<F> a = pinv;
+        ec::proj_add<F>(a, pinv);
+        ec::Proj<F> nx{mx(pinv.x, a.x), mx(pinv.y, a.y), mx(pinv.z, a.z)};
+        bool fix = same(nx.x, pinv.x) && same(nx.y, pinv.y) && same(nx.z, pinv.z);
+        pinv = nx;
+        if (fix) break;
+        if (it == 63) fail("G2 proj_add invariant did not converge", it, 63);
+    }
+    printf("%s: xyzz_madd X < %.0fp, Y < %.0fp; proj_add X < %.0fp, Y < %.0fp, Z < %.0fp\n", tag, std::max(inv.x.c0, inv.x.c1),
+           std::max(inv.y.c0, inv.y.c1), std::max(pinv.x.c0, pinv.x.c1), std::max(pinv.y.c0, pinv.y.c1), std::max(pinv.z.c0, pinv.z.c1));
+}
+
 int main() {
     using F = BoundFp;
     // --- accumulate hot loop (k_accumulate): x2 exact < 2p (ingest output), y2 = y or its lazy negation 4p - y
@@ -104,6 +189,8 @@ int main() {
         if (it == 63) fail("proj_add invariant did not converge", it, 63);
     }
     printf("proj_add invariant: X < %.0fp, Y < %.0fp, Z < %.0fp\n", pinv.x.v, pinv.y.v, pinv.z.v);
+    // --- G2: hot loop on the inlined Fp2 variant, everything else on the shared-call variant (msm_kernels.cuh: G2C)
+    check_g2<BoundFp2<true>, BoundFp2<false>>("G2");
     printf("msm bounds OK: largest product %.0f p^2 (limit %.0f), largest column sum 2^%.2f (limit 2^%.2f), largest limb 2^%.2f\n",
            g_max_prod, LIMIT, std::log2(g_max_col), std::log2(COLMAX), std::log2(g_max_limb));
     return 0;

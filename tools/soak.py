@@ -2,7 +2,9 @@
 """Time-boxed randomized parity soak on one MI355X: MSM (G1/G2) and multi-pairing through the C ABI against the C
 oracles, over random sizes, window sizes, scalar formats/distributions, repeated / opposite / infinity bases.
 Prints a progress line every ~20 s and a final JSON summary; exits non-zero on the first mismatch.
-    python tools/soak.py [seconds=300] [seed=1]
+    python tools/soak.py [seconds=300] [seed=1] [threads=1]
+With threads > 1 the same loop runs from several host threads on ONE context (two lanes + exclusive entry points); the batch
+case, which changes the resident base set, is then left out.
 """
 import json, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +14,7 @@ from oracle import coracle as co, bls12_381 as o
 pkg = ge.load_package()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+nthreads = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 rnd = random.Random(seed)
 ncpu = min(16, len(os.sched_getaffinity(0)))
 POOL = {"g1": 60000, "g2": 20000}
@@ -26,10 +29,16 @@ def neg_point(g, blob):
 
 stats = {"msm_g1": 0, "msm_g2": 0, "pairing": 0, "points": 0, "pairs": 0}
 t0 = last = time.time()
-with pkg.Context([0]) as ctx:
-    while time.time() - t0 < budget:
+import threading
+stats_mu = threading.Lock()
+failed = []
+
+
+def loop(ctx, rnd, tid):
+    global last
+    while time.time() - t0 < budget and not failed:
         r = rnd.random()
-        if r < 0.04:   # batch entry point over a resident base set (two MSMs in flight on the context's lanes)
+        if r < 0.04 and nthreads == 1:   # batch entry point over a resident base set (two MSMs in flight on the context's lanes)
             g = rnd.choice(["g1", "g1", "g2"])
             aff, lim = AFF[g], POOL[g]
             n = rnd.randrange(1, lim)
@@ -41,7 +50,7 @@ with pkg.Context([0]) as ctx:
             got = ctx.msm_batch(g, vecs, n, pkg.SCALAR_CANONICAL)
             for v, x in zip(vecs, got):
                 if co.to_affine(g, x) != co.to_affine(g, co.msm(g, bases, v, n, 0, ncpu)):
-                    print("BATCH MISMATCH", seed, g, n, k); sys.exit(1)
+                    print("BATCH MISMATCH", seed, g, n, k); failed.append(1); return
             stats["batch"] = stats.get("batch", 0) + 1; stats["points"] += n * k
         elif r < 0.15:
             n = rnd.choice([1, 2, 9, 10, 11, 63, 64, 65, rnd.randrange(1, 3000)])
@@ -55,7 +64,7 @@ with pkg.Context([0]) as ctx:
             got = ctx.multi_pairing(bytes(g1), bytes(g2))
             want = co.multi_pairing(bytes(g1), bytes(g2), ncpu)
             if got != want:
-                print("PAIRING MISMATCH", seed, n); sys.exit(1)
+                print("PAIRING MISMATCH", seed, n); failed.append(1); return
             stats["pairing"] += 1; stats["pairs"] += n
         else:
             g = "g2" if r < 0.4 else "g1"
@@ -82,18 +91,28 @@ with pkg.Context([0]) as ctx:
             canon = b"".join(o.fr_to_canon_bytes(x) for x in sc)
             fmt = rnd.choice([pkg.SCALAR_CANONICAL, pkg.SCALAR_MONTGOMERY])
             data = canon if fmt == pkg.SCALAR_CANONICAL else co.fr_to_mont(canon)
-            c = rnd.choice([0, 0, 0, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
-            ctx.set_window_bits(c)
+            c = rnd.choice([0, 0, 0, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]) if nthreads == 1 else 0   # the setting is per context
+            if nthreads == 1:
+                ctx.set_window_bits(c)
             try:
                 got = ctx.msm(g, bytes(bases), data, n, fmt)
             finally:
-                ctx.set_window_bits(0)
+                if nthreads == 1:
+                    ctx.set_window_bits(0)
             want = co.msm(g, bytes(bases), canon, n, 0, ncpu)
             if co.to_affine(g, got) != co.to_affine(g, want):
-                print("MSM MISMATCH", seed, g, n, kind, c, fmt); sys.exit(1)
+                print("MSM MISMATCH", seed, g, n, kind, c, fmt); failed.append(1); return
             stats["msm_" + g] += 1; stats["points"] += n
-        if time.time() - last > 20:
+        if tid == 0 and time.time() - last > 20:
             last = time.time()
             print("soak", round(last - t0), "s", stats, flush=True)
-stats.update({"seconds": round(time.time() - t0, 1), "seed": seed, "mismatches": 0})
+
+
+with pkg.Context([0]) as ctx:
+    ths = [threading.Thread(target=loop, args=(ctx, random.Random(seed * 1000 + t), t)) for t in range(nthreads)]
+    for t in ths: t.start()
+    for t in ths: t.join()
+if failed:
+    sys.exit(1)
+stats.update({"seconds": round(time.time() - t0, 1), "seed": seed, "threads": nthreads, "mismatches": 0})
 print(json.dumps(stats))
