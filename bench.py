@@ -201,6 +201,21 @@ def main() -> None:
         two_thread = {"value": n * args.steps / e2, "unit": "points/s", "ms_per_step": e2 / args.steps * 1e3, "same_result": ok2,
                       "note": "the same K steps issued by two host threads on ONE context (two lanes, shared resident bases)"}
 
+    # ---- secondary figure (N = 1 only): end-to-end call shapes (SURVEY 8(d) "timing scope"): scalars from host memory per call
+    # with resident bases, and the reference driver's shape — bases AND scalars uploaded on every call (src/gpu.rs:149-150)
+    call_shapes = None
+    if world == 1 and args.concurrency == 1 and not args.no_secondary:
+        def best_of(fn, reps=3):
+            fn()
+            b = 1e30
+            for _ in range(reps):
+                t1 = time.perf_counter(); r = fn(); b = min(b, time.perf_counter() - t1)
+            assert co.to_affine(g, r) == co.to_affine(g, result)
+            return b * 1e3
+        call_shapes = {"resident_bases_host_scalars_ms": best_of(lambda: ctx.msm(g, None, scalars, n, pkg.SCALAR_CANONICAL)),
+                       "host_bases_host_scalars_ms": best_of(lambda: ctx.msm(g, bases, scalars, n, pkg.SCALAR_CANONICAL)),
+                       "note": "per call incl. H2D of the scalars (and bases) from pageable host memory; the headline keeps both in HBM"}
+
     # ---- secondary figure (N = 1 only): the pairing row (BASELINE config #5): 2^16 G1 x G2 pairs through
     # mi_multi_pairing; parity = prod e(P_i, Q_i) e(-P_i, Q_i) == 1 at full size (tools/bench_pairing.py has the oracle check)
     pairing = None
@@ -298,19 +313,39 @@ def main() -> None:
             "input_gen_s": gen_s,
             "two_host_threads": two_thread,
             "pairing_2p16": pairing,
+            "call_shapes": call_shapes,
         }
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
-            best = 1e30
-            runs = 3 if args.log_n <= 20 else 1
+            # one warm-up + median of >= 5 runs (3 at 2^24 and above), CPU model and core count in the result,
+            # plus a single-thread figure (on a 2^16-point prefix) for scaling
+            import statistics
+            runs = 5 if args.log_n <= 20 else (3 if args.log_n <= 24 else 1)
+            if args.log_n <= 22:
+                co.msm(g, bases, scalars, n, 0, ncpu)
+            times = []
             for _ in range(runs):
                 t0 = time.perf_counter()
                 cpu = co.msm(g, bases, scalars, n, 0, ncpu)
-                best = min(best, time.perf_counter() - t0)
+                times.append(time.perf_counter() - t0)
+            med = statistics.median(times)
             assert co.to_affine(g, cpu) == co.dlog_expected(g, scalars, seed_b, n)
-            out["cpu_baseline"] = {"value": n / best, "unit": "points/s", "cores": ncpu, "kind": "port",
-                                   "sample": f"full workload of one GPU (2^{args.log_n} points), best of {runs} runs, "
+            n1 = min(n, 1 << 16)
+            t0 = time.perf_counter()
+            co.msm(g, bases[:aff * n1], scalars[:32 * n1], n1, 0, 1)
+            t_single = time.perf_counter() - t0
+            model = "unknown"
+            try:
+                for line in open("/proc/cpuinfo"):
+                    if line.startswith("model name"):
+                        model = line.split(":", 1)[1].strip()
+                        break
+            except OSError:
+                pass
+            out["cpu_baseline"] = {"value": n / med, "unit": "points/s", "cores": ncpu, "kind": "port", "cpu_model": model,
+                                   "sample": f"full workload of one GPU (2^{args.log_n} points), median of {runs} runs after a warm-up, "
                                              "blst-style Pippenger restatement in portable C (oracle/msm_oracle.c), not blst assembly",
-                                   "seconds": best}
+                                   "seconds": med, "best_seconds": min(times),
+                                   "single_thread": {"value": n1 / t_single, "unit": "points/s", "points": n1}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
