@@ -584,7 +584,12 @@ __global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hi
                                                  uint32_t* __restrict__ order, uint32_t* __restrict__ item_bucket,
                                                  uint32_t* __restrict__ merge_list, uint32_t* __restrict__ meta) {
     __shared__ uint32_t pe[1024], pi[1024], cur[SCHED_CLASSES];
+    // buckets split into many items (skewed scalars: one bucket can hold all N entries) are written out by the whole
+    // workgroup after the per-lane pass; one lane doing it alone cost 0.65 ms for a bucket of 2^20 entries
+    constexpr uint32_t HV_CAP = 64, HV_MIN = 64;
+    __shared__ uint32_t hv_k[HV_CAP], hv_run[HV_CAP], hv_it[HV_CAP], hv_pos[HV_CAP], hv_mp[HV_CAP], hv_n;
     uint32_t t = threadIdx.x, blk = blockIdx.x;
+    if (t == 0) hv_n = 0;
     if (t < SCHED_CLASSES) cur[t] = blk_cls[t * nblk + blk];
     uint32_t per_t = per_blk >> 10;
     uint32_t lo = blk * per_blk + t * per_t, hi = lo + per_t < m ? lo + per_t : m;
@@ -611,9 +616,14 @@ __global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hi
         woff[k] = run_i;
         if (it > 1) {  // full-length chunks of a split bucket: one reservation in the longest class
             uint32_t pos = atomicAdd(&cur[64], it - 1);
-            for (uint32_t j = 0; j + 1 < it; j++) { order[pos + j] = run_i + j; item_bucket[run_i + j] = k; }
             uint32_t mp = atomicAdd(&meta[3], it);     // the merge passes only visit the items of split buckets
-            for (uint32_t j = 0; j < it; j++) merge_list[mp + j] = run_i + j;
+            uint32_t slot = it >= HV_MIN ? atomicAdd(&hv_n, 1u) : HV_CAP;
+            if (slot < HV_CAP) {
+                hv_k[slot] = k; hv_run[slot] = run_i; hv_it[slot] = it; hv_pos[slot] = pos; hv_mp[slot] = mp;
+            } else {
+                for (uint32_t j = 0; j + 1 < it; j++) { order[pos + j] = run_i + j; item_bucket[run_i + j] = k; }
+                for (uint32_t j = 0; j < it; j++) merge_list[mp + j] = run_i + j;
+            }
         }
         uint32_t last = run_i + it - 1;
         uint32_t pos = atomicAdd(&cur[class_of(h - (it - 1) * T, logT)], 1u);
@@ -623,6 +633,15 @@ __global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hi
         run_i += it;
     }
     if (blk == nblk - 1 && t == 1023) { offsets[m] = run_e; woff[m] = run_i; }
+    __syncthreads();
+    const uint32_t nh = hv_n < HV_CAP ? hv_n : HV_CAP;
+    for (uint32_t s = 0; s < nh; s++) {
+        const uint32_t k = hv_k[s], r0 = hv_run[s], it = hv_it[s], pos = hv_pos[s], mp = hv_mp[s];
+        for (uint32_t j = t; j < it; j += 1024) {
+            if (j + 1 < it) { order[pos + j] = r0 + j; item_bucket[r0 + j] = k; }
+            merge_list[mp + j] = r0 + j;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- accumulate
