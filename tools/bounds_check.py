@@ -83,7 +83,7 @@ def check_xyzz_to_proj(X=10, Y=6):
 
 
 def check_rcb_add(B=8):
-    """Renes-Costello-Batina 2016 Alg. 7 (a = 0, b3 = 12), scheduled as 12 multiplications."""
+    """Renes-Costello-Batina 2016 Alg. 7 (a = 0, b3 = 12), scheduled as 12 multiplications, the three outputs as fused two-product reductions."""
     X1, Y1, Z1, X2, Y2, Z2 = (V(B) for _ in range(6))
     t0 = mul(X1, X2)
     t1 = mul(Y1, Y2)
@@ -99,15 +99,10 @@ def check_rcb_add(B=8):
     Z3 = add(t1, t2)
     t1 = sub(32, t1, t2)
     t5 = scale(12, t5)
-    X3 = mul(t4, t5)
-    t2 = mul(t3, t1)
-    Y3 = mul(t5, t0)
-    t1 = mul(t1, Z3)
-    t0 = mul(t0, t3)
-    Z3 = mul(Z3, t4)
-    X3 = sub(4, t2, X3)
-    Y3 = add(t1, Y3)
-    Z3 = add(Z3, t0)
+    u = Z3
+    X3 = mul2add(t1, t3, t5, sub(16, V(0), t4))   # t1 t3 - t5 t4, fused: one reduction per output
+    Y3 = mul2add(t1, u, t5, t0)
+    Z3 = mul2add(u, t4, t0, t3)
     assert max(X3.v, Y3.v, Z3.v) <= B, (X3.v, Y3.v, Z3.v)
     return X3.v, Y3.v, Z3.v
 
