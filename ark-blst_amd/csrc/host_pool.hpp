@@ -64,6 +64,26 @@ public:
         while (done_.load(std::memory_order_acquire) < n) cpu_relax();
     }
 
+    // Split form of parallel_for: start() publishes the loop and returns at once (the workers run it), finish() lets the
+    // caller help with what is left and waits for the end.  Between the two the caller may do work that consumes the
+    // loop's results as they appear (the Horner fold over window sums).  False from start(): no workers — run it inline.
+    bool start(unsigned n, const std::function<void(unsigned)>& fn) {
+        if (threads_.empty() || n == 0) return false;
+        while (inside_.load(std::memory_order_acquire) != 0) cpu_relax();
+        uint64_t gen = (ticket_.load(std::memory_order_relaxed) >> 32) + 1;
+        Desc& d = desc_[gen & 1];
+        d.fn = &fn;
+        d.n = n;
+        done_.store(0, std::memory_order_relaxed);
+        ticket_.store(gen << 32, std::memory_order_release);
+        prewake();
+        return true;
+    }
+    void finish(unsigned n) {
+        run_items();
+        while (done_.load(std::memory_order_acquire) < n) cpu_relax();
+    }
+
 private:
     struct Desc {
         const std::function<void(unsigned)>* fn = nullptr;

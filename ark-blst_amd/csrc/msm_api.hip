@@ -273,30 +273,6 @@ J host_fold(mi_ctx* ctx, const J* pairs, const Plan& pl) {
         J sab = a < b ? run.add(p[2 * a]) : J::inf();
         part[u] = Part{acc, sab, tsum};
     };
-    size_t work = (size_t)pl.nwin * cpw;
-    std::unique_lock<std::mutex> pool_lock(ctx->pool_mu, std::defer_lock);
-    const bool use_pool = work >= 128 && ctx->pool && ctx->devs.size() == 1;
-    if (use_pool) pool_lock.lock();   // the other lane's fold (~0.3 ms) may be running
-    // multi-device context: every device thread folds its own pairs; it may take a few helper threads of its own (the
-    // shared pool runs one loop at a time and would serialise the devices)
-    const unsigned helpers = !use_pool && work >= 512 && ctx->devs.size() > 1
-                                 ? std::min<unsigned>(4, std::max<unsigned>(1, std::thread::hardware_concurrency() / (unsigned)ctx->devs.size()))
-                                 : 1;
-    if (use_pool) {
-        ctx->pool->parallel_for(pl.nwin * parts, do_part);
-    } else if (helpers > 1) {
-        std::atomic<uint32_t> next{0};
-        const uint32_t units = pl.nwin * parts;
-        auto loop = [&]() {
-            for (uint32_t u = next.fetch_add(1); u < units; u = next.fetch_add(1)) do_part(u);
-        };
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < helpers; t++) th.emplace_back(loop);
-        loop();
-        for (auto& t : th) t.join();
-    } else {
-        for (uint32_t u = 0; u < pl.nwin * parts; u++) do_part(u);
-    }
     // seg is a power of two whenever parts > 1 (chunks_per_win is): a * S = (q * seg) * S by doublings
     unsigned log_seg = 0;
     while ((1u << log_seg) < seg) log_seg++;
@@ -316,10 +292,56 @@ J host_fold(mi_ctx* ctx, const J* pairs, const Plan& pl) {
         J x = parts > 1 ? wsum.add(qs.dbl_n(log_seg)) : wsum;
         win[w] = x.dbl_n(6 + pl.logL).add(tsum);
     };
+    size_t work = (size_t)pl.nwin * cpw;
+    const uint32_t units = pl.nwin * parts;
+    const bool use_pool = work >= 128 && ctx->pool && ctx->devs.size() == 1;
     if (use_pool) {
-        ctx->pool->parallel_for(pl.nwin, do_window);
-        pool_lock.unlock();
+        // Pipelined with the Horner fold: the workers take the units of the TOP window first; whoever finishes the last part
+        // of a window combines it and flags it; this thread folds the windows top-down as they become ready, so the 240
+        // serial doublings run beside the chunk sums instead of after them.
+        std::lock_guard<std::mutex> pool_lock(ctx->pool_mu);   // the other lane's fold (~0.2 ms) may be running
+        std::vector<std::atomic<int>> left(pl.nwin), ready(pl.nwin);
+        for (uint32_t w = 0; w < pl.nwin; w++) { left[w].store((int)parts); ready[w].store(0); }
+        std::function<void(unsigned)> job = [&](unsigned k) {
+            uint32_t w = pl.nwin - 1 - k / parts, q = k % parts;
+            do_part(w * parts + q);
+            if (left[w].fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                do_window(w);
+                ready[w].store(1, std::memory_order_release);
+            }
+        };
+        if (ctx->pool->start(units, job)) {
+            J r = J::inf();
+            for (int w = (int)pl.nwin - 1; w >= 0; w--) {
+                while (!ready[w].load(std::memory_order_acquire)) {
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                }
+                r = r.dbl_n(pl.c).add(win[w]);
+            }
+            ctx->pool->finish(units);
+            return r;
+        }
+        for (uint32_t k = 0; k < units; k++) job(k);   // no workers
     } else {
+        // multi-device context: every device thread folds its own pairs; it may take a few helper threads of its own (the
+        // shared pool runs one loop at a time and would serialise the devices)
+        const unsigned helpers = work >= 512 && ctx->devs.size() > 1
+                                     ? std::min<unsigned>(4, std::max<unsigned>(1, std::thread::hardware_concurrency() / (unsigned)ctx->devs.size()))
+                                     : 1;
+        if (helpers > 1) {
+            std::atomic<uint32_t> next{0};
+            auto loop = [&]() {
+                for (uint32_t u = next.fetch_add(1); u < units; u = next.fetch_add(1)) do_part(u);
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < helpers; t++) th.emplace_back(loop);
+            loop();
+            for (auto& t : th) t.join();
+        } else {
+            for (uint32_t u = 0; u < units; u++) do_part(u);
+        }
         for (uint32_t w = 0; w < pl.nwin; w++) do_window(w);
     }
     J r = J::inf();
