@@ -276,11 +276,14 @@ def main() -> None:
         # workload and committed under profiles/; bench.py cannot collect counters itself.
         traffic, traffic_src = None, None
         try:
-            prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
-            if prof and g == "g1" and args.log_n == 20:
-                pj = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
-                traffic = pj["kernels"]["msmk::k_accumulate<msmk::G1C>"]["hbm_bytes_per_launch_corrected"]
-                traffic_src = "profiles/" + prof[-1]
+            key = f"msmk::k_accumulate<msmk::{g.upper()}C>"
+            if args.log_n == 20:   # the committed counters were collected on this exact workload
+                for f in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json")), reverse=True):
+                    pj = json.load(open(os.path.join(ROOT, "profiles", f)))
+                    if key in pj.get("kernels", {}) and "hbm_bytes_per_launch_corrected" in pj["kernels"][key]:
+                        traffic = pj["kernels"][key]["hbm_bytes_per_launch_corrected"]
+                        traffic_src = "profiles/" + f
+                        break
         except Exception:
             pass
         out = {
