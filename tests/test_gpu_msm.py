@@ -504,3 +504,28 @@ def test_msm_batch_over_resident_bases(ctx, co, pkg, group):
     assert co.to_affine(group, one[0]) == co.to_affine(group, got[0])
     mont = ctx.msm_batch(group, [co.fr_to_mont(v) for v in vecs[:2]], n, pkg.SCALAR_MONTGOMERY)
     assert [co.to_affine(group, x) for x in mont] == [co.to_affine(group, x) for x in got[:2]]
+
+
+def test_bench_json_contract():
+    """bench.py prints ONE JSON line with the fields the driver and the judge read (small size, as a child process)"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--log-n", "14", "--steps", "2", "--warmup", "1", "--no-secondary"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "bit_exact"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["bit_exact"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "points/s" and d["higher_is_better"] is True and "workload" in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert d["cpu_baseline"]["kind"] == "port"
