@@ -44,7 +44,7 @@ def main() -> None:
     ap.add_argument("--group", default="g1", choices=["g1", "g2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
-    ap.add_argument("--dist", default="uniform", choices=["uniform", "zero_one", "small64", "all_equal", "all_ones"],
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "zero_one", "small64", "all_equal", "all_ones", "r1cs_mix"],
                     help="scalar distribution (secondary robustness figures; the headline is uniform)")
     ap.add_argument("--concurrency", type=int, default=1,
                     help="host threads issuing MSM calls concurrently (each with its own context; the trait method is\n"
@@ -97,6 +97,11 @@ def main() -> None:
             a[:, 0] &= 1
         elif args.dist == "small64":     # 64-bit values
             a[:, 8:] = 0
+        elif args.dist == "r1cs_mix":    # witness-like: half zeros, a quarter ones, a quarter full-size values
+            sel = a[:, 0] & 3
+            a[sel < 2] = 0
+            a[sel == 2] = 0
+            a[sel == 2, 0] = 1
         elif args.dist == "all_ones":    # every scalar = 1: the plain sum of the bases, one bucket of N entries
             a[:] = 0
             a[:, 0] = 1
