@@ -18,23 +18,23 @@ class MsmError(RuntimeError):
 
 class Profile(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("h2d_ms", "ingest_ms", "digits_ms", "scan_ms", "scatter_ms", "accumulate_ms",
-                                          "reduce_ms", "d2h_ms", "host_fold_ms", "total_ms")] + [
+                                          "reduce_ms", "combine_ms", "d2h_ms", "host_fold_ms", "total_ms")] + [
         ("window_bits", C.c_uint32), ("num_windows", C.c_uint32), ("n", C.c_uint64), ("accumulate_adds", C.c_uint64),
         ("work_items", C.c_uint32), ("max_items_per_bucket", C.c_uint32)]
 
 
-def lib_path() -> str:
-    return os.path.join(_HERE, "lib", "libarkblst_amd.so")
+def lib_path(test_hooks: bool = False) -> str:
+    """The product library, or the test build of the same sources (-DMI_TEST_HOOKS, csrc/test_hooks.h)."""
+    return os.path.join(_HERE, "lib", "libarkblst_amd_test.so" if test_hooks else "libarkblst_amd.so")
 
 
-_LIB = None
+_LIBS = {}
 
 
-def load_library():
+def load_library(test_hooks: bool = False):
     """Load the HIP library; raises (never falls back) when it has not been built."""
-    global _LIB
-    if _LIB is None:
-        path = lib_path()
+    if test_hooks not in _LIBS:
+        path = lib_path(test_hooks)
         if not os.path.exists(path):
             raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
@@ -46,6 +46,7 @@ def load_library():
         L.mi_msm_num_devices.argtypes = [vp]
         for g in ("g1", "g2"):
             getattr(L, f"mi_msm_{g}_set_bases").argtypes = [vp, vp, sz]
+            getattr(L, f"mi_msm_{g}_set_bases_precomputed").argtypes = [vp, vp, sz, u]
             getattr(L, f"mi_msm_{g}").argtypes = [vp, vp, vp, sz, u, vp]
             getattr(L, f"mi_msm_{g}_device").argtypes = [vp, vp, sz, u, vp]
             getattr(L, f"mi_{g}_sum").argtypes = [vp, sz, vp]
@@ -63,9 +64,14 @@ def load_library():
         L.mi_msm_last_error.restype = C.c_char_p
         L.mi_msm_strerror.argtypes = [i]
         L.mi_msm_strerror.restype = C.c_char_p
-        L.mi_test_fp_op.argtypes = [vp, i, vp, vp, vp, sz]
-        _LIB = L
-    return _LIB
+        if test_hooks:
+            L.mi_test_fp_op.argtypes = [vp, i, vp, vp, vp, sz]
+            L.mi_test_set_pairing.argtypes = [vp, u, u, i]
+            L.mi_test_set_max_part.argtypes = [vp, sz]
+            L.mi_test_fail_allocs.argtypes = [i]
+            L.mi_test_fail_allocs.restype = None
+        _LIBS[test_hooks] = L
+    return _LIBS[test_hooks]
 
 
 def _buf(b):
@@ -82,10 +88,11 @@ def _buf(b):
 
 
 class Context:
-    """Owns one mi_ctx (streams, resident bases, scratch).  device_ids=None -> device 0 only."""
+    """Owns one mi_ctx (streams, resident bases, scratch).  device_ids=None -> device 0 only.
+    test_hooks=True loads the test build of the library (extra mi_test_* entry points; tests only)."""
 
-    def __init__(self, device_ids=None):
-        self._L = load_library()
+    def __init__(self, device_ids=None, test_hooks: bool = False):
+        self._L = load_library(test_hooks)
         self._h = C.c_void_p()
         if device_ids is None:
             device_ids = [0]
@@ -124,6 +131,12 @@ class Context:
     def set_bases(self, group: str, bases, n: int):
         p, keep = _buf(bases)
         self._check(getattr(self._L, f"mi_msm_{group}_set_bases")(self._h, p, n), f"mi_msm_{group}_set_bases")
+
+    def set_bases_precomputed(self, group: str, bases, n: int, window_bits: int = 0):
+        """Resident SRS with 2^(c j) P tables: all windows of later MSMs share one bucket set (opt-in, W x the memory)."""
+        p, keep = _buf(bases)
+        self._check(getattr(self._L, f"mi_msm_{group}_set_bases_precomputed")(self._h, p, n, window_bits),
+                    f"mi_msm_{group}_set_bases_precomputed")
 
     def msm(self, group: str, bases, scalars, n: int, scalar_fmt: int = SCALAR_CANONICAL) -> bytes:
         """bases=None uses the resident set. Returns the Jacobian result bytes (blst_p1 / blst_p2)."""
@@ -201,11 +214,21 @@ class Context:
         self._check(self._L.mi_msm_last_profile(self._h, C.byref(p)), "mi_msm_last_profile")
         return {f: getattr(p, f) for f, _ in Profile._fields_}
 
+    # ---- test build only (Context(..., test_hooks=True))
     def test_fp_op(self, op: int, a: bytes, b: bytes) -> bytes:
         n = len(a) // 48
         out = C.create_string_buffer(48 * n)
         self._check(self._L.mi_test_fp_op(self._h, op, a, b, out, n), "mi_test_fp_op")
         return out.raw
+
+    def test_set_pairing(self, share: int = 0, batch: int = 0, single_lane: bool = False):
+        self._check(self._L.mi_test_set_pairing(self._h, share, batch, int(single_lane)), "mi_test_set_pairing")
+
+    def test_set_max_part(self, points: int):
+        self._check(self._L.mi_test_set_max_part(self._h, points), "mi_test_set_max_part")
+
+    def test_fail_allocs(self, count: int):
+        self._L.mi_test_fail_allocs(count)
 
 
 def final_exponentiation(f: bytes) -> bytes:

@@ -1,0 +1,216 @@
+// extern "C" entry points of include/arkblst_amd.h: context lifetime, argument checks, dispatch into the curve / pairing /
+// codec translation units.  Nothing throws across this boundary (every body below either cannot throw or runs in guarded()).
+#include "internal.hpp"
+#if defined(MI_TEST_HOOKS)
+#include "test_hooks.h"
+namespace mi { std::atomic<int> g_fail_allocs{0}; }
+#endif
+
+using namespace mi;
+
+extern "C" {
+
+int mi_msm_init(mi_ctx** out, const int* device_ids, int n_devices) {
+    if (!out || n_devices < 0) return MI_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MI_E_NO_DEVICE;
+    if (n_devices == 0) n_devices = device_ids ? 0 : count;
+    if (n_devices <= 0 || (!device_ids && n_devices > count) || n_devices > 64) return MI_E_NO_DEVICE;
+    mi_ctx* ctx = new (std::nothrow) mi_ctx();
+    if (!ctx) return MI_E_NOMEM;
+    int rc = guarded(ctx, [&]() -> int {
+        ctx->devs.resize(n_devices);
+        ctx->devs_b.resize(n_devices);
+        ctx->residents.resize(n_devices);
+        for (int k = 0; k < n_devices; k++) {
+            int id = device_ids ? device_ids[k] : k;
+            if (id < 0 || id >= count) return MI_E_NO_DEVICE;
+            HIP_TRY(hipSetDevice(id));
+            for (DevState* d : {&ctx->devs[k], &ctx->devs_b[k]}) {
+                d->dev = id;
+                d->res = ctx->residents[k].data();
+                HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+                for (auto& e : d->ev) HIP_TRY(hipEventCreate(&e));
+            }
+        }
+        if (n_devices > 1) {
+            // one persistent host thread per device and lane (nothing is spawned per call); peer access so that a device can read
+            // its shard of a scalar vector that lives on another device of the context (xGMI)
+            for (int l = 0; l < NLANES; l++) ctx->workers[l].reset(new DeviceWorkers((size_t)n_devices));
+            for (int a = 0; a < n_devices; a++)
+                for (int b = 0; b < n_devices; b++) {
+                    int da = ctx->devs[a].dev, db = ctx->devs[b].dev, can = 0;
+                    if (da == db) continue;
+                    if (hipDeviceCanAccessPeer(&can, da, db) == hipSuccess && can) {
+                        (void)hipSetDevice(da);
+                        hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+                        if (e != hipSuccess) (void)hipGetLastError();   // already enabled (by torch, or a second context): fine
+                    }
+                }
+        }
+        return MI_OK;
+    });
+    if (rc != MI_OK) {
+        mi_msm_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return MI_OK;
+}
+
+void mi_msm_destroy(mi_ctx* ctx) {
+    if (!ctx) return;
+    for (int l = 0; l < NLANES; l++) ctx->workers[l].reset();
+    for (std::vector<DevState>* lane : {&ctx->devs, &ctx->devs_b})
+        for (auto& d : *lane) {
+            (void)hipSetDevice(d.dev);
+            if (d.stream) (void)hipStreamSynchronize(d.stream);
+            d.for_each_buf([](DevBuf& b) { b.release(); });
+            if (d.h_pairs) (void)hipHostFree(d.h_pairs);
+            if (d.h_meta) (void)hipHostFree(d.h_meta);
+            for (auto& e : d.ev)
+                if (e) (void)hipEventDestroy(e);
+            if (d.stream) (void)hipStreamDestroy(d.stream);
+        }
+    for (size_t k = 0; k < ctx->residents.size() && k < ctx->devs.size(); k++) {
+        (void)hipSetDevice(ctx->devs[k].dev);
+        for (Resident& x : ctx->residents[k]) { x.buf.release(); x.flags.release(); }
+    }
+    delete ctx;
+}
+
+int mi_msm_num_devices(const mi_ctx* ctx) { return ctx ? (int)ctx->devs.size() : 0; }
+
+int mi_msm_g1_set_bases(mi_ctx* ctx, const mi_g1_affine* bases, size_t n) { return g1_set_bases(ctx, bases, n, 0); }
+int mi_msm_g2_set_bases(mi_ctx* ctx, const mi_g2_affine* bases, size_t n) { return g2_set_bases(ctx, bases, n, 0); }
+int mi_msm_g1_set_bases_precomputed(mi_ctx* ctx, const mi_g1_affine* bases, size_t n, unsigned window_bits) {
+    return g1_set_bases(ctx, bases, n, window_bits ? window_bits : 1);
+}
+int mi_msm_g2_set_bases_precomputed(mi_ctx* ctx, const mi_g2_affine* bases, size_t n, unsigned window_bits) {
+    return g2_set_bases(ctx, bases, n, window_bits ? window_bits : 1);
+}
+
+int mi_msm_g1(mi_ctx* ctx, const mi_g1_affine* bases, const uint8_t* scalars, size_t n, unsigned scalar_fmt, mi_g1* out) {
+    return g1_msm(ctx, bases, scalars, false, n, scalar_fmt, out);
+}
+int mi_msm_g2(mi_ctx* ctx, const mi_g2_affine* bases, const uint8_t* scalars, size_t n, unsigned scalar_fmt, mi_g2* out) {
+    return g2_msm(ctx, bases, scalars, false, n, scalar_fmt, out);
+}
+int mi_msm_g1_device(mi_ctx* ctx, const void* d_scalars, size_t n, unsigned scalar_fmt, mi_g1* out) {
+    return g1_msm(ctx, nullptr, static_cast<const uint8_t*>(d_scalars), true, n, scalar_fmt, out);
+}
+int mi_msm_g2_device(mi_ctx* ctx, const void* d_scalars, size_t n, unsigned scalar_fmt, mi_g2* out) {
+    return g2_msm(ctx, nullptr, static_cast<const uint8_t*>(d_scalars), true, n, scalar_fmt, out);
+}
+
+int mi_msm_g1_batch(mi_ctx* ctx, const uint8_t* const* scalars, size_t k, size_t n, unsigned scalar_fmt, mi_g1* out) {
+    return g1_msm_batch(ctx, scalars, k, n, scalar_fmt, out);
+}
+int mi_msm_g2_batch(mi_ctx* ctx, const uint8_t* const* scalars, size_t k, size_t n, unsigned scalar_fmt, mi_g2* out) {
+    return g2_msm_batch(ctx, scalars, k, n, scalar_fmt, out);
+}
+
+int mi_g1_normalize_batch(mi_ctx* ctx, const mi_g1* in, size_t n, mi_g1_affine* out) { return g1_normalize(ctx, in, n, out); }
+int mi_g2_normalize_batch(mi_ctx* ctx, const mi_g2* in, size_t n, mi_g2_affine* out) { return g2_normalize(ctx, in, n, out); }
+
+int mi_g1_deserialize_batch(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int validate, mi_g1_affine* out,
+                            uint8_t* status) {
+    return g1_deserialize(ctx, bytes, n, compressed, validate, out, status);
+}
+int mi_g1_serialize_batch(mi_ctx* ctx, const mi_g1_affine* points, size_t n, int compressed, uint8_t* bytes) {
+    return g1_serialize(ctx, points, n, compressed, bytes);
+}
+int mi_g2_deserialize_batch(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int validate, mi_g2_affine* out,
+                            uint8_t* status) {
+    return g2_deserialize(ctx, bytes, n, compressed, validate, out, status);
+}
+int mi_g2_serialize_batch(mi_ctx* ctx, const mi_g2_affine* points, size_t n, int compressed, uint8_t* bytes) {
+    return g2_serialize(ctx, points, n, compressed, bytes);
+}
+
+int mi_multi_miller_loop(mi_ctx* ctx, const mi_g1_affine* p, const mi_g2_affine* q, size_t n, mi_fp12* out) {
+    return miller(ctx, p, q, n, out, false);
+}
+int mi_multi_pairing(mi_ctx* ctx, const mi_g1_affine* p, const mi_g2_affine* q, size_t n, mi_fp12* out) {
+    return miller(ctx, p, q, n, out, true);
+}
+int mi_final_exponentiation(const mi_fp12* f, mi_fp12* out) { return final_exponentiation(f, out); }
+
+int mi_g1_sum(const mi_g1* partials, size_t n, mi_g1* out) {
+    if (!out || (n && !partials)) return MI_E_INVALID;
+    hostec::G1 r = hostec::G1::inf();
+    for (size_t i = 0; i < n; i++) {
+        hostec::G1 p;
+        memcpy(&p, &partials[i], sizeof p);
+        r = r.add(p);
+    }
+    memcpy(out, &r, sizeof r);
+    return MI_OK;
+}
+
+int mi_g2_sum(const mi_g2* partials, size_t n, mi_g2* out) {
+    if (!out || (n && !partials)) return MI_E_INVALID;
+    hostec::G2 r = hostec::G2::inf();
+    for (size_t i = 0; i < n; i++) {
+        hostec::G2 p;
+        memcpy(&p, &partials[i], sizeof p);
+        r = r.add(p);
+    }
+    memcpy(out, &r, sizeof r);
+    return MI_OK;
+}
+
+int mi_msm_set_window_bits(mi_ctx* ctx, unsigned window_bits) {
+    if (!ctx || (window_bits != 0 && (window_bits < 7 || window_bits > 22))) return fail(ctx, MI_E_INVALID, "window_bits must be 0 or 7..22");
+    LaneLock lk(ctx, true);
+    ctx->forced_c = window_bits;
+    return MI_OK;
+}
+
+int mi_msm_last_profile(const mi_ctx* ctx, mi_profile* out) {
+    if (!ctx || !out) return MI_E_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->info_mu);
+    *out = ctx->prof;
+    return MI_OK;
+}
+
+// text of the calling thread's most recent failure (thread-local: valid until the same thread fails again)
+const char* mi_msm_last_error(const mi_ctx* ctx) {
+    (void)ctx;
+    return tls_error().c_str();
+}
+
+const char* mi_msm_strerror(int code) {
+    switch (code) {
+        case MI_OK: return "ok";
+        case MI_E_INVALID: return "invalid argument";
+        case MI_E_NO_DEVICE: return "no usable HIP device";
+        case MI_E_HIP: return "HIP runtime error";
+        case MI_E_NOMEM: return "out of memory";
+        case MI_E_NO_BASES: return "no resident base set";
+        case MI_E_UNSUPPORTED: return "not supported in this build";
+        default: return "unknown error";
+    }
+}
+
+#if defined(MI_TEST_HOOKS)
+int mi_test_fp_op(mi_ctx* ctx, int op, const mi_fp* a, const mi_fp* b, mi_fp* out, size_t n) { return test_fp_op(ctx, op, a, b, out, n); }
+int mi_test_set_pairing(mi_ctx* ctx, unsigned share, unsigned batch, int single_lane) {
+    if (!ctx) return MI_E_INVALID;
+    LaneLock lk(ctx, true);
+    ctx->test_pairing_share = share;
+    ctx->test_pairing_batch = batch;
+    ctx->test_pairing_single_lane = single_lane != 0;
+    return MI_OK;
+}
+int mi_test_set_max_part(mi_ctx* ctx, size_t points) {
+    if (!ctx) return MI_E_INVALID;
+    LaneLock lk(ctx, true);
+    ctx->test_max_part = points;
+    return MI_OK;
+}
+void mi_test_fail_allocs(int count) { g_fail_allocs.store(count); }
+#endif
+
+}  // extern "C"

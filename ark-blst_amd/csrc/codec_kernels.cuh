@@ -1,0 +1,351 @@
+// Bulk point (de)serialisation kernels and the field-level test hook.  Compiled in points.hip only.
+#pragma once
+#include "kernels_common.cuh"
+
+namespace msmk {
+
+// ---------------------------------------------------------------------------------------------- G1 point decoding
+// Bulk CanonicalDeserialize + Valid::check for G1 (/root/reference/src/g1.rs:386-431): ZCash/IETF encoding
+// (48-byte compressed / 96-byte uncompressed, big-endian, flag bits 0x80 compressed, 0x40 infinity, 0x20 y is the
+// lexicographically larger root) -> blst_p1_affine, with per-point status instead of the reference's unwrap():
+//   0 ok, 1 malformed encoding (flags, x >= p, no square root), 2 not on the curve, 3 not in the prime-order subgroup.
+// Decompression: y = (x^3 + 4)^((p+1)/4).  Subgroup check (blstrs is_torsion_free [ext]) by the endomorphism test
+// (beta x, y) == -[z^2](x, y), z = 0xd201000000010000 (M. Scott, eprint 2021/1130): two 64-bit double-and-add ladders
+// on the complete projective formulas instead of a 255-bit multiplication by r.
+__device__ __forceinline__ bool words_lt_p(const uint32_t (&w)[12]) {
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        uint64_t v = (uint64_t)w[k] - fp28c::P32[k] - borrow;
+        borrow = (v >> 32) & 1;
+    }
+    return borrow != 0;
+}
+__device__ __forceinline__ void be48_to_words(uint32_t (&w)[12], const uint8_t* b, uint32_t top_mask) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const uint8_t* q = b + 44 - 4 * k;  // word k = bytes [44-4k, 48-4k) big-endian
+        w[k] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
+    }
+    w[11] &= top_mask;
+}
+// canonical integer of an internal value (< 50p), exact 28-bit limbs
+__device__ __forceinline__ Fp fp_to_canonical(const Fp& a) {
+    Fp one_int = fp28::fp_zero();
+    one_int.l[0] = 1;
+    return fp28::fp_canon_2p(fp28::fp_mul_call(a, one_int));
+}
+__device__ __forceinline__ bool fp_equal(const Fp& a, const Fp& b) {  // a == b (mod p), a, b < 15p
+    return fp28::fp_is_zero_any(fp28::fp_sub<16>(a, b));
+}
+
+// r = [|z|] p on the complete formulas (63 doublings + 5 additions)
+__device__ __noinline__ void g1_mul_z(ec::Proj<ec::FpOps>& r, const ec::Proj<ec::FpOps>& p) {
+    using F = ec::FpOps;
+    r = p;
+#pragma unroll 1
+    for (int bit = 62; bit >= 0; bit--) {
+        ec::Proj<F> c = r;
+        ec::proj_add<F>(r, c);
+        if ((fp28c::Z_ABS >> bit) & 1) ec::proj_add<F>(r, p);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_deserialize_g1(const uint8_t* __restrict__ bytes, uint32_t n, int compressed, int validate,
+                                                        uint32_t* __restrict__ out_aff, uint8_t* __restrict__ status) {
+    using F = ec::FpOps;
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t size = compressed ? 48u : 96u;
+    const uint8_t* b = bytes + (size_t)i * size;
+    uint32_t* o = out_aff + (size_t)i * 24;
+    uint8_t b0 = b[0];
+    uint32_t c_flag = b0 >> 7, i_flag = (b0 >> 6) & 1, s_flag = (b0 >> 5) & 1;
+    uint32_t xw[12], yw[12];
+    be48_to_words(xw, b, 0x1fffffffu);
+#pragma unroll
+    for (int k = 0; k < 12; k++) yw[k] = 0;
+    if (!compressed) be48_to_words(yw, b + 48, 0xffffffffu);
+    uint8_t st = 0;
+    bool is_inf = false;
+    if (c_flag != (uint32_t)(compressed ? 1 : 0)) st = 1;
+    if (st == 0 && i_flag) {
+        uint32_t any = s_flag;
+#pragma unroll
+        for (int k = 0; k < 12; k++) any |= xw[k] | yw[k];
+        if (any) st = 1;
+        is_inf = true;
+    }
+    if (st == 0 && !is_inf) {
+        if (!words_lt_p(xw) || (!compressed && (!words_lt_p(yw) || s_flag))) st = 1;
+    }
+    Fp x = fp28::fp_zero(), y = fp28::fp_zero();
+    if (st == 0 && !is_inf) {
+        const Fp r2 = fp28::fp_const(fp28c::R2);
+        x = fp28::fp_mul_call(fp28::fp_unpack384(xw), r2);                       // canonical integer -> internal
+        Fp rhs = fp28::fp_add(fp28::fp_mul_call(fp28::fp_sqr_call(x), x), fp28::fp_const(fp28c::FOUR));   // x^3 + 4  < 4p
+        bool on_curve;
+        if (compressed) {
+            // y = rhs^((p+1)/4): left-to-right square and multiply over the 379-bit exponent
+            Fp acc = rhs;
+#pragma unroll 1
+            for (int bit = 377; bit >= 0; bit--) {  // top set bit of (p+1)/4 is bit 378
+                acc = fp28::fp_sqr_call(acc);
+                if ((fp28c::SQRT_EXP32[bit >> 5] >> (bit & 31)) & 1) acc = fp28::fp_mul_call(acc, rhs);
+            }
+            y = acc;
+            on_curve = fp_equal(fp28::fp_sqr_call(y), rhs);
+            if (!on_curve) st = 1;  // no square root: malformed compressed encoding
+            // pick the root the sort flag asks for
+            Fp yc = fp_to_canonical(y);
+            bool larger = false, decided = false;
+#pragma unroll
+            for (int k = NL - 1; k >= 0; k--) {
+                if (!decided && yc.l[k] != fp28c::HALF_P[k]) { larger = yc.l[k] > fp28c::HALF_P[k]; decided = true; }
+            }
+            if (larger != (s_flag != 0)) y = fp28::fp_neg<4>(y);
+        } else {
+            y = fp28::fp_mul_call(fp28::fp_unpack384(yw), r2);
+            on_curve = !validate || fp_equal(fp28::fp_sqr_call(y), rhs);
+            if (!on_curve) st = 2;
+        }
+        if (st == 0 && validate) {
+            ec::Proj<F> p1 = ec::proj_from_affine<F>(x, y), q, q2;
+            g1_mul_z(q, p1);
+            g1_mul_z(q2, q);                                                     // [z^2] P
+            // membership: (beta x, y) == -[z^2] P, i.e. X == beta x Z, Y == -y Z, Z != 0
+            Fp bx = fp28::fp_mul_call(x, fp28::fp_const(fp28c::BETA));
+            bool ok = !fp28::fp_is_zero_any(q2.z);
+            ok = ok && fp_equal(q2.x, fp28::fp_mul_call(bx, q2.z));
+            ok = ok && fp28::fp_is_zero_any(fp28::fp_add(q2.y, fp28::fp_mul_call(y, q2.z)));
+            if (!ok) st = 3;
+        }
+    }
+    uint32_t w[12];
+    bool keep = st == 0 && !is_inf;
+    fp28::fp_to_blst(w, x);
+#pragma unroll
+    for (int k = 0; k < 12; k++) o[k] = keep ? w[k] : 0u;
+    fp28::fp_to_blst(w, y);
+#pragma unroll
+    for (int k = 0; k < 12; k++) o[12 + k] = keep ? w[k] : 0u;
+    status[i] = st;
+}
+
+// affine (blst form) -> ZCash encoding
+__global__ void __launch_bounds__(256) k_serialize_g1(const uint32_t* __restrict__ aff, uint32_t n, int compressed, uint8_t* __restrict__ bytes) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* q = aff + (size_t)i * 24;
+    const uint32_t size = compressed ? 48u : 96u;
+    uint8_t* b = bytes + (size_t)i * size;
+    uint32_t any = 0;
+#pragma unroll 4
+    for (int k = 0; k < 24; k++) any |= q[k];
+    Fp x, y;
+    fp_from_raw(x, q);
+    fp_from_raw(y, q + 12);
+    Fp xc = fp_to_canonical(x), yc = fp_to_canonical(y);
+    uint32_t xw[12], yw[12];
+    fp28::fp_pack384(xw, xc);
+    fp28::fp_pack384(yw, yc);
+    bool larger = false, decided = false;
+#pragma unroll
+    for (int k = NL - 1; k >= 0; k--) {
+        if (!decided && yc.l[k] != fp28c::HALF_P[k]) { larger = yc.l[k] > fp28c::HALF_P[k]; decided = true; }
+    }
+    for (uint32_t k = 0; k < size; k++) b[k] = 0;
+    if (any == 0) {
+        b[0] = compressed ? 0xC0 : 0x40;
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        uint8_t* d = b + 44 - 4 * k;
+        d[0] = (uint8_t)(xw[k] >> 24); d[1] = (uint8_t)(xw[k] >> 16); d[2] = (uint8_t)(xw[k] >> 8); d[3] = (uint8_t)xw[k];
+        if (!compressed) {
+            uint8_t* e = b + 48 + 44 - 4 * k;
+            e[0] = (uint8_t)(yw[k] >> 24); e[1] = (uint8_t)(yw[k] >> 16); e[2] = (uint8_t)(yw[k] >> 8); e[3] = (uint8_t)yw[k];
+        }
+    }
+    if (compressed) b[0] |= (uint8_t)(0x80 | (larger ? 0x20 : 0));
+}
+
+// ---------------------------------------------------------------------------------------------- G2 point decoding
+// Same for G2 (/root/reference/src/g2.rs:338-411): 96-byte compressed / 192-byte uncompressed, coordinates in Fp2
+// serialised c1 first; y^2 = x^3 + 4(1 + u).  Square root in Fp2 for p = 3 mod 4 (Adj, Rodriguez-Henriquez Alg. 9):
+// a1 = a^((p-3)/4), alpha = a1^2 a, x0 = a1 a; root = u x0 if alpha = -1 else (1 + alpha)^((p-1)/2) x0.
+// Subgroup test: psi(P) == [z] P (z < 0), psi(x, y) = (conj(x) PSI_X, conj(y) PSI_Y)  (M. Scott, eprint 2021/1130).
+using G2F = ec::Fp2Ops;
+__device__ __forceinline__ bool fp2_equal(const ec::Fp2& a, const ec::Fp2& b) { return fp_equal(a.c0, b.c0) && fp_equal(a.c1, b.c1); }
+__device__ __forceinline__ bool fp2_is_zero(const ec::Fp2& a) { return fp28::fp_is_zero_any(a.c0) && fp28::fp_is_zero_any(a.c1); }
+__device__ __forceinline__ ec::Fp2 fp2_conj(const ec::Fp2& a) { return ec::Fp2{a.c0, fp28::fp_neg<16>(a.c1)}; }
+
+__device__ __noinline__ ec::Fp2 fp2_pow(const ec::Fp2& a, const uint32_t (&e)[12], int top_bit) {
+    ec::Fp2 acc = a;
+#pragma unroll 1
+    for (int bit = top_bit - 1; bit >= 0; bit--) {
+        acc = G2F::sqr(acc);
+        if ((e[bit >> 5] >> (bit & 31)) & 1) acc = G2F::mul(acc, a);
+    }
+    return acc;
+}
+__device__ __noinline__ void g2_mul_z(ec::Proj<G2F>& r, const ec::Proj<G2F>& p) {
+    r = p;
+#pragma unroll 1
+    for (int bit = 62; bit >= 0; bit--) {
+        ec::Proj<G2F> c = r;
+        ec::proj_add<G2F>(r, c);
+        if ((fp28c::Z_ABS >> bit) & 1) ec::proj_add<G2F>(r, p);
+    }
+}
+__device__ __forceinline__ bool canon_gt_half(const Fp& c) {
+    bool larger = false, decided = false;
+#pragma unroll
+    for (int k = NL - 1; k >= 0; k--) {
+        if (!decided && c.l[k] != fp28c::HALF_P[k]) { larger = c.l[k] > fp28c::HALF_P[k]; decided = true; }
+    }
+    return larger;
+}
+__device__ __forceinline__ bool fp2_lex_largest(const ec::Fp2& y) {  // c1 first, then c0
+    Fp c1 = fp_to_canonical(y.c1);
+    uint32_t z = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) z |= c1.l[k];
+    if (z != 0) return canon_gt_half(c1);
+    return canon_gt_half(fp_to_canonical(y.c0));
+}
+
+__global__ void __launch_bounds__(256) k_deserialize_g2(const uint8_t* __restrict__ bytes, uint32_t n, int compressed, int validate,
+                                                        uint32_t* __restrict__ out_aff, uint8_t* __restrict__ status) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t size = compressed ? 96u : 192u;
+    const uint8_t* b = bytes + (size_t)i * size;
+    uint32_t* o = out_aff + (size_t)i * 48;
+    uint8_t b0 = b[0];
+    uint32_t c_flag = b0 >> 7, i_flag = (b0 >> 6) & 1, s_flag = (b0 >> 5) & 1;
+    uint32_t x1w[12], x0w[12], y1w[12], y0w[12];
+    be48_to_words(x1w, b, 0x1fffffffu);
+    be48_to_words(x0w, b + 48, 0xffffffffu);
+#pragma unroll
+    for (int k = 0; k < 12; k++) { y1w[k] = 0; y0w[k] = 0; }
+    if (!compressed) {
+        be48_to_words(y1w, b + 96, 0xffffffffu);
+        be48_to_words(y0w, b + 144, 0xffffffffu);
+    }
+    uint8_t st = 0;
+    bool is_inf = false;
+    if (c_flag != (uint32_t)(compressed ? 1 : 0)) st = 1;
+    if (st == 0 && i_flag) {
+        uint32_t any = s_flag;
+#pragma unroll
+        for (int k = 0; k < 12; k++) any |= x1w[k] | x0w[k] | y1w[k] | y0w[k];
+        if (any) st = 1;
+        is_inf = true;
+    }
+    if (st == 0 && !is_inf) {
+        bool ok = words_lt_p(x1w) && words_lt_p(x0w);
+        if (!compressed) ok = ok && words_lt_p(y1w) && words_lt_p(y0w) && !s_flag;
+        if (!ok) st = 1;
+    }
+    ec::Fp2 x = G2F::zero(), y = G2F::zero();
+    if (st == 0 && !is_inf) {
+        const Fp r2 = fp28::fp_const(fp28c::R2), four = fp28::fp_const(fp28c::FOUR);
+        x.c0 = fp28::fp_mul_call(fp28::fp_unpack384(x0w), r2);
+        x.c1 = fp28::fp_mul_call(fp28::fp_unpack384(x1w), r2);
+        ec::Fp2 rhs = G2F::add(G2F::mul(G2F::sqr(x), x), ec::Fp2{four, four});     // x^3 + 4(1 + u)   < 4p
+        if (compressed) {
+            ec::Fp2 a1 = fp2_pow(rhs, fp28c::EXP_P3_4_32, 378);                      // (p-3)/4 has its top bit at 378
+            ec::Fp2 x0 = G2F::mul(a1, rhs);
+            ec::Fp2 alpha = G2F::mul(a1, x0);
+            ec::Fp2 ap1 = G2F::add(alpha, G2F::one());
+            if (fp2_is_zero(ap1)) {
+                y = ec::Fp2{fp28::fp_neg<4>(x0.c1), x0.c0};                          // u * x0
+            } else {
+                ec::Fp2 bb = fp2_pow(ap1, fp28c::EXP_P1_2_32, 379);                  // (p-1)/2: top bit 379
+                y = G2F::mul(bb, x0);
+            }
+            if (!fp2_equal(G2F::sqr(y), rhs)) st = 1;                                // not a square: malformed
+            if (fp2_lex_largest(y) != (s_flag != 0)) y = G2F::neg<4>(y);
+        } else {
+            y.c0 = fp28::fp_mul_call(fp28::fp_unpack384(y0w), r2);
+            y.c1 = fp28::fp_mul_call(fp28::fp_unpack384(y1w), r2);
+            if (validate && !fp2_equal(G2F::sqr(y), rhs)) st = 2;
+        }
+        if (st == 0 && validate) {
+            ec::Proj<G2F> p1 = ec::proj_from_affine<G2F>(x, y), q;
+            g2_mul_z(q, p1);                                                          // [|z|] P
+            ec::Fp2 px = G2F::mul(fp2_conj(x), ec::Fp2{fp28::fp_zero(), fp28::fp_const(fp28c::PSI_X1)});
+            ec::Fp2 py = G2F::mul(fp2_conj(y), ec::Fp2{fp28::fp_const(fp28c::PSI_Y0), fp28::fp_const(fp28c::PSI_Y1)});
+            // psi(P) == [z] P = -[|z|] P :  X_q == px Z_q,  Y_q == -py Z_q,  Z_q != 0
+            bool ok = !fp2_is_zero(q.z);
+            ok = ok && fp2_equal(q.x, G2F::mul(px, q.z));
+            ok = ok && fp2_is_zero(G2F::add(q.y, G2F::mul(py, q.z)));
+            if (!ok) st = 3;
+        }
+    }
+    bool keep = st == 0 && !is_inf;
+    ElemIO<ec::Fp2>::to_raw(o, x, keep);
+    ElemIO<ec::Fp2>::to_raw(o + 24, y, keep);
+    status[i] = st;
+}
+
+__device__ __forceinline__ void words_to_be48(uint8_t* d, const uint32_t (&w)[12]) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        uint8_t* q = d + 44 - 4 * k;
+        q[0] = (uint8_t)(w[k] >> 24); q[1] = (uint8_t)(w[k] >> 16); q[2] = (uint8_t)(w[k] >> 8); q[3] = (uint8_t)w[k];
+    }
+}
+__global__ void __launch_bounds__(256) k_serialize_g2(const uint32_t* __restrict__ aff, uint32_t n, int compressed, uint8_t* __restrict__ bytes) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* q = aff + (size_t)i * 48;
+    const uint32_t size = compressed ? 96u : 192u;
+    uint8_t* b = bytes + (size_t)i * size;
+    uint32_t any = 0;
+#pragma unroll 4
+    for (int k = 0; k < 48; k++) any |= q[k];
+    for (uint32_t k = 0; k < size; k++) b[k] = 0;
+    if (any == 0) {
+        b[0] = compressed ? 0xC0 : 0x40;
+        return;
+    }
+    ec::Fp2 x, y;
+    ElemIO<ec::Fp2>::from_raw(x, q);
+    ElemIO<ec::Fp2>::from_raw(y, q + 24);
+    uint32_t w[12];
+    fp28::fp_pack384(w, fp_to_canonical(x.c1)); words_to_be48(b, w);
+    fp28::fp_pack384(w, fp_to_canonical(x.c0)); words_to_be48(b + 48, w);
+    if (!compressed) {
+        fp28::fp_pack384(w, fp_to_canonical(y.c1)); words_to_be48(b + 96, w);
+        fp28::fp_pack384(w, fp_to_canonical(y.c0)); words_to_be48(b + 144, w);
+    } else {
+        b[0] |= (uint8_t)(0x80 | (fp2_lex_largest(y) ? 0x20 : 0));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- field test hook
+#if defined(MI_TEST_HOOKS)
+__global__ void __launch_bounds__(256) k_test_fp_op(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                    uint32_t* __restrict__ out, uint32_t n) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t aw[12], bw[12], ow[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) { aw[k] = a[(size_t)i * 12 + k]; bw[k] = b[(size_t)i * 12 + k]; }
+    Fp x = fp28::fp_from_blst(aw), y = fp28::fp_from_blst(bw), z;
+    if (op == 0) z = fp28::fp_mul_call(x, y);
+    else if (op == 1) z = fp28::fp_sqr(x);
+    else if (op == 2) z = fp28::fp_add(x, y);
+    else z = fp28::fp_sub<4>(x, y);
+    
+    fp28::fp_to_blst(ow, z);
+#pragma unroll
+    for (int k = 0; k < 12; k++) out[(size_t)i * 12 + k] = ow[k];
+}
+
+#endif
+
+}  // namespace msmk

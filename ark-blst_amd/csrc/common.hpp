@@ -1,0 +1,321 @@
+// Host-side state shared by the translation units of the C-ABI library (see include/arkblst_amd.h).
+//
+// One mi_ctx owns, per device: streams, a resident base set in device form, and reusable scratch (histogram / offsets /
+// sorted indices / buckets / chunk sums) sized for the largest call seen so far — the reference rebuilds its program
+// and re-allocates every buffer on every call (/root/reference/src/gpu.rs:148-156,235).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/arkblst_amd.h"
+#include "host_curve.hpp"
+
+namespace mi {
+
+struct HipFail {
+    std::string msg;
+    bool oom = false;
+};
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) {                                                                           \
+            char _b[512];                                                                                 \
+            snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            throw ::mi::HipFail{_b, _e == hipErrorOutOfMemory};                                           \
+        }                                                                                                 \
+    } while (0)
+
+// Test builds (-DMI_TEST_HOOKS, libarkblst_amd_test.so) can make the next device allocations fail, to prove that an
+// allocation failure anywhere (worker threads included) comes back as MI_E_NOMEM instead of an abort.
+#if defined(MI_TEST_HOOKS)
+extern std::atomic<int> g_fail_allocs;   // > 0: that many upcoming DevBuf::ensure calls that need to grow will throw
+#endif
+
+struct Plan {
+    uint32_t c, nwin;     // window bits, digit windows = ceil(256 / c)
+    uint32_t bwin;        // bucket sets: nwin, or 1 when all windows share one (precomputed tables)
+    uint32_t nb, logL, chunks_per_win, logT, lo_bits;
+    uint64_t nbuckets, nchunks;
+    uint32_t chunk_log;   // log2 of the buckets one reduce wave covers
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+#if defined(MI_TEST_HOOKS)
+        if (g_fail_allocs.load() > 0 && g_fail_allocs.fetch_sub(1) > 0) throw HipFail{"injected allocation failure (test hook): out of memory", true};
+#endif
+        if (p) HIP_TRY(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        HIP_TRY(hipMalloc(&p, bytes));
+        cap = bytes;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// resident bases (device form) of one device, per group: [0] = G1, [1] = G2.  Shared by the context's lanes.
+struct Resident {
+    DevBuf buf, flags;   // device-form points; one byte per point: 1 = point at infinity
+    size_t n = 0;        // points resident on this device
+    size_t lo = 0;       // global index of the first resident point
+    uint32_t tables = 1; // 1 = plain bases; W > 1 = precomputed 2^(c j) P_i tables, j < W (see mi_msm_g1_set_bases_precomputed)
+    uint32_t table_c = 0;// window size the tables were built for
+};
+
+// Per-device state of ONE LANE of a context: stream, events and scratch.  A context has two lanes per device so that two
+// host threads (arkworks calls the trait method from rayon workers) overlap: one call's sort / reduce / host tail runs
+// under the other's accumulate kernel.  The resident bases are shared.
+struct DevState {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[12] = {};
+    Resident* res = nullptr;   // -> mi_ctx::residents[device][2]
+    // scratch
+    DevBuf raw, call_bases, call_flags, scalars, hist, offsets, woff, meta, sched, sorted, partial, order, item_bucket, pairs, pairs2;
+    DevBuf tilecnt, bin_tot, bin_base, coarse, seg_cnt, seg_base, segcnt, merge_list;
+    DevBuf pr_p, pr_q, pr_lvl[2], pr_raw, pr_lines;   // pairing: inputs, tree levels, top values, line coefficients
+    void* h_pairs = nullptr;   // pinned host staging: window sums (D2H) and the schedule's item counts
+    size_t h_pairs_cap = 0;
+    uint32_t* h_meta = nullptr;   // pinned, 16 B
+    mi_profile prof{};
+
+    void ensure_host(size_t bytes) {
+        if (bytes <= h_pairs_cap) return;
+        if (h_pairs) (void)hipHostFree(h_pairs);
+        h_pairs = nullptr;
+        h_pairs_cap = 0;
+        HIP_TRY(hipHostMalloc(&h_pairs, bytes, hipHostMallocDefault));
+        h_pairs_cap = bytes;
+    }
+    template <class Fn> void for_each_buf(Fn fn) {
+        for (DevBuf* b : {&raw, &call_bases, &call_flags, &scalars, &hist, &offsets, &woff, &meta, &sched, &sorted, &partial, &order, &item_bucket,
+                          &pairs, &pairs2, &tilecnt, &bin_tot, &bin_base, &coarse, &seg_cnt, &seg_base, &segcnt, &merge_list, &pr_p, &pr_q, &pr_lvl[0],
+                          &pr_lvl[1], &pr_raw, &pr_lines})
+            fn(*b);
+    }
+};
+
+constexpr int NLANES = 2;
+
+// One persistent host thread per device of a multi-device context: the calling thread posts one job per device and
+// waits; nothing is spawned per call (a std::thread per device per call cost 1.4 ms for 0.2 ms of work).
+class DeviceWorkers {
+public:
+    explicit DeviceWorkers(size_t n) : slots_(n) {
+        for (size_t k = 0; k < n; k++) threads_.emplace_back([this, k] { loop(k); });
+    }
+    ~DeviceWorkers() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    DeviceWorkers(const DeviceWorkers&) = delete;
+    DeviceWorkers& operator=(const DeviceWorkers&) = delete;
+    size_t size() const { return threads_.size(); }
+    // Runs fn(k) on worker k for every k and returns when all are done.  fn must not throw (callers wrap it).
+    // One run at a time per worker set (callers hold a lane of the context).
+    void run(const std::function<void(size_t)>& fn) {
+        std::unique_lock<std::mutex> lk(mu_);
+        fn_ = &fn;
+        pending_ = slots_.size();
+        for (auto& s : slots_) s = true;
+        cv_.notify_all();
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void loop(size_t k) {
+        for (;;) {
+            const std::function<void(size_t)>* fn;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || slots_[k]; });
+                if (stop_) return;
+                slots_[k] = false;
+                fn = fn_;
+            }
+            (*fn)(k);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--pending_ == 0) done_cv_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::vector<char> slots_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t pending_ = 0;
+    bool stop_ = false;
+};
+
+}  // namespace mi
+
+struct mi_ctx {
+    std::vector<mi::DevState> devs;                              // lane 0 (also used by every non-MSM entry point)
+    std::vector<mi::DevState> devs_b;                            // lane 1
+    std::vector<std::array<mi::Resident, 2>> residents;          // per device
+    std::unique_ptr<mi::DeviceWorkers> workers[mi::NLANES];      // multi-device contexts only: one thread per device and lane
+    std::mutex lane_mu;                                          // lane bookkeeping
+    std::condition_variable lane_cv;
+    bool lane_busy[mi::NLANES] = {false, false};
+    mutable std::mutex info_mu;                                  // prof / err
+    unsigned forced_c = 0;
+    mi_profile prof{};
+    std::string err;
+#if defined(MI_TEST_HOOKS)
+    unsigned test_pairing_share = 0, test_pairing_batch = 0;
+    bool test_pairing_single_lane = false;
+    size_t test_max_part = 0;   // points per pass of the pipeline (0 = the built-in limit)
+#endif
+};
+
+namespace mi {
+
+// An MSM call takes ONE free lane (two calls run concurrently); everything that touches the resident bases or the
+// shared settings takes BOTH (exclusive).
+struct LaneLock {
+    mi_ctx* c;
+    int lane;   // 0 / 1, or -1 = both
+    LaneLock(mi_ctx* ctx, bool exclusive) : c(ctx), lane(-1) {
+        std::unique_lock<std::mutex> lk(c->lane_mu);
+        if (exclusive) {
+            c->lane_cv.wait(lk, [&] { return !c->lane_busy[0] && !c->lane_busy[1]; });
+            c->lane_busy[0] = c->lane_busy[1] = true;
+        } else {
+            c->lane_cv.wait(lk, [&] { return !c->lane_busy[0] || !c->lane_busy[1]; });
+            lane = c->lane_busy[0] ? 1 : 0;
+            c->lane_busy[lane] = true;
+        }
+    }
+    ~LaneLock() {
+        {
+            std::lock_guard<std::mutex> lk(c->lane_mu);
+            if (lane < 0) c->lane_busy[0] = c->lane_busy[1] = false;
+            else c->lane_busy[lane] = false;
+        }
+        c->lane_cv.notify_all();
+    }
+    LaneLock(const LaneLock&) = delete;
+    LaneLock& operator=(const LaneLock&) = delete;
+    std::vector<DevState>& devs() { return lane == 1 ? c->devs_b : c->devs; }
+    DeviceWorkers* workers() { return c->workers[lane == 1 ? 1 : 0].get(); }
+};
+
+inline void set_prof(mi_ctx* ctx, const mi_profile& p) {
+    std::lock_guard<std::mutex> lk(ctx->info_mu);
+    ctx->prof = p;
+}
+
+inline double ev_ms(hipEvent_t a, hipEvent_t b) {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    return ms;
+}
+
+// The text of the calling thread's most recent failure: mi_msm_last_error() hands out a pointer that stays valid until
+// the same thread fails again, whatever other threads do on the context (two lanes can fail concurrently).
+inline std::string& tls_error() {
+    static thread_local std::string e;
+    return e;
+}
+
+inline int fail(mi_ctx* ctx, int code, const std::string& msg) {
+    tls_error() = msg;
+    if (ctx) {
+        std::lock_guard<std::mutex> lk(ctx->info_mu);
+        ctx->err = msg;
+    }
+    return code;
+}
+
+// Nothing may cross the C ABI as an exception (include/arkblst_amd.h): every entry point body runs inside guarded().
+template <class Fn>
+int guarded(mi_ctx* ctx, Fn fn) {
+    try {
+        return fn();
+    } catch (const HipFail& e) {
+        bool oom = e.oom || e.msg.find("out of memory") != std::string::npos;
+        return fail(ctx, oom ? MI_E_NOMEM : MI_E_HIP, e.msg);
+    } catch (const std::bad_alloc&) {
+        return fail(ctx, MI_E_NOMEM, "host allocation failed");
+    } catch (const std::exception& e) {
+        return fail(ctx, MI_E_HIP, std::string("unexpected exception: ") + e.what());
+    } catch (...) {
+        return fail(ctx, MI_E_HIP, "unexpected exception");
+    }
+}
+
+// Per-device share of a call: what a worker reports back instead of throwing (a throw inside a std::thread is std::terminate).
+struct PartErr {
+    int code = MI_OK;
+    std::string msg;
+};
+template <class Fn>
+void guarded_part(PartErr& e, Fn fn) noexcept {
+    try {
+        fn();
+    } catch (const HipFail& f) {
+        e.code = (f.oom || f.msg.find("out of memory") != std::string::npos) ? MI_E_NOMEM : MI_E_HIP;
+        e.msg = f.msg;
+    } catch (const std::bad_alloc&) {
+        e.code = MI_E_NOMEM;
+        e.msg = "host allocation failed";
+    } catch (const std::exception& x) {
+        e.code = MI_E_HIP;
+        e.msg = std::string("unexpected exception: ") + x.what();
+    } catch (...) {
+        e.code = MI_E_HIP;
+        e.msg = "unexpected exception";
+    }
+}
+
+// fn(k) for every device k of the lane: inline for one device, on the lane's persistent workers otherwise
+template <class Fn>
+void for_each_device(LaneLock& lane, size_t g, Fn fn) {
+    DeviceWorkers* w = lane.workers();
+    if (g == 1 || !w) {
+        for (size_t k = 0; k < g; k++) fn(k);
+    } else {
+        std::function<void(size_t)> f = fn;
+        w->run(f);
+    }
+}
+
+// contiguous shard [lo, hi) of n items for device k of g
+inline void shard_range(size_t n, size_t g, size_t k, size_t& lo, size_t& hi) {
+    size_t per = (n + g - 1) / g;
+    lo = std::min(n, k * per);
+    hi = std::min(n, lo + per);
+}
+
+}  // namespace mi

@@ -1,0 +1,523 @@
+// Curve-generic kernels of the MSM pipeline (ingest, accumulate, merge, reduce, combine) and normalize_batch.
+#pragma once
+#include "kernels_common.cuh"
+
+namespace msmk {
+
+// ---------------------------------------------------------------------------------------------- ingest
+// raw: n affine points in the reference's form.  One thread per point.
+template <class C>
+__global__ void __launch_bounds__(256) k_ingest(const uint32_t* __restrict__ raw, uint32_t* __restrict__ out,
+                                                uint8_t* __restrict__ inf_flags, uint32_t n) {
+    using E = typename C::F::E;
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* q = raw + (size_t)i * Geo<C>::RAW_AFF;
+    uint32_t any = 0;
+#pragma unroll 4
+    for (int k = 0; k < Geo<C>::RAW_AFF; k++) any |= q[k];
+    E x, y;
+    ElemIO<E>::from_raw(x, q);
+    ElemIO<E>::from_raw(y, q + ElemIO<E>::RAW);
+    uint32_t* o = out + (size_t)i * Geo<C>::PT_WORDS;
+    ElemIO<E>::store(o, x);
+    ElemIO<E>::store(o + Geo<C>::SLOT, y, any == 0 ? 1u : 0u);
+    inf_flags[i] = any == 0 ? 1 : 0;   // compact copy for the sort passes (a 4-byte read per 128-byte point costs a line)
+}
+
+// ---------------------------------------------------------------------------------------------- accumulate
+template <class C>
+__device__ __forceinline__ void load_point(typename C::F::E& x, typename C::F::E& y, const uint32_t* bases, uint32_t ent) {
+    using E = typename C::F::E;
+    const uint32_t* p = bases + (size_t)(ent & 0x7fffffffu) * Geo<C>::PT_WORDS;
+    ElemIO<E>::load(x, p);
+    ElemIO<E>::load(y, p + Geo<C>::SLOT);
+}
+
+// One lane per WORK ITEM = (bucket, chunk): item i of bucket b covers entries
+// sorted[offsets[b] + k*T .. min(offsets[b] + (k+1)*T, offsets[b+1])), k = i - woff[b]; entries are (index | sign<<31).
+// Hot loop: XYZZ mixed additions.  Register budget is the constraint (256 VGPRs at 2 waves/SIMD), so the next
+// point is not staged in registers: its index is fetched one iteration ahead and its line(s) touched early so the
+// real load hits L2; the other resident wave covers what latency is left (staging the next point in 28 more
+// registers was measured slower: 3.06 vs 2.88 ms, it pushes the loop into scratch spills).
+// A lane that meets an exceptional pair (same x) leaves the hot loop and finishes on the complete formulas.
+// Output: partial[i] (projective), i = natural item id.
+template <class C>
+__global__ void __launch_bounds__(256, C::OCC) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                            const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ woff,
+                                                            const uint32_t* __restrict__ order, const uint32_t* __restrict__ item_bucket,
+                                                            uint32_t nitems, uint32_t logT, uint32_t* __restrict__ partial) {
+    using F = typename C::F;
+    using FA = typename C::FA;
+    using E = typename F::E;
+    uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nitems) return;
+    uint32_t i = order[j];          // items are processed longest class first; partial[] keeps natural item order
+    uint32_t b = item_bucket[i];
+    uint32_t k = i - woff[b];
+    uint32_t e = offsets[b] + (k << logT), bend = offsets[b + 1];
+    uint32_t end = e + (1u << logT) < bend ? e + (1u << logT) : bend;
+    ec::Xyzz<FA> acc;
+    acc.x = F::zero(); acc.y = F::zero(); acc.zz = F::zero(); acc.zzz = F::zero();
+    bool inf = true;
+    uint32_t nent = e < end ? sorted[e] : 0u;
+    while (e < end) {
+        uint32_t ent = nent;
+        E x, y;
+        load_point<C>(x, y, bases, ent);
+        if (e + 1 < end) {
+            nent = sorted[e + 1];
+            __builtin_prefetch(bases + (size_t)(nent & 0x7fffffffu) * Geo<C>::PT_WORDS, 0, 1);
+        }
+        y = F::select((ent >> 31) != 0, y, FA::template neg_l<4>(y));
+        if (inf) {
+            acc.x = x; acc.y = FA::norm(y); acc.zz = F::one(); acc.zzz = F::one();   // acc.y must be subtractable: N-form
+            inf = false;
+        } else if (ec::xyzz_madd<FA>(acc, x, y)) {
+            break;  // exceptional pair at entry e: acc untouched
+        }
+        e++;
+    }
+    ec::Proj<F> out = ec::proj_inf<F>();
+    if (!inf) out = ec::xyzz_to_proj<F>(reinterpret_cast<const ec::Xyzz<F>&>(acc));
+    while (e < end) {  // cold path (never taken on random inputs): complete additions
+        uint32_t ent = sorted[e];
+        E x, y;
+        load_point<C>(x, y, bases, ent);
+        y = F::select((ent >> 31) != 0, y, F::template neg<4>(y));
+        ec::Proj<F> q = ec::proj_from_affine<F>(x, y);
+        ec::proj_add<F>(out, q);  // shared-call multiplier: keeps the cold path out of the hot loop's register budget
+        e++;
+    }
+    store_bucket<C>(partial + (size_t)i * Geo<C>::BK_WORDS, out);
+}
+
+// One binary-tree level of the per-bucket merge of split buckets: partial[i] += partial[i + d] for the items whose
+// chunk index is a multiple of 2d.  After ceil(log2(max items)) levels partial[woff[b]] is bucket b.  Launched only
+// when some bucket was split (meta[1] > 1), over the items of split buckets only (merge_list, meta[3] entries).
+template <class C>
+__global__ void __launch_bounds__(256, 1) k_merge(uint32_t* __restrict__ partial, const uint32_t* __restrict__ item_bucket,
+                                                       const uint32_t* __restrict__ woff, const uint32_t* __restrict__ merge_list,
+                                                       uint32_t nlist, uint32_t d) {
+    uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nlist) return;
+    uint32_t i = merge_list[j];
+    uint32_t b = item_bucket[i];
+    uint32_t n = woff[b + 1] - woff[b];
+    if (n <= d) return;
+    uint32_t k = i - woff[b];
+    if ((k & (2 * d - 1)) != 0 || k + d >= n) return;
+    auto a = load_bucket<C>(partial + (size_t)i * Geo<C>::BK_WORDS);
+    auto c = load_bucket<C>(partial + (size_t)(i + d) * Geo<C>::BK_WORDS);
+    add_inplace(a, c);
+    store_bucket<C>(partial + (size_t)i * Geo<C>::BK_WORDS, a);
+}
+
+// ---------------------------------------------------------------------------------------------- precomputed tables
+// T_j[i] = 2^c T_{j-1}[i] for a resident base set (mi_msm_g{1,2}_set_bases_precomputed): c complete doublings per point, then one
+// batch inversion (the product tree of normalize_batch) back to affine.  Neither curve group has points of even order (both
+// cofactors are odd), so a multiple of a finite point is finite; a Z of zero (input not on the curve) is kept out of the
+// shared inversion and only spoils its own entry.
+template <class C>
+__global__ void __launch_bounds__(256) k_table_dbl(const uint32_t* __restrict__ prev, const uint8_t* __restrict__ inf_flags, uint32_t n, uint32_t c,
+                                                   uint32_t* __restrict__ proj, uint32_t* __restrict__ vals) {
+    using F = typename C::F;
+    using E = typename F::E;
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    E x, y;
+    load_point<C>(x, y, prev, i);
+    ec::Proj<F> p = ec::proj_from_affine<F>(x, y);
+#pragma unroll 1
+    for (uint32_t k = 0; k < c; k++) {
+        ec::Proj<F> q = p;
+        add_inplace(p, q);
+    }
+    store_bucket<C>(proj + (size_t)i * Geo<C>::BK_WORDS, p);
+    bool skip = inf_flags[i] != 0 || F::is_zero_2p(p.z);
+    ElemIO<E>::store(vals + (size_t)i * Geo<C>::SLOT, F::select(skip, p.z, F::one()));
+}
+template <class C>
+__global__ void __launch_bounds__(256) k_table_affine(const uint32_t* __restrict__ proj, const uint32_t* __restrict__ zinv,
+                                                      const uint8_t* __restrict__ inf_flags, uint32_t n, uint32_t* __restrict__ out) {
+    using F = typename C::F;
+    using E = typename F::E;
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    ec::Proj<F> p = load_bucket<C>(proj + (size_t)i * Geo<C>::BK_WORDS);
+    E zi;
+    ElemIO<E>::load(zi, zinv + (size_t)i * Geo<C>::SLOT);
+    uint32_t* o = out + (size_t)i * Geo<C>::PT_WORDS;
+    ElemIO<E>::store(o, F::mul(p.x, zi));
+    ElemIO<E>::store(o + Geo<C>::SLOT, F::mul(p.y, zi), inf_flags[i] != 0 ? 1u : 0u);
+}
+
+// ---------------------------------------------------------------------------------------------- reduce + combine
+// Bucket reduction with SEVERAL LANES PER LOGICAL LANE.  A complete projective addition is 12 multiplications on one
+// lane (5200 instructions, 17 us for a lone wave); the reduction is a dependent chain of them, so the step time sets the
+// kernel time.  A "coop scheme" CS splits one addition over the lanes of a small lane group:
+//   QuadG1   (G1): the lanes 0..2 of a quad hold X, Y, Z of a point (lane 3 mirrors lane 2).  Step 1: lane q computes
+//            own_q = a_q b_q and cross_q = (a_q + a_q')(b_q + b_q'), q' = q+1 mod 3 (partner coordinates by DPP quad_perm);
+//            step 2: the six values are broadcast inside the quad and lane q computes output coordinate q as ONE fused
+//            two-product reduction.  2 multiplications + 1 fused pair per lane instead of 6 + 3: ~1800 instructions per step,
+//            a third of the registers (two waves per SIMD), 16 logical lanes per wave.
+//   PairG2   (G2): the even lane holds c0, the odd lane c1 of every Fp2 coordinate (CoopF2, coop_fp2.cuh): 32 logical lanes.
+// A scheme provides: LOG_LL (log2 logical lanes per wave), LPL (lanes per logical lane), Pt (per-lane state of a point),
+// inf / add / select / load (device bucket layout) / store / shfl_down / bcast0 / store_jac_raw.
+struct QuadG1 {
+    using C = G1C;
+    static constexpr int LOG_LL = 4, LPL = 4, MAX_OCC = 2;
+    struct Pt { Fp c; };
+    static __device__ __forceinline__ uint32_t q() { return threadIdx.x & 3u; }
+    static __device__ __forceinline__ uint32_t ll() { return (threadIdx.x & 63u) >> 2; }
+    template <int CTRL>
+    static __device__ __forceinline__ Fp dpp(const Fp& a) {
+        Fp r;
+#pragma unroll
+        for (int k = 0; k < NL; k++) r.l[k] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.l[k], CTRL, 0xF, 0xF, true);
+        return r;
+    }
+    static constexpr int NEXT = 0xC9;                                    // quad_perm [1,2,0,3]: lane q reads coordinate q+1 mod 3
+    static constexpr int B0 = 0x00, B1 = 0x55, B2 = 0xAA;                // broadcast of lane 0 / 1 / 2 inside the quad
+    static __device__ __forceinline__ Pt inf() { return Pt{fp28::fp_select(q() == 1, fp28::fp_zero(), fp28::fp_one())}; }   // (0 : 1 : 0)
+    static __device__ __forceinline__ Pt select(bool take_b, const Pt& a, const Pt& b) { return Pt{fp28::fp_select(take_b, a.c, b.c)}; }
+    static __device__ __forceinline__ Pt load(const uint32_t* bucket) {   // 3 slots of 16 words: X | Y | Z
+        uint32_t s = q() < 2 ? q() : 2;
+        Pt r;
+        load_fp16(r.c, bucket + 16 * s);
+        return r;
+    }
+    static __device__ __forceinline__ void store(uint32_t* bucket, const Pt& p) {
+        if (q() < 3) store_fp16(bucket + 16 * q(), p.c);
+    }
+    static __device__ __forceinline__ Pt shfl_down(const Pt& a, int d) { return Pt{shfl_down_fp(a.c, 4 * d)}; }   // logical lane ll + d
+    static __device__ __forceinline__ Pt from_ll(const Pt& a, int src) {                                           // value of logical lane src
+        Pt r;
+#pragma unroll
+        for (int k = 0; k < NL; k++) r.c.l[k] = __shfl(a.c.l[k], 4 * src + (int)q(), 64);
+        return r;
+    }
+    // a <- a + b, complete (RCB16 Alg. 7, the formulas of ec::proj_add; the same values, hence the same bounds)
+    static __device__ __forceinline__ void add(Pt& a, const Pt& b) {
+        using namespace fp28;
+        const bool is2 = q() >= 2, is0 = q() == 0;
+        Fp an = dpp<NEXT>(a.c), bn = dpp<NEXT>(b.c);
+        Fp own = fp_mul(a.c, b.c);                                        // t0 | t1 | t2
+        Fp cross = fp_mul(fp_add(a.c, an), fp_add(b.c, bn));              // t3 | t4 | t5
+        cross = fp_sub<8>(cross, fp_add(own, dpp<NEXT>(own)));            // X1Y2+X2Y1 | Y1Z2+Y2Z1 | X1Z2+X2Z1
+        Fp t0 = fp_mul_small<3>(dpp<B0>(own));                            // 3 X1X2
+        Fp t1 = dpp<B1>(own);
+        Fp t2 = fp_mul_small<12>(dpp<B2>(own));                           // b3 Z1Z2
+        Fp u = fp_add(t1, t2);
+        Fp t1m = fp_sub<32>(t1, t2);
+        Fp t3 = dpp<B0>(cross), t4 = dpp<B1>(cross);
+        Fp t5 = fp_mul_small<12>(dpp<B2>(cross));
+        // X3 = t1m t3 - t5 t4 ; Y3 = t1m u + t5 t0 ; Z3 = u t4 + t0 t3
+        Fp A1 = fp_select(is2, t1m, u);
+        Fp B1v = fp_select(is0, fp_select(is2, u, t4), t3);
+        Fp A2 = fp_select(is2, t5, t0);
+        Fp B2v = fp_select(is0, fp_select(is2, t0, t3), fp_neg<16>(t4));
+        a.c = fp_mul2add(A1, B1v, A2, B2v);
+    }
+    // logical lane's point -> Jacobian in the reference's form (X Z, Y Z^2, Z); infinity (Z == 0 mod p) -> all-zero
+    static __device__ __forceinline__ void store_jac_raw(uint32_t* out, const Pt& p) {
+        using namespace fp28;
+        Fp z = dpp<B2>(p.c);
+        Fp zz = fp_sqr(z);
+        Fp v = fp_select(q() >= 2, fp_mul(p.c, fp_select(q() == 0, zz, z)), p.c);
+        uint32_t w[12], any = 0;
+        fp_to_blst(w, v);
+#pragma unroll
+        for (int k = 0; k < 12; k++) any |= w[k];
+        any = (uint32_t)__builtin_amdgcn_mov_dpp((int)any, B2, 0xF, 0xF, true);   // Z's words
+        if (q() < 3) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) out[12 * q() + k] = any != 0 ? w[k] : 0u;
+        }
+    }
+};
+
+struct PairG2 {
+    using C = G2C;
+    using F = CoopF2;
+    static constexpr int LOG_LL = 5, LPL = 2, MAX_OCC = 1;
+    using Pt = ec::Proj<F>;
+    static __device__ __forceinline__ uint32_t h() { return threadIdx.x & 1u; }
+    static __device__ __forceinline__ uint32_t ll() { return (threadIdx.x & 63u) >> 1; }
+    static __device__ __forceinline__ Pt inf() { return ec::proj_inf<F>(); }
+    static __device__ __forceinline__ Pt select(bool take_b, const Pt& a, const Pt& b) { return ec::proj_select<F>(take_b, a, b); }
+    static __device__ __forceinline__ Pt load(const uint32_t* bucket) {   // x | y | z, each (c0, c1) in 16-word slots
+        const uint32_t* p = bucket + 16 * h();
+        Pt r;
+        load_fp16(r.x, p); load_fp16(r.y, p + 32); load_fp16(r.z, p + 64);
+        return r;
+    }
+    static __device__ __forceinline__ void store(uint32_t* bucket, const Pt& p) {
+        uint32_t* o = bucket + 16 * h();
+        store_fp16(o, p.x); store_fp16(o + 32, p.y); store_fp16(o + 64, p.z);
+    }
+    static __device__ __forceinline__ Pt shfl_down(const Pt& a, int d) {
+        Pt r;
+        r.x = shfl_down_fp(a.x, 2 * d); r.y = shfl_down_fp(a.y, 2 * d); r.z = shfl_down_fp(a.z, 2 * d);
+        return r;
+    }
+    static __device__ __forceinline__ Fp from_fp(const Fp& a, int src) {
+        Fp r;
+#pragma unroll
+        for (int k = 0; k < NL; k++) r.l[k] = __shfl(a.l[k], 2 * src + (int)h(), 64);
+        return r;
+    }
+    static __device__ __forceinline__ Pt from_ll(const Pt& a, int src) { return Pt{from_fp(a.x, src), from_fp(a.y, src), from_fp(a.z, src)}; }
+    static __device__ __forceinline__ void add(Pt& a, const Pt& b) { ec::proj_add<F>(a, b); }
+    static __device__ __forceinline__ void store_jac_raw(uint32_t* out, const Pt& p) {   // this lane's component of (X Z, Y Z^2, Z)
+        uint32_t* o = out + 12 * h();
+        uint32_t zw[12];
+        fp28::fp_to_blst(zw, p.z);
+        uint32_t any = 0;
+#pragma unroll
+        for (int t = 0; t < 12; t++) any |= zw[t];
+        any |= (uint32_t)__builtin_amdgcn_mov_dpp((int)any, 0xB1, 0xF, 0xF, true);   // either component non-zero
+        Fp zz = F::sqr(p.z);
+        fp_to_raw(o, F::mul(p.x, p.z), any != 0);
+        fp_to_raw(o + 24, F::mul(p.y, zz), any != 0);
+#pragma unroll
+        for (int t = 0; t < 12; t++) o[48 + t] = any != 0 ? zw[t] : 0u;
+    }
+};
+template <class C> struct CoopOf;
+template <> struct CoopOf<G1C> { using CS = QuadG1; };
+template <> struct CoopOf<G2C> { using CS = PairG2; };
+
+// One wave per chunk of K = NLL * L consecutive buckets of one window (NLL = 2^LOG_LL logical lanes, L = 2^logL).  Logical lane l
+// owns buckets [l L, l L + L) of the chunk.  Output per chunk, in the device bucket layout: pairs[2 chunk] = K * S with
+// S = sum B, pairs[2 chunk + 1] = T = sum (rel + 1) B, rel = index inside the chunk.
+//
+// The whole reduction is ONE loop with ONE inlined addition site: the operands of step s are selected by the (wave-uniform)
+// step number (an out-of-line addition passes its operands through scratch; several inlined sites would multiply the code).
+//   [0, 2L)            t = L-1 .. 0 :  run += B_t ;  acc += run          (lane-serial running sums)
+//   LOG_LL steps       run += shfl_down(run, 1, 2, 4, ..)                 (suffix scan: run_l = sum_{j>=l} S_j)
+//   logL steps         LP = 2 LP  (LP starts as run)                      (L * P_l)
+//   one step           acc += (l == 0 ? inf : LP)                         (V_l = T_l + L P_l)
+//   LOG_LL steps       acc += shfl_down(acc, NLL/2, .., 1)                (sum over lanes)
+// The last logical lane is idle in the final butterfly after its value has been read in the first step: it doubles
+// LP_0 = L * S there, LOG_LL times, which gives K * S without a single extra step ("rider").
+template <class CS>
+__global__ void __launch_bounds__(64, CS::MAX_OCC) k_reduce_coop(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ woff,
+                                                                 uint32_t* __restrict__ pairs, uint32_t logL) {
+    using Pt = typename CS::Pt;
+    constexpr int NLL = 1 << CS::LOG_LL, BK = Geo<typename CS::C>::BK_WORDS;
+    const uint32_t chunk = blockIdx.x, ll = CS::ll();
+    const uint32_t L = 1u << logL;
+    const uint32_t* wp = woff + (size_t)chunk * NLL * L + (size_t)ll * L;   // bucket b lives at partial[woff[b]]
+    Pt run = CS::inf(), acc = CS::inf(), LP = CS::inf();
+    const uint32_t s_scan = 2 * L, s_dbl = s_scan + CS::LOG_LL, s_comb = s_dbl + logL, s_end = s_comb + 1 + CS::LOG_LL;
+    const bool rider = ll == NLL - 1;
+#pragma unroll 1
+    for (uint32_t s = 0; s < s_end; s++) {
+        Pt A, B;
+        uint32_t dst;  // 0 run, 1 acc, 2 LP
+        if (s < s_scan) {
+            if ((s & 1u) == 0) {
+                A = run; B = CS::load(partial + (size_t)wp[L - 1 - (s >> 1)] * BK); dst = 0;
+            } else {
+                A = acc; B = run; dst = 1;
+            }
+        } else if (s < s_dbl) {
+            int d = 1 << (s - s_scan);
+            A = run;
+            B = CS::select((int)ll + d < NLL, CS::inf(), CS::shfl_down(run, d));
+            dst = 0;
+        } else if (s < s_comb) {
+            if (s == s_dbl) LP = run;
+            A = LP; B = LP; dst = 2;
+        } else if (s == s_comb) {
+            if (logL == 0) LP = run;
+            A = acc;
+            B = CS::select(ll == 0, LP, CS::inf());
+            dst = 1;
+        } else {
+            int k = s - s_comb - 1, d = (NLL / 2) >> k;
+            Pt sh = CS::shfl_down(acc, d);
+            A = acc;
+            B = CS::select((int)ll < d, CS::inf(), sh);
+            if (k == 0) A = CS::select(rider, A, CS::from_ll(LP, 0));   // rider: start from LP_0 = L * S (k is wave-uniform: the
+            B = CS::select(rider, B, A);                                 // shuffle runs with every lane active, after acc was read)
+            dst = 1;
+        }
+        CS::add(A, B);
+        if (dst == 0) run = A;
+        else if (dst == 1) acc = A;
+        else LP = A;
+    }
+    if (rider) CS::store(pairs + (size_t)(2 * chunk) * BK, acc);
+    if (ll == 0) CS::store(pairs + (size_t)(2 * chunk + 1) * BK, acc);
+}
+
+// One level of the per-window combine: a wave takes NLL consecutive pairs (S'_j, T_j) of one window (S'_j = K S_j already
+// scaled by the element size K of this level) and leaves ONE pair for the next level:
+//   T_out = sum_j T_j + sum_{j >= 1} P'_j,  P'_j = sum_{i >= j} S'_i  (= sum_j (T_j + j K S_j)),   S'_out = NLL * P'_0.
+//   LOG_LL steps  run += shfl_down(run, 1, 2, ..)     suffix scan of S'
+//   one step      acc = T + (l == 0 ? inf : run)
+//   LOG_LL steps  butterfly over the lanes; the last logical lane doubles P'_0 meanwhile (rider, as in k_reduce_coop)
+// cpw_in pairs per window come in, cpw_out = ceil(cpw_in / NLL) go out.  With jac_out != nullptr (last level, cpw_out == 1) the
+// window sum is written as a Jacobian point in the reference's form instead: the host does only the Horner fold over the
+// windows (/root/reference/src/gpu.rs:193-209 does the whole tail on the host).  grid = nwin * cpw_out waves.
+template <class CS>
+__global__ void __launch_bounds__(64, CS::MAX_OCC) k_combine(const uint32_t* __restrict__ pairs_in, uint32_t cpw_in, uint32_t cpw_out,
+                                                             uint32_t* __restrict__ pairs_out, uint32_t* __restrict__ jac_out) {
+    using Pt = typename CS::Pt;
+    constexpr int NLL = 1 << CS::LOG_LL, BK = Geo<typename CS::C>::BK_WORDS, RJ = Geo<typename CS::C>::RAW_JAC;
+    const uint32_t w = blockIdx.x / cpw_out, g = blockIdx.x % cpw_out, ll = CS::ll();
+    const uint32_t j = g * NLL + ll;
+    const bool have = j < cpw_in;
+    const uint32_t* src = pairs_in + ((size_t)w * cpw_in + (have ? j : 0)) * 2 * BK;
+    Pt run = CS::select(have, CS::inf(), CS::load(src));
+    Pt acc = CS::select(have, CS::inf(), CS::load(src + BK));
+    const bool rider = ll == NLL - 1;
+    if (cpw_in > 1) {
+        const uint32_t s_comb = CS::LOG_LL, s_end = s_comb + 1 + CS::LOG_LL;
+#pragma unroll 1
+        for (uint32_t s = 0; s < s_end; s++) {
+            Pt A, B;
+            uint32_t dst;  // 0 run, 1 acc
+            if (s < s_comb) {
+                int d = 1 << s;
+                A = run;
+                B = CS::select((int)ll + d < NLL, CS::inf(), CS::shfl_down(run, d));
+                dst = 0;
+            } else if (s == s_comb) {
+                A = acc;
+                B = CS::select(ll == 0, run, CS::inf());
+                dst = 1;
+            } else {
+                int k = s - s_comb - 1, d = (NLL / 2) >> k;
+                Pt sh = CS::shfl_down(acc, d);
+                A = acc;
+                B = CS::select((int)ll < d, CS::inf(), sh);
+                if (k == 0) A = CS::select(rider, A, CS::from_ll(run, 0));
+                B = CS::select(rider, B, A);
+                dst = 1;
+            }
+            CS::add(A, B);
+            if (dst == 0) run = A;
+            else acc = A;
+        }
+    }
+    if (jac_out) {
+        if (ll == 0) CS::store_jac_raw(jac_out + (size_t)w * RJ, acc);
+    } else {
+        uint32_t* o = pairs_out + ((size_t)w * cpw_out + g) * 2 * BK;
+        if (rider) CS::store(o, acc);
+        if (ll == 0) CS::store(o + BK, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- normalize_batch
+// Jacobian -> affine for n points with ONE field inversion (Montgomery's trick as a product tree of fan-out NORM_K):
+// replaces blstrs::G{1,2}Projective::batch_normalize behind CurveGroup::normalize_batch
+// (/root/reference/src/g1.rs:537-543, src/g2.rs:517-523; the step arkworks provers run right before an MSM,
+// `batch_convert_to_mul_base`, src/g1.rs:597-599).  Infinity (Z = 0) maps to the all-zero affine point.
+//   k_norm_load : Z_i (raw) -> device form, infinity replaced by 1
+//   k_norm_up   : per group of K values: exclusive prefix products + group total (= value of the next level)
+//   (top level <= 64 values: inverted on the host, one Fermat inversion)
+//   k_norm_down : per group: inverse of each value from the inverse of the group total
+//   k_norm_final: x = X / Z^2, y = Y / Z^3, back to the reference's form
+constexpr uint32_t NORM_K = 32;
+
+template <class C>
+__global__ void __launch_bounds__(256) k_norm_load(const uint32_t* __restrict__ raw_jac, uint32_t n, uint32_t* __restrict__ vals) {
+    using F = typename C::F;
+    using E = typename F::E;
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* zr = raw_jac + (size_t)i * Geo<C>::RAW_JAC + 2 * ElemIO<E>::RAW;
+    uint32_t any = 0;
+#pragma unroll 4
+    for (int k = 0; k < ElemIO<E>::RAW; k++) any |= zr[k];
+    E z;
+    ElemIO<E>::from_raw(z, zr);
+    z = F::select(any == 0, z, F::one());
+    ElemIO<E>::store(vals + (size_t)i * Geo<C>::SLOT, z);
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) k_norm_up(const uint32_t* __restrict__ vals, uint32_t m, uint32_t* __restrict__ pref,
+                                                 uint32_t* __restrict__ tot) {
+    using F = typename C::F;
+    using E = typename F::E;
+    uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    uint32_t lo = g * NORM_K, hi = lo + NORM_K < m ? lo + NORM_K : m;
+    if (lo >= m) return;
+    E run = F::one();
+    for (uint32_t k = lo; k < hi; k++) {
+        ElemIO<E>::store(pref + (size_t)k * Geo<C>::SLOT, run);
+        E v;
+        ElemIO<E>::load(v, vals + (size_t)k * Geo<C>::SLOT);
+        run = F::mul(run, v);
+    }
+    ElemIO<E>::store(tot + (size_t)g * Geo<C>::SLOT, run);
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) k_norm_down(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ pref,
+                                                   const uint32_t* __restrict__ inv_tot, uint32_t m, uint32_t* __restrict__ inv_vals) {
+    using F = typename C::F;
+    using E = typename F::E;
+    uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    uint32_t lo = g * NORM_K, hi = lo + NORM_K < m ? lo + NORM_K : m;
+    if (lo >= m) return;
+    E I;
+    ElemIO<E>::load(I, inv_tot + (size_t)g * Geo<C>::SLOT);
+    for (uint32_t k = hi; k-- > lo;) {
+        E p, v;
+        ElemIO<E>::load(p, pref + (size_t)k * Geo<C>::SLOT);
+        ElemIO<E>::load(v, vals + (size_t)k * Geo<C>::SLOT);
+        ElemIO<E>::store(inv_vals + (size_t)k * Geo<C>::SLOT, F::mul(I, p));
+        I = F::mul(I, v);
+    }
+}
+
+template <class C>
+__global__ void __launch_bounds__(256) k_norm_final(const uint32_t* __restrict__ raw_jac, const uint32_t* __restrict__ zinv, uint32_t n,
+                                                    uint32_t* __restrict__ raw_aff) {
+    using F = typename C::F;
+    using E = typename F::E;
+    constexpr int R = ElemIO<E>::RAW;
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* q = raw_jac + (size_t)i * Geo<C>::RAW_JAC;
+    uint32_t any = 0;
+#pragma unroll 4
+    for (int k = 0; k < R; k++) any |= q[2 * R + k];
+    E x, y, zi;
+    ElemIO<E>::from_raw(x, q);
+    ElemIO<E>::from_raw(y, q + R);
+    ElemIO<E>::load(zi, zinv + (size_t)i * Geo<C>::SLOT);
+    E zi2 = F::mul(zi, zi);
+    E zi3 = F::mul(zi2, zi);
+    uint32_t* o = raw_aff + (size_t)i * Geo<C>::RAW_AFF;
+    ElemIO<E>::to_raw(o, F::mul(x, zi2), any != 0);
+    ElemIO<E>::to_raw(o + R, F::mul(y, zi3), any != 0);
+}
+
+// device form <-> reference form for a short vector of field elements (top of the product tree, host inversion)
+template <class C>
+__global__ void __launch_bounds__(64) k_elems_to_raw(const uint32_t* __restrict__ dev, uint32_t m, uint32_t* __restrict__ raw) {
+    using E = typename C::F::E;
+    uint32_t i = threadIdx.x;
+    if (i >= m) return;
+    E v;
+    ElemIO<E>::load(v, dev + (size_t)i * Geo<C>::SLOT);
+    ElemIO<E>::to_raw(raw + (size_t)i * ElemIO<E>::RAW, v, true);
+}
+template <class C>
+__global__ void __launch_bounds__(64) k_elems_from_raw(const uint32_t* __restrict__ raw, uint32_t m, uint32_t* __restrict__ dev) {
+    using E = typename C::F::E;
+    uint32_t i = threadIdx.x;
+    if (i >= m) return;
+    E v;
+    ElemIO<E>::from_raw(v, raw + (size_t)i * ElemIO<E>::RAW);
+    ElemIO<E>::store(dev + (size_t)i * Geo<C>::SLOT, v);
+}
+
+}  // namespace msmk

@@ -21,7 +21,7 @@
 
 #if defined(__HIPCC__)
 #define FP_HD __host__ __device__ __forceinline__
-#define FP_HD_NOINLINE __host__ __device__ __noinline__
+#define FP_HD_NOINLINE inline __host__ __device__ __noinline__
 #else
 #define FP_HD inline
 #define FP_HD_NOINLINE inline

@@ -1,0 +1,57 @@
+// Functions that cross the translation units of the library (all host code; kernels never do).
+//   msm_sort.hip     window-size plan, bucket sort + work-item schedule (curve independent)
+//   msm_g1.hip / msm_g2.hip   the curve pipelines (explicit instantiations of msm_curve.hpp), normalize_batch
+//   points.hip       bulk (de)serialisation
+//   pairing_api.hip  batched Miller loop + final exponentiation
+//   api.hip          the extern "C" entry points of include/arkblst_amd.h
+#pragma once
+#include "common.hpp"
+
+namespace mi {
+
+// ---- msm_sort.hip
+struct CurveCost {        // what the plan needs to know about the curve's kernels (microseconds, measured)
+    int log_ll;           // log2 logical lanes per reduce wave (coop scheme)
+    uint32_t max_chunks;  // reduce waves that run at once (1024 SIMDs x occupancy)
+    double add_per_us;    // mixed additions per microsecond of the accumulate kernel at full occupancy
+    double lane_add_us;   // one lane's time per mixed addition (latency view)
+    double step_us;       // one complete addition of the reduce / combine chain
+    double merge_us;      // one level of the split-bucket merge
+};
+// shared = false: one bucket set per window (plain bases).  shared = true: resident 2^(c j) P tables — every window feeds ONE
+// bucket set; `stride` = points per table (entry index = w * stride + i).  forced_c = 0 lets the time model choose.
+Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, size_t stride);
+
+struct SortOut {
+    uint32_t nitems = 0, max_items = 0, nlist = 0;
+    uint64_t entries = 0;
+};
+// scalars -> signed digits -> sorted (index | sign) entries, bucket offsets, work items, processing order.  Records
+// d.ev[ev0] .. d.ev[ev0 + 3] (start, coarse done, fine done, schedule done) and synchronises once to read the item counts.
+void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, const uint8_t* d_flags, size_t n, unsigned fmt, bool shared_buckets,
+                       size_t stride, int ev0, SortOut& out);
+
+// ---- msm_g1.hip / msm_g2.hip
+int g1_set_bases(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute_c);
+int g2_set_bases(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute_c);
+int g1_msm(mi_ctx* ctx, const void* bases, const uint8_t* scalars, bool scalars_on_device, size_t n, unsigned fmt, void* out);
+int g2_msm(mi_ctx* ctx, const void* bases, const uint8_t* scalars, bool scalars_on_device, size_t n, unsigned fmt, void* out);
+int g1_msm_batch(mi_ctx* ctx, const uint8_t* const* scalars, size_t k, size_t n, unsigned fmt, mi_g1* out);
+int g2_msm_batch(mi_ctx* ctx, const uint8_t* const* scalars, size_t k, size_t n, unsigned fmt, mi_g2* out);
+int g1_normalize(mi_ctx* ctx, const mi_g1* in, size_t n, mi_g1_affine* out);
+int g2_normalize(mi_ctx* ctx, const mi_g2* in, size_t n, mi_g2_affine* out);
+
+// ---- points.hip
+int g1_deserialize(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int validate, mi_g1_affine* out, uint8_t* status);
+int g1_serialize(mi_ctx* ctx, const mi_g1_affine* points, size_t n, int compressed, uint8_t* bytes);
+int g2_deserialize(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int validate, mi_g2_affine* out, uint8_t* status);
+int g2_serialize(mi_ctx* ctx, const mi_g2_affine* points, size_t n, int compressed, uint8_t* bytes);
+#if defined(MI_TEST_HOOKS)
+int test_fp_op(mi_ctx* ctx, int op, const mi_fp* a, const mi_fp* b, mi_fp* out, size_t n);
+#endif
+
+// ---- pairing_api.hip
+int miller(mi_ctx* ctx, const mi_g1_affine* p, const mi_g2_affine* q, size_t n, mi_fp12* out, bool final_exp);
+int final_exponentiation(const mi_fp12* f, mi_fp12* out);
+
+}  // namespace mi

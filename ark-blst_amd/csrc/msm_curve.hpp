@@ -1,0 +1,442 @@
+// The MSM pipeline of one curve on the host side: templates over the curve descriptor (msmk::G1C / msmk::G2C), instantiated
+// in msm_g1.hip and msm_g2.hip.  Replaces crate::gpu::msm + SingleMultiexpKernel::multiexp of the reference
+// (/root/reference/src/gpu.rs:126-241) behind <G{1,2}Projective as VariableBaseMSM>::msm (src/g1.rs:602-632, src/g2.rs:582-612).
+#pragma once
+#include "internal.hpp"
+#include "curve_kernels.cuh"
+
+namespace mi {
+
+// host-side view of a curve: the reference's raw sizes and the CPU Jacobian type used for the O(windows) tail
+template <class C> struct HostCurve;
+template <> struct HostCurve<msmk::G1C> {
+    using J = hostec::G1;
+    static constexpr int IDX = 0;
+    // accumulate 7.1e9 additions/s, 11 us per addition and lane; quad-lane complete addition ~6 us per step, two waves per SIMD
+    static CurveCost cost() { return CurveCost{msmk::QuadG1::LOG_LL, 2048, 7100.0, 11.0, 6.0, 60.0}; }
+};
+template <> struct HostCurve<msmk::G2C> {
+    using J = hostec::G2;
+    static constexpr int IDX = 1;
+    static CurveCost cost() { return CurveCost{msmk::PairG2::LOG_LL, 1024, 1950.0, 36.0, 30.0, 150.0}; }
+};
+template <class C> constexpr size_t aff_bytes() { return (size_t)msmk::Geo<C>::RAW_AFF * 4; }
+template <class C> constexpr size_t jac_bytes() { return (size_t)msmk::Geo<C>::RAW_JAC * 4; }
+
+// One call handles at most this many points per device in one pass of the pipeline (32-bit entry offsets: n * windows < 2^32);
+// longer inputs are cut into parts whose sums are added (cf. the unfinished calc_chunk_size path, /root/reference/src/gpu.rs:64-85,238-239).
+constexpr size_t MAX_PART_POINTS = (size_t)1 << 26;
+inline size_t max_part(mi_ctx* ctx) {
+#if defined(MI_TEST_HOOKS)
+    if (ctx->test_max_part) return ctx->test_max_part;
+#endif
+    (void)ctx;
+    return MAX_PART_POINTS;
+}
+
+// bases raw (host or device) -> device form in `dst`
+template <class C>
+void ingest(DevState& d, const void* bases, bool bases_on_device, size_t n, uint32_t* dst, uint8_t* flags) {
+    const void* src = bases;
+    if (!bases_on_device) {
+        d.raw.ensure(n * aff_bytes<C>());
+        HIP_TRY(hipMemcpyAsync(d.raw.p, bases, n * aff_bytes<C>(), hipMemcpyHostToDevice, d.stream));
+        src = d.raw.p;
+    }
+    uint32_t grid = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(msmk::k_ingest<C>, dim3(grid), dim3(256), 0, d.stream, (const uint32_t*)src, dst, flags, (uint32_t)n);
+    HIP_TRY(hipGetLastError());
+}
+
+// ---- batch inversion of n device-form field elements (Montgomery's trick as a product tree of fan-out NORM_K; the <= 64 values
+// at the top are inverted on the host with one Fermat inversion: a single GPU lane would need ~1 ms for it)
+struct InvTree {
+    std::vector<size_t> sz, off;
+    size_t total = 0;
+    explicit InvTree(size_t n) {
+        sz.push_back(n);
+        while (sz.back() > 64) sz.push_back((sz.back() + msmk::NORM_K - 1) / msmk::NORM_K);
+        off.resize(sz.size());
+        for (size_t l = 0; l < sz.size(); total += sz[l], l++) off[l] = total;
+    }
+};
+// vals level 0 must be filled; on return inv level 0 holds the inverses.  Synchronises the stream once (host inversion).
+template <class C>
+void invert_tree(DevState& d, const InvTree& t, DevBuf& vals, DevBuf& pref, DevBuf& inv, DevBuf& top_raw) {
+    using J = typename HostCurve<C>::J;
+    using FE = decltype(J::inf().x);
+    constexpr size_t SLOTB = (size_t)msmk::Geo<C>::SLOT * 4;
+    hipStream_t s = d.stream;
+    auto at = [&](DevBuf& b, size_t l) { return (uint32_t*)((char*)b.p + t.off[l] * SLOTB); };
+    for (size_t l = 0; l + 1 < t.sz.size(); l++) {
+        uint32_t groups = (uint32_t)t.sz[l + 1];
+        hipLaunchKernelGGL(msmk::k_norm_up<C>, dim3((groups + 255) / 256), dim3(256), 0, s, (const uint32_t*)at(vals, l), (uint32_t)t.sz[l],
+                           at(pref, l), at(vals, l + 1));
+    }
+    size_t top = t.sz.size() - 1, m = t.sz[top];
+    hipLaunchKernelGGL(msmk::k_elems_to_raw<C>, dim3(1), dim3(64), 0, s, (const uint32_t*)at(vals, top), (uint32_t)m, (uint32_t*)top_raw.p);
+    std::vector<FE> v(m), pre(m), iv(m);
+    HIP_TRY(hipMemcpyAsync(v.data(), top_raw.p, m * sizeof(FE), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    FE run = FE::one();
+    for (size_t k = 0; k < m; k++) { pre[k] = run; run = run * v[k]; }
+    FE I = run.inv();
+    for (size_t k = m; k-- > 0;) { iv[k] = I * pre[k]; I = I * v[k]; }
+    HIP_TRY(hipMemcpyAsync(top_raw.p, iv.data(), m * sizeof(FE), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(msmk::k_elems_from_raw<C>, dim3(1), dim3(64), 0, s, (const uint32_t*)top_raw.p, (uint32_t)m, at(inv, top));
+    HIP_TRY(hipStreamSynchronize(s));   // iv is a local: the copy must have read it before it goes away
+    for (size_t l = top; l-- > 0;) {
+        uint32_t groups = (uint32_t)t.sz[l + 1];
+        hipLaunchKernelGGL(msmk::k_norm_down<C>, dim3((groups + 255) / 256), dim3(256), 0, s, (const uint32_t*)at(vals, l),
+                           (const uint32_t*)at(pref, l), (const uint32_t*)at(inv, l + 1), (uint32_t)t.sz[l], at(inv, l));
+    }
+}
+
+struct ScopedBufs {   // per-call device buffers of the cold entry points (normalize, table build): freed on every path
+    std::vector<DevBuf*> v;
+    ~ScopedBufs() { for (DevBuf* b : v) b->release(); }
+};
+
+// Host tail: Horner fold over the window sums (the chunk combine ran on the GPU).  256 doublings: ~0.1 ms on one core; a
+// GPU lane would need ~2 ms for the same serial chain (cf. /root/reference/src/gpu.rs:193-209, which folds ~32k partials here).
+template <class J>
+J horner(const J* win, const Plan& pl) {
+    J r = J::inf();
+    for (int w = (int)pl.bwin - 1; w >= 0; w--) r = r.dbl_n(pl.c).add(win[w]);
+    return r;
+}
+
+// The pipeline on one device.  d_bases: device-form points (tables of `stride` points when shared); d_scalars: n x 32 B on device.
+template <class C>
+typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint8_t* d_flags, const uint32_t* d_scalars,
+                                 size_t n, unsigned fmt, bool shared, unsigned table_c, size_t stride, int ev0) {
+    using J = typename HostCurve<C>::J;
+    using CS = typename msmk::CoopOf<C>::CS;
+    constexpr int BK = msmk::Geo<C>::BK_WORDS;
+    Plan pl = make_plan(n, shared ? table_c : ctx->forced_c, HostCurve<C>::cost(), shared, stride);
+    if (pl.c == 0) throw HipFail{"window_bits not usable for this n (sort geometry)"};
+    d.prof.window_bits = pl.c;
+    d.prof.num_windows = pl.nwin;
+    d.prof.n = n;
+    d.pairs.ensure(pl.nchunks * 2 * BK * 4);
+    d.pairs2.ensure(((pl.nchunks >> CS::LOG_LL) + pl.bwin) * 2 * BK * 4 + (size_t)pl.bwin * jac_bytes<C>());
+    d.ensure_host((size_t)pl.bwin * jac_bytes<C>());
+
+    SortOut so;
+    sort_and_schedule(d, pl, d_scalars, d_flags, n, fmt, shared, stride, ev0, so);
+
+    hipStream_t s = d.stream;
+    const uint32_t nitems = so.nitems, max_items = so.max_items;
+    d.partial.ensure((size_t)nitems * BK * 4);
+    uint32_t grid_items = (nitems + 255) / 256;
+    hipLaunchKernelGGL(msmk::k_accumulate<C>, dim3(grid_items), dim3(256), 0, s, d_bases, (const uint32_t*)d.sorted.p,
+                       (const uint32_t*)d.offsets.p, (const uint32_t*)d.woff.p, (const uint32_t*)d.order.p,
+                       (const uint32_t*)d.item_bucket.p, nitems, pl.logT, (uint32_t*)d.partial.p);
+    uint32_t nlist = so.nlist;
+    for (uint32_t dd = 1; dd < max_items && nlist; dd <<= 1)
+        hipLaunchKernelGGL(msmk::k_merge<C>, dim3((nlist + 255) / 256), dim3(256), 0, s, (uint32_t*)d.partial.p,
+                           (const uint32_t*)d.item_bucket.p, (const uint32_t*)d.woff.p, (const uint32_t*)d.merge_list.p, nlist, dd);
+    HIP_TRY(hipEventRecord(d.ev[ev0 + 4], s));
+    // bucket reduction: one wave per chunk of 2^chunk_log buckets -> (K S, T) pairs; then the per-window combine, 2^LOG_LL pairs per
+    // wave and level, down to one Jacobian point per window
+    hipLaunchKernelGGL(msmk::k_reduce_coop<CS>, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
+                       (const uint32_t*)d.woff.p, (uint32_t*)d.pairs.p, pl.logL);
+    HIP_TRY(hipEventRecord(d.ev[ev0 + 5], s));
+    uint32_t* jac_dev = (uint32_t*)((char*)d.pairs2.p + d.pairs2.cap - (size_t)pl.bwin * jac_bytes<C>());
+    {
+        uint32_t cpw = pl.chunks_per_win;
+        uint32_t* in = (uint32_t*)d.pairs.p;
+        uint32_t* out = (uint32_t*)d.pairs2.p;
+        for (;;) {
+            uint32_t cpw_out = (cpw + (1u << CS::LOG_LL) - 1) >> CS::LOG_LL;
+            const bool last = cpw_out == 1;
+            hipLaunchKernelGGL(msmk::k_combine<CS>, dim3(pl.bwin * cpw_out), dim3(64), 0, s, (const uint32_t*)in, cpw, cpw_out, out,
+                               last ? jac_dev : (uint32_t*)nullptr);
+            if (last) break;
+            std::swap(in, out);   // the levels shrink by 2^LOG_LL: ping-pong between the two pair buffers
+            cpw = cpw_out;
+        }
+    }
+    HIP_TRY(hipEventRecord(d.ev[ev0 + 6], s));
+    HIP_TRY(hipMemcpyAsync(d.h_pairs, jac_dev, (size_t)pl.bwin * jac_bytes<C>(), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(d.ev[ev0 + 7], s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+
+    d.prof.digits_ms += ev_ms(d.ev[ev0], d.ev[ev0 + 1]);      // digits + coarse partition (4 kernels)
+    d.prof.scatter_ms += ev_ms(d.ev[ev0 + 1], d.ev[ev0 + 2]);  // fine sort in LDS
+    d.prof.scan_ms += ev_ms(d.ev[ev0 + 2], d.ev[ev0 + 3]);     // schedule (3 kernels)
+    d.prof.accumulate_ms += ev_ms(d.ev[ev0 + 3], d.ev[ev0 + 4]);
+    d.prof.reduce_ms += ev_ms(d.ev[ev0 + 4], d.ev[ev0 + 5]);
+    d.prof.combine_ms += ev_ms(d.ev[ev0 + 5], d.ev[ev0 + 6]);
+    d.prof.d2h_ms += ev_ms(d.ev[ev0 + 6], d.ev[ev0 + 7]);
+    d.prof.accumulate_adds += so.entries;
+    d.prof.work_items = nitems;
+    d.prof.max_items_per_bucket = max_items;
+
+    auto t0 = std::chrono::steady_clock::now();
+    J r = horner<J>(reinterpret_cast<const J*>(d.h_pairs), pl);
+    d.prof.host_fold_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return r;
+}
+
+// One device's share of an MSM call. bases: host raw pointer for this shard or nullptr (= resident, starting at resident index r0).
+template <class C>
+typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bases, size_t r0, const uint8_t* scalars, bool scalars_on_device,
+                                    size_t n, unsigned fmt) {
+    using J = typename HostCurve<C>::J;
+    HIP_TRY(hipSetDevice(d.dev));
+    d.prof = mi_profile{};
+    auto t0 = std::chrono::steady_clock::now();
+    J total = J::inf();
+    if (n == 0) return total;
+    hipStream_t s = d.stream;
+    Resident& res = d.res[HostCurve<C>::IDX];
+    const bool shared = !bases && res.tables > 1;
+    const size_t part_max = max_part(ctx);
+    for (size_t lo = 0; lo < n; lo += part_max) {   // one pass unless n exceeds the per-pass limit
+        const size_t m = std::min(part_max, n - lo);
+        HIP_TRY(hipEventRecord(d.ev[0], s));
+        const uint32_t* d_scalars;
+        if (scalars_on_device) {
+            d_scalars = reinterpret_cast<const uint32_t*>(scalars + lo * 32);
+        } else {
+            d.scalars.ensure(m * 32);
+            HIP_TRY(hipMemcpyAsync(d.scalars.p, scalars + lo * 32, m * 32, hipMemcpyHostToDevice, s));
+            d_scalars = reinterpret_cast<const uint32_t*>(d.scalars.p);
+        }
+        const uint32_t* d_bases;
+        const uint8_t* d_flags;
+        if (bases) {
+            d.raw.ensure(m * aff_bytes<C>());
+            HIP_TRY(hipMemcpyAsync(d.raw.p, bases + lo * aff_bytes<C>(), m * aff_bytes<C>(), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipEventRecord(d.ev[1], s));
+            d.call_bases.ensure(m * msmk::Geo<C>::PT_WORDS * 4);
+            d.call_flags.ensure(m);
+            ingest<C>(d, d.raw.p, true, m, (uint32_t*)d.call_bases.p, (uint8_t*)d.call_flags.p);
+            d_bases = reinterpret_cast<const uint32_t*>(d.call_bases.p);
+            d_flags = reinterpret_cast<const uint8_t*>(d.call_flags.p);
+        } else {
+            HIP_TRY(hipEventRecord(d.ev[1], s));
+            d_bases = reinterpret_cast<const uint32_t*>(res.buf.p) + (r0 + lo) * msmk::Geo<C>::PT_WORDS;
+            d_flags = reinterpret_cast<const uint8_t*>(res.flags.p) + r0 + lo;
+        }
+        J r = run_msm<C>(ctx, d, d_bases, d_flags, d_scalars, m, fmt, shared, res.table_c, res.n, 2);
+        total = lo == 0 ? r : total.add(r);
+        d.prof.h2d_ms += ev_ms(d.ev[0], d.ev[1]);
+        d.prof.ingest_ms += ev_ms(d.ev[1], d.ev[2]);
+    }
+    d.prof.n = n;
+    d.prof.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return total;
+}
+
+// Resident base set.  precompute_c == 0: plain bases.  Otherwise W = ceil(256 / c) tables T_j[i] = 2^(c j) P_i (affine, device
+// form): every window of a later MSM then shares ONE bucket set (no per-window reduce, no Horner doublings) and c can be larger.
+template <class C>
+void build_resident(mi_ctx* ctx, DevState& d, Resident& res, const uint8_t* bases, size_t n, unsigned precompute_c) {
+    using F = typename C::F;
+    constexpr size_t PTB = (size_t)msmk::Geo<C>::PT_WORDS * 4, SLOTB = (size_t)msmk::Geo<C>::SLOT * 4, BKB = (size_t)msmk::Geo<C>::BK_WORDS * 4;
+    (void)sizeof(F);
+    HIP_TRY(hipSetDevice(d.dev));
+    unsigned c = 0, W = 1;
+    if (precompute_c) {
+        c = precompute_c == 1 ? make_plan(n, 0, HostCurve<C>::cost(), true, n).c : precompute_c;
+        W = (256 + c - 1) / c;
+        if (c < 7 || c > 22 || make_plan(n, c, HostCurve<C>::cost(), true, n).c == 0) throw HipFail{"window_bits not usable for precomputed tables of this size"};
+    }
+    res.buf.ensure(n * W * PTB);
+    res.flags.ensure(n);
+    res.tables = 1;
+    res.table_c = 0;
+    ingest<C>(d, bases, false, n, (uint32_t*)res.buf.p, (uint8_t*)res.flags.p);
+    if (W > 1) {
+        InvTree t(n);
+        DevBuf proj, vals, pref, inv, top_raw;
+        ScopedBufs guard{{&proj, &vals, &pref, &inv, &top_raw}};
+        proj.ensure(n * BKB);
+        vals.ensure(t.total * SLOTB); pref.ensure(t.total * SLOTB); inv.ensure(t.total * SLOTB);
+        top_raw.ensure(64 * sizeof(decltype(HostCurve<C>::J::inf().x)));
+        const uint32_t grid = (uint32_t)((n + 255) / 256);
+        for (unsigned j = 1; j < W; j++) {
+            const uint32_t* prev = (const uint32_t*)((const char*)res.buf.p + (size_t)(j - 1) * n * PTB);
+            uint32_t* next = (uint32_t*)((char*)res.buf.p + (size_t)j * n * PTB);
+            hipLaunchKernelGGL(msmk::k_table_dbl<C>, dim3(grid), dim3(256), 0, d.stream, prev, (const uint8_t*)res.flags.p, (uint32_t)n, c,
+                               (uint32_t*)proj.p, (uint32_t*)vals.p);
+            invert_tree<C>(d, t, vals, pref, inv, top_raw);
+            hipLaunchKernelGGL(msmk::k_table_affine<C>, dim3(grid), dim3(256), 0, d.stream, (const uint32_t*)proj.p, (const uint32_t*)inv.p,
+                               (const uint8_t*)res.flags.p, (uint32_t)n, next);
+        }
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        HIP_TRY(hipGetLastError());
+        res.tables = W;
+        res.table_c = c;
+    }
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    (void)ctx;
+}
+
+template <class C>
+int set_bases_impl(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute_c) {
+    if (!ctx || (n && !bases)) return fail(ctx, MI_E_INVALID, "invalid argument");
+    if (precompute_c > 1 && (precompute_c < 7 || precompute_c > 22)) return fail(ctx, MI_E_INVALID, "window_bits must be 0 (choose) or 7..22");
+    if ((n + ctx->devs.size() - 1) / ctx->devs.size() > (1ull << 31)) return fail(ctx, MI_E_INVALID, "more than 2^31 points per device");
+    LaneLock lk(ctx, true);
+    return guarded(ctx, [&]() -> int {
+        size_t g = ctx->devs.size();
+        std::vector<PartErr> errs(g);
+        for_each_device(lk, g, [&](size_t k) {
+            guarded_part(errs[k], [&] {
+                DevState& d = ctx->devs[k];
+                auto& res = d.res[HostCurve<C>::IDX];
+                size_t lo, hi;
+                shard_range(n, g, k, lo, hi);
+                res.lo = lo;
+                res.n = hi - lo;
+                res.tables = 1;
+                res.table_c = 0;
+                if (hi > lo) build_resident<C>(ctx, d, res, (const uint8_t*)bases + lo * aff_bytes<C>(), hi - lo, precompute_c);
+            });
+        });
+        for (size_t k = 0; k < g; k++)
+            if (errs[k].code != MI_OK) {
+                for (size_t q = 0; q < g; q++) { auto& r = ctx->devs[q].res[HostCurve<C>::IDX]; r.n = 0; r.tables = 1; }   // all or nothing
+                return fail(ctx, errs[k].code, errs[k].msg);
+            }
+        return MI_OK;
+    });
+}
+
+template <class C>
+int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scalars_on_device, size_t n, unsigned fmt, void* out) {
+    using J = typename HostCurve<C>::J;
+    const uint8_t* bases = static_cast<const uint8_t*>(bases_v);
+    if (!ctx || !out || (n && !scalars) || fmt > 1) return fail(ctx, MI_E_INVALID, "invalid argument");
+    LaneLock lane(ctx, false);
+    std::vector<DevState>& devs = lane.devs();
+    return guarded(ctx, [&]() -> int {
+        size_t g = devs.size();
+        std::vector<J> part(g, J::inf());
+        std::vector<PartErr> errs(g);
+        // resident path: each device covers the overlap of [0, n) with its resident shard
+        if (!bases) {
+            size_t have = 0;
+            for (auto& d : devs) have += d.res[HostCurve<C>::IDX].n;
+            if (have == 0 && n) return fail(ctx, MI_E_NO_BASES, "no resident base set for this group");
+            if (n > have) return fail(ctx, MI_E_INVALID, "n exceeds the resident base set");
+        }
+        // device-resident scalars of a multi-device context: the shard of device k is read by device k (peer access over xGMI, or
+        // the caller placed each shard on its device: mi_msm_g{1,2}_device takes ONE pointer to n x 32 B visible to every device)
+        auto t0 = std::chrono::steady_clock::now();
+        for_each_device(lane, g, [&](size_t k) {
+            guarded_part(errs[k], [&] {
+                DevState& d = devs[k];
+                size_t lo, hi;
+                if (bases) {
+                    shard_range(n, g, k, lo, hi);
+                } else {
+                    auto& res = d.res[HostCurve<C>::IDX];
+                    lo = std::min(n, res.lo);
+                    hi = std::min(n, res.lo + res.n);
+                }
+                part[k] = device_msm<C>(ctx, d, bases ? bases + lo * aff_bytes<C>() : nullptr, 0, scalars + lo * 32, scalars_on_device, hi - lo, fmt);
+            });
+        });
+        for (size_t k = 0; k < g; k++)
+            if (errs[k].code != MI_OK) return fail(ctx, errs[k].code, errs[k].msg);
+        J r = J::inf();
+        for (size_t k = 0; k < g; k++) r = r.add(part[k]);
+        memcpy(out, &r, sizeof r);
+        // report the slowest device's profile
+        size_t slow = 0;
+        for (size_t k = 1; k < g; k++)
+            if (devs[k].prof.total_ms > devs[slow].prof.total_ms) slow = k;
+        mi_profile pr = devs[slow].prof;
+        pr.n = n;
+        pr.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        set_prof(ctx, pr);
+        return MI_OK;
+    });
+}
+
+// k MSMs over the resident base set, two in flight (one per lane): the calling thread and one helper pull jobs
+template <class C, class Out>
+int msm_batch_impl(mi_ctx* ctx, const uint8_t* const* scalars, size_t k, size_t n, unsigned fmt, Out* out) {
+    if (!ctx || (k && (!scalars || !out))) return fail(ctx, MI_E_INVALID, "invalid argument");
+    for (size_t j = 0; j < k; j++)
+        if (n && !scalars[j]) return fail(ctx, MI_E_INVALID, "null scalar vector");
+    return guarded(ctx, [&]() -> int {
+        std::atomic<size_t> next{0};
+        std::atomic<int> first_err{MI_OK};
+        std::string first_msg;
+        std::mutex msg_mu;
+        auto worker = [&]() noexcept {
+            for (;;) {
+                size_t j = next.fetch_add(1);
+                if (j >= k || first_err.load() != MI_OK) break;
+                int rc = msm_impl<C>(ctx, nullptr, scalars[j], false, n, fmt, &out[j]);   // never throws (guarded)
+                int ok = MI_OK;
+                if (rc != MI_OK && first_err.compare_exchange_strong(ok, rc)) {
+                    std::lock_guard<std::mutex> lk(msg_mu);
+                    first_msg = tls_error();
+                }
+            }
+        };
+        if (k > 1) {
+            std::thread helper(worker);   // a failure to start it (std::system_error) is caught by guarded()
+            worker();
+            helper.join();
+        } else {
+            worker();
+        }
+        if (first_err.load() != MI_OK) return fail(ctx, first_err.load(), first_msg);
+        return MI_OK;
+    });
+}
+
+// normalize_batch on device 0 of the context (host pointers in the reference's forms)
+template <class C>
+void normalize_batch_dev(mi_ctx* ctx, DevState& d, const void* in, size_t n, void* out) {
+    using J = typename HostCurve<C>::J;
+    using FE = decltype(J::inf().x);
+    constexpr size_t SLOTB = (size_t)msmk::Geo<C>::SLOT * 4;
+    HIP_TRY(hipSetDevice(d.dev));
+    hipStream_t s = d.stream;
+    InvTree t(n);
+    DevBuf raw_in, raw_out, vals, pref, inv, top_raw;
+    ScopedBufs guard{{&raw_in, &raw_out, &vals, &pref, &inv, &top_raw}};
+    raw_in.ensure(n * jac_bytes<C>());
+    raw_out.ensure(n * aff_bytes<C>());
+    vals.ensure(t.total * SLOTB);
+    pref.ensure(t.total * SLOTB);
+    inv.ensure(t.total * SLOTB);
+    top_raw.ensure(64 * sizeof(FE));
+    HIP_TRY(hipEventRecord(d.ev[0], s));
+    HIP_TRY(hipMemcpyAsync(raw_in.p, in, n * jac_bytes<C>(), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(d.ev[1], s));
+    hipLaunchKernelGGL(msmk::k_norm_load<C>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)raw_in.p, (uint32_t)n,
+                       (uint32_t*)vals.p);
+    invert_tree<C>(d, t, vals, pref, inv, top_raw);
+    hipLaunchKernelGGL(msmk::k_norm_final<C>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)raw_in.p,
+                       (const uint32_t*)inv.p, (uint32_t)n, (uint32_t*)raw_out.p);
+    HIP_TRY(hipEventRecord(d.ev[2], s));
+    HIP_TRY(hipMemcpyAsync(out, raw_out.p, n * aff_bytes<C>(), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    mi_profile pr{};
+    pr.n = n;
+    pr.h2d_ms = ev_ms(d.ev[0], d.ev[1]);
+    pr.accumulate_ms = ev_ms(d.ev[1], d.ev[2]);   // all normalize kernels incl. the host inversion round trip
+    set_prof(ctx, pr);
+}
+
+template <class C, class In, class Out>
+int normalize_impl(mi_ctx* ctx, const In* in, size_t n, Out* out) {
+    if (!ctx || (n && (!in || !out))) return fail(ctx, MI_E_INVALID, "invalid argument");
+    if (n == 0) return MI_OK;
+    if (n > 0x7fffffffull) return fail(ctx, MI_E_INVALID, "n too large");
+    LaneLock lk(ctx, true);
+    return guarded(ctx, [&]() -> int { normalize_batch_dev<C>(ctx, ctx->devs[0], in, n, out); return MI_OK; });
+}
+
+}  // namespace mi

@@ -1,0 +1,176 @@
+// Window-size plan, two-level LDS-staged bucket sort and work-item schedule of one MSM call (curve independent).
+// Plays the role of calc_window_size / work_units / calc_chunk_size of the reference driver (/root/reference/src/gpu.rs:37-92,218-223).
+#include "internal.hpp"
+#include "sort_kernels.cuh"
+
+namespace mi {
+
+// Window size c by a time model of the pipeline on one MI355X (microseconds; constants measured):
+//   accumulate  max(throughput: N W mixed additions at cc.add_per_us,  latency: one lane walks an item of T entries)
+//   merge       one launch per binary-tree level when the short top window overfills its buckets
+//   reduce      a latency chain of 2L + 2 LOG_LL + logL + 1 complete additions per wave, max_chunks waves per round
+//   combine     2 LOG_LL + 1 additions per level;  sort  N W entries at 4.1e10 /s;  schedule ~ buckets / 1e4;  host Horner ~ 100 us
+Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, size_t stride) {
+    Plan best{};
+    double best_cost = 1e300;
+    for (unsigned c = 7; c <= 22; c++) {
+        if (forced_c && c != forced_c) continue;
+        Plan p{};
+        p.c = c;
+        p.nwin = (256 + c - 1) / c;
+        // sort geometry: lo bits share a 32-bit entry with the point index and the sign; the coarse bins of one
+        // window must fit the LDS counter array
+        uint32_t idx_bits = 1;
+        const uint64_t nidx = shared ? (uint64_t)std::max(stride, n) * p.nwin : n;
+        while ((1ull << idx_bits) < nidx) idx_bits++;
+        if (idx_bits > 30) continue;
+        uint32_t lo_bits = std::min<uint32_t>(std::min<uint32_t>(8, c - 1), 31 - idx_bits);
+        if (((1u << (c - 1)) >> lo_bits) > msmk::SORT_MAX_COUNTERS) continue;
+        p.lo_bits = lo_bits;
+        if ((uint64_t)n * p.nwin >= (1ull << 32)) continue;   // entry offsets are 32-bit
+        p.nb = 1u << (c - 1);
+        p.bwin = shared ? 1 : p.nwin;
+        p.nbuckets = (uint64_t)p.nb * p.bwin;
+        // reduce geometry: the smallest L = 2^logL buckets per logical lane that still lets every chunk's wave run at once
+        // (<= max_chunks chunks of NLL * L buckets), capped at L = 64
+        const uint32_t log_ll = (uint32_t)cc.log_ll;
+        if (c - 1 < log_ll) continue;
+        p.logL = 0;
+        while (p.logL < 6 && p.logL + log_ll < c - 1 && (p.nbuckets >> (log_ll + p.logL)) > cc.max_chunks) p.logL++;
+        p.chunk_log = log_ll + p.logL;
+        p.chunks_per_win = p.nb >> p.chunk_log;
+        p.nchunks = (uint64_t)p.chunks_per_win * p.bwin;
+        // work-item size: twice the mean bucket load (uniform scalars then never split), at least 32 entries
+        const double entries = (double)n * p.nwin;
+        double mean = entries / (double)p.nbuckets;
+        p.logT = 5;
+        while ((double)(1u << p.logT) < 2.0 * mean && p.logT < 20) p.logT++;
+        const double T = (double)(1u << p.logT);
+        // The top window holds only 255 - c (nwin - 1) significant bits: its n entries share 2^top_bits buckets, and
+        // buckets beyond T entries are split and merged by a binary tree
+        int top_bits = std::max(0, std::min<int>(255 - (int)c * ((int)p.nwin - 1), (int)c - 1));
+        double per_bucket = (double)n / (double)(1u << top_bits) + (shared ? mean : 0.0);
+        int merge_levels = 0;
+        for (double x = per_bucket; x > T; x *= 0.5) merge_levels++;
+        const double item_len = std::min(T, std::max(mean, std::min(per_bucket, T)));   // entries a lane walks serially
+        const double rounds = (double)((p.nchunks + cc.max_chunks - 1) / cc.max_chunks);
+        int levels = 0;
+        for (uint32_t m = p.chunks_per_win; m > 1; m = (m + (1u << log_ll) - 1) >> log_ll) levels++;
+        double cost = std::max(entries / cc.add_per_us, item_len * cc.lane_add_us) + merge_levels * cc.merge_us +
+                      rounds * (2.0 * (1u << p.logL) + 2.0 * log_ll + p.logL + 1.0) * cc.step_us +
+                      std::max(1, levels) * ((2.0 * log_ll + 1.0) * cc.step_us + 8.0) + entries / 41000.0 + (double)p.nbuckets / 1e4 +
+                      (shared ? 20.0 : 100.0);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = p;
+        }
+    }
+    return best;
+}
+
+namespace {
+
+// k_coarse is compiled per window size (static digit extraction): dispatch on c = 7..22
+template <bool SCATTER, int CB = 7>
+void launch_coarse(uint32_t c, dim3 grid, dim3 block, hipStream_t s, const uint32_t* scalars, const uint8_t* flags, const msmk::SortGeom& g,
+                   uint32_t* tilecnt, const uint32_t* bin_base, uint32_t* coarse) {
+    if constexpr (CB > 22) {
+        throw HipFail{"window_bits out of range"};
+    } else {
+        if (c == CB)
+            hipLaunchKernelGGL((msmk::k_coarse<SCATTER, CB>), grid, block, 0, s, scalars, flags, g, tilecnt, bin_base, coarse);
+        else
+            launch_coarse<SCATTER, CB + 1>(c, grid, block, s, scalars, flags, g, tilecnt, bin_base, coarse);
+    }
+}
+
+}  // namespace
+
+void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, const uint8_t* d_flags, size_t n, unsigned fmt, bool shared_buckets,
+                       size_t stride, int ev0, SortOut& out) {
+    const size_t entries_cap = (size_t)n * pl.nwin;
+    d.hist.ensure(pl.nbuckets * 4);
+    d.offsets.ensure((pl.nbuckets + 1) * 4);
+    d.woff.ensure((pl.nbuckets + 1) * 4);
+    d.meta.ensure(16);
+    d.sorted.ensure(entries_cap * 4);
+    if (!d.h_meta) HIP_TRY(hipHostMalloc((void**)&d.h_meta, 16, hipHostMallocDefault));
+
+    hipStream_t s = d.stream;
+    HIP_TRY(hipEventRecord(d.ev[ev0], s));
+    // ---- two-level LDS-staged bucket sort (geometry in msmk::SortGeom)
+    msmk::SortGeom g{};
+    g.n = (uint32_t)n; g.fmt = fmt; g.c = pl.c; g.nwin = pl.nwin;
+    g.shared = shared_buckets ? 1u : 0u;
+    g.stride = (uint32_t)stride;
+    g.lo_bits = pl.lo_bits;
+    g.H = pl.nb >> g.lo_bits;
+    // A tile contributes tile_pts / H entries to each coarse bin of a window, written as one contiguous run: keep
+    // runs >= 64 entries (256 B) or the 4-byte scatter is write-amplified (9.5 ms at n = 2^24 with 16-entry runs).
+    size_t want = std::max<size_t>(std::max<size_t>(4096, n / 512), (size_t)64 * g.H / (shared_buckets ? pl.nwin : 1));
+    g.tile_pts = (uint32_t)((std::min(want, n) + 1023) / 1024 * 1024);
+    g.tiles = (uint32_t)((n + g.tile_pts - 1) / g.tile_pts);
+    const uint32_t coarse_block = g.tile_pts >= 16384 ? 1024 : 256;
+    g.wgroup = shared_buckets ? pl.nwin : std::max<uint32_t>(1, std::min<uint32_t>(pl.nwin, msmk::SORT_MAX_COUNTERS / g.H));
+    g.ngroups = (pl.nwin + g.wgroup - 1) / g.wgroup;
+    g.nbins = pl.bwin * g.H;
+    d.tilecnt.ensure((size_t)g.tiles * g.nbins * 4);
+    d.bin_tot.ensure((size_t)g.nbins * 4);
+    d.bin_base.ensure((size_t)(g.nbins + 1) * 4);
+    d.coarse.ensure(entries_cap * 4);
+    launch_coarse<false>(pl.c, dim3(g.tiles, g.ngroups), dim3(coarse_block), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
+                         (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(msmk::k_colscan, dim3((g.nbins + 255) / 256), dim3(256), 0, s, (uint32_t*)d.tilecnt.p, g.nbins, g.tiles,
+                       (uint32_t*)d.bin_tot.p);
+    hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.bin_tot.p, g.nbins, (uint32_t*)d.bin_base.p);
+    launch_coarse<true>(pl.c, dim3(g.tiles, g.ngroups), dim3(coarse_block), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
+                        (const uint32_t*)d.bin_base.p, (uint32_t*)d.coarse.p);
+    HIP_TRY(hipEventRecord(d.ev[ev0 + 1], s));
+    // fine sort over bin segments (upper bound on the segment count: one per bin plus one per FINE_SEG entries)
+    uint32_t segs_cap = g.nbins + (uint32_t)(entries_cap / msmk::FINE_SEG) + 1;
+    d.seg_cnt.ensure((size_t)g.nbins * 4);
+    d.seg_base.ensure((size_t)(g.nbins + 1) * 4);
+    d.segcnt.ensure((size_t)segs_cap * (1u << g.lo_bits) * 4);
+    hipLaunchKernelGGL(msmk::k_seg_count, dim3((g.nbins + 255) / 256), dim3(256), 0, s, (const uint32_t*)d.bin_base.p, g.nbins,
+                       (uint32_t*)d.seg_cnt.p);
+    hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.seg_cnt.p, g.nbins, (uint32_t*)d.seg_base.p);
+    hipLaunchKernelGGL(msmk::k_fine_count, dim3(segs_cap), dim3(256), 0, s, (const uint32_t*)d.coarse.p, (const uint32_t*)d.bin_base.p,
+                       (const uint32_t*)d.seg_base.p, g, (uint32_t*)d.segcnt.p);
+    hipLaunchKernelGGL(msmk::k_fine_scan, dim3(g.nbins), dim3(256), 0, s, (const uint32_t*)d.seg_base.p, g, (uint32_t*)d.segcnt.p,
+                       (uint32_t*)d.hist.p);
+    hipLaunchKernelGGL(msmk::k_fine_scatter, dim3(segs_cap), dim3(256), 0, s, (const uint32_t*)d.coarse.p, (const uint32_t*)d.bin_base.p,
+                       (const uint32_t*)d.seg_base.p, g, (const uint32_t*)d.segcnt.p, (uint32_t*)d.sorted.p);
+    HIP_TRY(hipEventRecord(d.ev[ev0 + 2], s));
+    // ---- schedule: <= 256 blocks of 1024 lanes, each lane owning per_blk/1024 consecutive buckets
+    uint32_t per_blk = 4096;
+    while ((pl.nbuckets + per_blk - 1) / per_blk > 256) per_blk <<= 1;
+    uint32_t nblk = (uint32_t)((pl.nbuckets + per_blk - 1) / per_blk);
+    size_t items_cap = pl.nbuckets + (entries_cap >> pl.logT) + 1;  // one per bucket plus one per T entries
+    d.sched.ensure((size_t)(3 + msmk::SCHED_CLASSES) * nblk * 4);
+    d.order.ensure(items_cap * 4);
+    d.item_bucket.ensure(items_cap * 4);
+    d.merge_list.ensure(items_cap * 4);
+    uint32_t* blk_e = (uint32_t*)d.sched.p;
+    uint32_t* blk_i = blk_e + nblk;
+    uint32_t* blk_max = blk_i + nblk;
+    uint32_t* blk_cls = blk_max + nblk;
+    hipLaunchKernelGGL(msmk::k_sched1, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT,
+                       nblk, blk_e, blk_i, blk_cls, blk_max);
+    hipLaunchKernelGGL(msmk::k_sched2, dim3(1), dim3(1024), 0, s, nblk, blk_e, blk_i, blk_cls, (const uint32_t*)blk_max,
+                       (uint32_t*)d.meta.p);
+    hipLaunchKernelGGL(msmk::k_sched3, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT,
+                       nblk, (const uint32_t*)blk_e, (const uint32_t*)blk_i, (const uint32_t*)blk_cls, (uint32_t*)d.offsets.p,
+                       (uint32_t*)d.woff.p, (uint32_t*)d.order.p, (uint32_t*)d.item_bucket.p, (uint32_t*)d.merge_list.p,
+                       (uint32_t*)d.meta.p);
+    // the item count sizes the next launches: one small read-back into pinned memory (the only mid-pipeline sync)
+    HIP_TRY(hipMemcpyAsync(d.h_meta, d.meta.p, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(d.ev[ev0 + 3], s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    out.nitems = d.h_meta[0];
+    out.max_items = d.h_meta[1];
+    out.entries = d.h_meta[2];
+    out.nlist = d.h_meta[3];
+}
+
+}  // namespace mi

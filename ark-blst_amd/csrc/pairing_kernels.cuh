@@ -6,11 +6,12 @@
 //   k_fp12_prod          one multiplication-tree level, six lanes per output: out[g] = prod in[g*K .. g*K+K)
 //   k_fp12_to_raw        internal form -> the reference's blst_fp12 (12 x blst_fp, Montgomery R = 2^384)
 //   k_miller_loop        the first version, one lane per pair for the whole loop (generic pairing.cuh code; 4 KB of
-//                        scratch per lane) — kept behind MI_PAIRING_SINGLE_LANE=1 as a second implementation to cross-check
+//                        scratch per lane) — compiled into test builds only (MI_TEST_HOOKS) as a second implementation to cross-check
 // A pair with P or Q at infinity contributes 1 (pairing.rs:58-60).
 // Device form of an Fp12: 12 slots of 16 words (14 limbs used), order c0.c0.c0, c0.c0.c1, c0.c1.c0, ... as blst_fp12.
 #pragma once
-#include "msm_kernels.cuh"
+#include "kernels_common.cuh"
+#include "coop_fp2.cuh"
 #include "pairing.cuh"
 
 namespace msmk {
@@ -32,6 +33,7 @@ __device__ __forceinline__ void store_fp12(uint32_t* p, const PTower::E12& a) {
     for (int i = 0; i < 6; i++) ElemIO<ec::Fp2>::store(p + 32 * i, c[i]);
 }
 
+#if defined(MI_TEST_HOOKS)   // the first version, one lane per pair: a second implementation for cross-checks (test builds only)
 __global__ void __launch_bounds__(64, 1) k_miller_loop(const uint32_t* __restrict__ g1_raw, const uint32_t* __restrict__ g2_raw, uint32_t n,
                                                        uint32_t* __restrict__ out) {
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
@@ -56,6 +58,7 @@ __global__ void __launch_bounds__(64, 1) k_miller_loop(const uint32_t* __restric
     }
     store_fp12(out + (size_t)i * FP12_WORDS, f);
 }
+#endif
 
 
 // ------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,388 @@
+// Two-level LDS-staged bucket sort and the work-item schedule (curve independent).  Compiled in msm_sort.hip only.
+#pragma once
+#include "kernels_common.cuh"
+
+namespace msmk {
+
+// ---------------------------------------------------------------------------------------------- bucket sort
+// Two-level sort of the N*W (window, bucket) keys, staged through LDS — replaces one global atomic per key in the
+// histogram pass and one returning global atomic + 4-byte scatter per key in the scatter pass.
+//   bucket id = (hi, lo): lo = low `lo_bits` (<= 8) bits -> F = 2^lo_bits fine buckets, H = 2^(c-1) / F coarse bins
+//   level 1 (global, coarse):  k_coarse_count   per tile of points: LDS histogram over (window, hi)  -> tilecnt[tile][bin]
+//                              k_colscan        per bin: exclusive scan over tiles, bin totals
+//                              k_binscan        exclusive scan of the bin totals                     -> bin_base[bin]
+//                              k_coarse_scatter per tile: LDS cursors seeded with the scanned bases; entries
+//                                               (index | sign | lo) land in their coarse bin of `coarse`
+//   level 2 (LDS, fine):       k_fine_count / k_fine_scan / k_fine_scatter over bin SEGMENTS (see below)
+//                                               -> sorted[] in (window, bucket) order and hist[window][bucket]
+// Windows are processed in groups of `wgroup` so that wgroup * H counters fit LDS (<= 16384 counters, 64 KB).
+struct SortGeom {
+    uint32_t n, fmt, c, nwin;
+    uint32_t lo_bits, H;          // fine bits, coarse bins per window
+    uint32_t tiles, tile_pts;     // point tiles (grid.x) and points per tile (multiple of 1024)
+    uint32_t wgroup, ngroups;     // windows per group, groups (grid.y)
+    uint32_t nbins;               // bucket windows * H
+    uint32_t shared, stride;      // shared = 1: every digit window feeds ONE bucket set (precomputed 2^(c j) P tables of
+                                  // `stride` points each); entry index = w * stride + i
+};
+constexpr uint32_t SORT_MAX_COUNTERS = 16384;  // 64 KB of LDS counters per workgroup (2 workgroups per CU)
+
+// entry in `coarse`: (point index << (lo_bits+1)) | (negative << lo_bits) | lo
+template <bool SCATTER, int CB>
+__global__ void __launch_bounds__(1024) k_coarse(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flags, SortGeom g,
+                                                 uint32_t* __restrict__ tilecnt, const uint32_t* __restrict__ bin_base,
+                                                 uint32_t* __restrict__ coarse) {
+    __shared__ uint32_t cnt[SORT_MAX_COUNTERS];
+    const uint32_t tile = blockIdx.x, grp = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
+    uint32_t w0 = grp * g.wgroup, w1 = w0 + g.wgroup < g.nwin ? w0 + g.wgroup : g.nwin;
+    const uint32_t bin0 = g.shared ? 0u : w0 * g.H;
+    uint32_t ncnt = (g.shared ? 1u : (w1 - w0)) * g.H;
+    for (uint32_t k = t; k < ncnt; k += nt) {
+        if (SCATTER) {
+            uint32_t bin = bin0 + k;
+            cnt[k] = bin_base[bin] + tilecnt[(size_t)tile * g.nbins + bin];  // where this tile's run of the bin starts
+        } else {
+            cnt[k] = 0;
+        }
+    }
+    __syncthreads();
+    uint32_t lo_mask = (1u << g.lo_bits) - 1u;
+    uint32_t p0 = tile * g.tile_pts, p1 = p0 + g.tile_pts < g.n ? p0 + g.tile_pts : g.n;
+    for (uint32_t i = p0 + t; i < p1; i += nt) {
+        if (inf_flags[i] != 0) continue;  // infinity base: contributes nothing
+        uint32_t s[8];
+        load_scalar(s, scalars, i, g.fmt);
+        for_each_digit_static<CB>(s, w0, w1, [&](uint32_t w, uint32_t b, bool neg) {
+            uint32_t k = (g.shared ? 0u : (w - w0) * g.H) + (b >> g.lo_bits);
+            uint32_t pos = atomicAdd(&cnt[k], 1u);
+            uint32_t idx = g.shared ? w * g.stride + i : i;
+            if (SCATTER) coarse[pos] = (idx << (g.lo_bits + 1)) | ((neg ? 1u : 0u) << g.lo_bits) | (b & lo_mask);
+        });
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t k = t; k < ncnt; k += nt) tilecnt[(size_t)tile * g.nbins + bin0 + k] = cnt[k];
+    }
+}
+
+// per bin: exclusive scan over the tiles (in place) and the bin total.  One lane per bin: coalesced across bins.
+__global__ void __launch_bounds__(256) k_colscan(uint32_t* __restrict__ tilecnt, uint32_t nbins, uint32_t tiles,
+                                                 uint32_t* __restrict__ bin_tot) {
+    uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nbins) return;
+    uint32_t run = 0;
+    for (uint32_t k = 0; k < tiles; k++) {
+        uint32_t v = tilecnt[(size_t)k * nbins + b];
+        tilecnt[(size_t)k * nbins + b] = run;
+        run += v;
+    }
+    bin_tot[b] = run;
+}
+
+// exclusive scan of m <= ~100k values by one workgroup; out[m] = total
+__global__ void __launch_bounds__(1024) k_binscan(const uint32_t* __restrict__ in, uint32_t m, uint32_t* __restrict__ out) {
+    __shared__ uint32_t part[1024];
+    uint32_t t = threadIdx.x;
+    uint32_t per = (m + 1023) / 1024;
+    uint32_t lo = t * per, hi = lo + per < m ? lo + per : m;
+    uint32_t sum = 0;
+    for (uint32_t k = lo; k < hi; k++) sum += in[k];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (uint32_t k = lo; k < hi; k++) {
+        uint32_t v = in[k];
+        out[k] = run;
+        run += v;
+    }
+    if (t == 1023) out[m] = part[1023];
+}
+
+// ---- level 2: fine sort.  A coarse bin is cut into SEGMENTS of at most FINE_SEG entries, one workgroup each, so a
+// heavy bin (skewed scalars; the short top window, whose n entries share a handful of buckets) is spread over
+// the chip instead of being streamed by a single workgroup (measured: 30 ms for two 8 M-entry bins at n = 2^24).
+//   k_seg_count   segments per bin                       -> seg_cnt[bin]      (then k_binscan -> seg_base[bin])
+//   k_fine_count  per segment: LDS histogram of lo       -> segcnt[seg][lo]
+//   k_fine_scan   per bin: scan over its segments and over lo -> segcnt becomes the start of (seg, lo) inside the
+//                 bin; emits hist[window][bucket]
+//   k_fine_scatter per segment: LDS cursors seeded from segcnt -> sorted[]
+constexpr uint32_t FINE_SEG = 8192;
+
+__global__ void __launch_bounds__(256) k_seg_count(const uint32_t* __restrict__ bin_base, uint32_t nbins, uint32_t* __restrict__ seg_cnt) {
+    uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nbins) return;
+    uint32_t sz = bin_base[b + 1] - bin_base[b];
+    seg_cnt[b] = sz == 0 ? 1u : (sz + FINE_SEG - 1) / FINE_SEG;
+}
+
+// segment id -> (bin, first entry, one-past-last entry); identity guess first (no bin split before it), else binary search
+__device__ __forceinline__ bool seg_locate(uint32_t seg, const uint32_t* seg_base, const uint32_t* bin_base, uint32_t nbins,
+                                           uint32_t& bin, uint32_t& beg, uint32_t& end) {
+    if (seg >= seg_base[nbins]) return false;
+    uint32_t b = seg < nbins ? seg : nbins - 1;
+    if (!(seg_base[b] <= seg && seg < seg_base[b + 1])) {
+        uint32_t lo = 0, hi = b;
+        while (lo < hi) {
+            uint32_t mid = (lo + hi + 1) >> 1;
+            if (seg_base[mid] <= seg) lo = mid; else hi = mid - 1;
+        }
+        b = lo;
+    }
+    uint32_t k = seg - seg_base[b];
+    bin = b;
+    beg = bin_base[b] + k * FINE_SEG;
+    uint32_t bend = bin_base[b + 1];
+    end = beg + FINE_SEG < bend ? beg + FINE_SEG : bend;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_fine_count(const uint32_t* __restrict__ coarse, const uint32_t* __restrict__ bin_base,
+                                                    const uint32_t* __restrict__ seg_base, SortGeom g, uint32_t* __restrict__ segcnt) {
+    __shared__ uint32_t cnt[256];
+    __shared__ uint32_t sb[3];
+    uint32_t t = threadIdx.x, seg = blockIdx.x;
+    if (t == 0) {
+        uint32_t bin = 0, beg = 0, end = 0;
+        bool ok = seg_locate(seg, seg_base, bin_base, g.nbins, bin, beg, end);
+        sb[0] = ok ? beg : 1u; sb[1] = ok ? end : 0u; sb[2] = ok ? 1u : 0u;
+    }
+    cnt[t] = 0;
+    __syncthreads();
+    if (!sb[2]) return;
+    uint32_t beg = sb[0], end = sb[1];
+    uint32_t F = 1u << g.lo_bits, lo_mask = F - 1u;
+    for (uint32_t i = beg + t; i < end; i += 256) atomicAdd(&cnt[coarse[i] & lo_mask], 1u);
+    __syncthreads();
+    if (t < F) segcnt[(size_t)seg * F + t] = cnt[t];
+}
+
+// one workgroup per bin, lane = lo.  segcnt[seg][lo] <- offset of (seg, lo) relative to the bin start.
+__global__ void __launch_bounds__(256) k_fine_scan(const uint32_t* __restrict__ seg_base, SortGeom g, uint32_t* __restrict__ segcnt,
+                                                   uint32_t* __restrict__ hist) {
+    __shared__ uint32_t scan[256];
+    uint32_t bin = blockIdx.x, t = threadIdx.x;
+    uint32_t F = 1u << g.lo_bits;
+    uint32_t s0 = seg_base[bin], s1 = seg_base[bin + 1];
+    uint32_t tot = 0;
+    if (t < F)
+        for (uint32_t sg = s0; sg < s1; sg++) {
+            uint32_t v = segcnt[(size_t)sg * F + t];
+            segcnt[(size_t)sg * F + t] = tot;   // exclusive over the segments of this (bin, lo)
+            tot += v;
+        }
+    scan[t] = t < F ? tot : 0;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        uint32_t v = t >= d ? scan[t - d] : 0;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    if (t < F) {
+        hist[(size_t)bin * F + t] = tot;                 // bucket (window, hi, lo) has index bin * F + lo
+        uint32_t lo_base = scan[t] - tot;                // start of fine bucket lo inside the bin
+        for (uint32_t sg = s0; sg < s1; sg++) segcnt[(size_t)sg * F + t] += lo_base;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_fine_scatter(const uint32_t* __restrict__ coarse, const uint32_t* __restrict__ bin_base,
+                                                      const uint32_t* __restrict__ seg_base, SortGeom g,
+                                                      const uint32_t* __restrict__ segcnt, uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t cur[256];
+    __shared__ uint32_t sb[4];
+    uint32_t t = threadIdx.x, seg = blockIdx.x;
+    if (t == 0) {
+        uint32_t bin = 0, beg = 0, end = 0;
+        bool ok = seg_locate(seg, seg_base, bin_base, g.nbins, bin, beg, end);
+        sb[0] = beg; sb[1] = end; sb[2] = ok ? 1u : 0u; sb[3] = ok ? bin_base[bin] : 0u;
+    }
+    __syncthreads();
+    if (!sb[2]) return;
+    uint32_t beg = sb[0], end = sb[1], bin_beg = sb[3];
+    uint32_t F = 1u << g.lo_bits, lo_mask = F - 1u;
+    cur[t] = t < F ? bin_beg + segcnt[(size_t)seg * F + t] : 0u;
+    __syncthreads();
+    uint32_t sh = g.lo_bits + 1;
+    for (uint32_t i = beg + t; i < end; i += 256) {
+        uint32_t e = coarse[i];
+        uint32_t pos = atomicAdd(&cur[e & lo_mask], 1u);
+        sorted[pos] = (e >> sh) | (((e >> g.lo_bits) & 1u) << 31);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- scan / schedule
+// Three small launches turn the histogram into (a) entry offsets for the scatter, (b) WORK ITEMS and (c) a
+// length-sorted processing order for them:
+//   * a bucket with cnt entries becomes max(1, ceil(cnt / T)) items of at most T = 2^logT entries, so a heavy
+//     bucket (skewed scalars, or the short top window) is spread over many lanes instead of serialising one;
+//   * order[] lists item ids by DESCENDING length class (65 classes): the 64 lanes of a wave then run the same
+//     number of additions (bucket loads are Poisson distributed: unsorted, a wave waits for its longest lane,
+//     ~70 % lane efficiency at a mean of 32) and the longest items start first.
+// Layout: nblk <= 256 blocks of 1024 lanes; block k owns `per_blk` consecutive buckets, lane t owns
+// per_blk/1024 consecutive ones.  item id of (bucket b, chunk k) = woff[b] + k.
+constexpr int SCHED_CLASSES = 65;
+
+__device__ __forceinline__ uint32_t items_of(uint32_t cnt, uint32_t logT) {
+    return cnt == 0 ? 1u : (cnt + (1u << logT) - 1u) >> logT;
+}
+__device__ __forceinline__ uint32_t class_of(uint32_t len, uint32_t logT) { return (len << 6) >> logT; }  // 0..64
+
+__global__ void __launch_bounds__(1024) k_sched1(const uint32_t* __restrict__ hist, uint32_t m, uint32_t per_blk, uint32_t logT,
+                                                 uint32_t nblk, uint32_t* __restrict__ blk_e, uint32_t* __restrict__ blk_i,
+                                                 uint32_t* __restrict__ blk_cls, uint32_t* __restrict__ blk_max) {
+    __shared__ uint32_t cls[SCHED_CLASSES];
+    __shared__ uint32_t se, si, smax;
+    uint32_t t = threadIdx.x, blk = blockIdx.x;
+    if (t < SCHED_CLASSES) cls[t] = 0;
+    if (t == 0) { se = 0; si = 0; smax = 1; }
+    __syncthreads();
+    uint32_t per_t = per_blk >> 10;
+    uint32_t lo = blk * per_blk + t * per_t, hi = lo + per_t < m ? lo + per_t : m;
+    uint32_t sum_e = 0, sum_i = 0, mx = 1, T = 1u << logT;
+    for (uint32_t k = lo; k < hi; k++) {
+        uint32_t h = hist[k], it = items_of(h, logT);
+        sum_e += h;
+        sum_i += it;
+        mx = it > mx ? it : mx;
+        if (it > 1) atomicAdd(&cls[64], it - 1);
+        atomicAdd(&cls[class_of(h - (it - 1) * T, logT)], 1u);
+    }
+    atomicAdd(&se, sum_e);
+    atomicAdd(&si, sum_i);
+    atomicMax(&smax, mx);
+    __syncthreads();
+    if (t < SCHED_CLASSES) blk_cls[t * nblk + blk] = cls[t];
+    if (t == 0) { blk_e[blk] = se; blk_i[blk] = si; blk_max[blk] = smax; }
+}
+
+// one workgroup: exclusive scans over the <= 256 block sums, and per (class, block) the base position in order[]
+__global__ void __launch_bounds__(1024) k_sched2(uint32_t nblk, uint32_t* __restrict__ blk_e, uint32_t* __restrict__ blk_i,
+                                                 uint32_t* __restrict__ blk_cls, const uint32_t* __restrict__ blk_max,
+                                                 uint32_t* __restrict__ meta) {
+    __shared__ uint32_t a[256], b[256], ctot[SCHED_CLASSES], cbase[SCHED_CLASSES];
+    uint32_t t = threadIdx.x;
+    uint32_t ve = 0, vi = 0;
+    if (t < 256) {
+        ve = t < nblk ? blk_e[t] : 0;
+        vi = t < nblk ? blk_i[t] : 0;
+        a[t] = ve;
+        b[t] = vi;
+    }
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        uint32_t xa = 0, xb = 0;
+        if (t < 256 && t >= d) { xa = a[t - d]; xb = b[t - d]; }
+        __syncthreads();
+        if (t < 256) { a[t] += xa; b[t] += xb; }
+        __syncthreads();
+    }
+    if (t < nblk) { blk_e[t] = a[t] - ve; blk_i[t] = b[t] - vi; }
+    // class rows: wave w handles classes w, w+16, ...; exclusive scan of each row in chunks of 64 lanes
+    uint32_t wave = t >> 6, lane = t & 63;
+    for (uint32_t c = wave; c < SCHED_CLASSES; c += 16) {
+        uint32_t run = 0;
+        for (uint32_t base = 0; base < nblk; base += 64) {
+            uint32_t idx = base + lane;
+            uint32_t v = idx < nblk ? blk_cls[c * nblk + idx] : 0, incl = v;
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t u = __shfl_up(incl, d, 64);
+                if ((int)lane >= d) incl += u;
+            }
+            if (idx < nblk) blk_cls[c * nblk + idx] = run + incl - v;
+            run += __shfl(incl, 63, 64);
+        }
+        if (lane == 0) ctot[c] = run;
+    }
+    __syncthreads();
+    if (t < SCHED_CLASSES) {  // descending class order: class c starts after all longer classes
+        uint32_t above = 0;
+        for (uint32_t c = t + 1; c < SCHED_CLASSES; c++) above += ctot[c];
+        cbase[t] = above;
+    }
+    __syncthreads();
+    for (uint32_t idx = t; idx < SCHED_CLASSES * nblk; idx += 1024) blk_cls[idx] += cbase[idx / nblk];
+    if (t == 0) {
+        uint32_t mx = 1;
+        for (uint32_t k = 0; k < nblk; k++) mx = blk_max[k] > mx ? blk_max[k] : mx;
+        meta[0] = b[255];  // total items   (a[], b[] are inclusive scans; entries past nblk are zero)
+        meta[1] = mx;      // max items of any bucket
+        meta[2] = a[255];  // total entries
+        meta[3] = 0;       // merge-list length, filled by k_sched3
+    }
+}
+
+// per block: bucket-level exclusive scans -> offsets / cursor / woff; every item gets its slot in order[]
+__global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hist, uint32_t m, uint32_t per_blk, uint32_t logT,
+                                                 uint32_t nblk, const uint32_t* __restrict__ blk_e, const uint32_t* __restrict__ blk_i,
+                                                 const uint32_t* __restrict__ blk_cls, uint32_t* __restrict__ offsets,
+                                                 uint32_t* __restrict__ woff,
+                                                 uint32_t* __restrict__ order, uint32_t* __restrict__ item_bucket,
+                                                 uint32_t* __restrict__ merge_list, uint32_t* __restrict__ meta) {
+    __shared__ uint32_t pe[1024], pi[1024], cur[SCHED_CLASSES];
+    // buckets split into many items (skewed scalars: one bucket can hold all N entries) are written out by the whole
+    // workgroup after the per-lane pass; one lane doing it alone cost 0.65 ms for a bucket of 2^20 entries
+    constexpr uint32_t HV_CAP = 64, HV_MIN = 64;
+    __shared__ uint32_t hv_k[HV_CAP], hv_run[HV_CAP], hv_it[HV_CAP], hv_pos[HV_CAP], hv_mp[HV_CAP], hv_n;
+    uint32_t t = threadIdx.x, blk = blockIdx.x;
+    if (t == 0) hv_n = 0;
+    if (t < SCHED_CLASSES) cur[t] = blk_cls[t * nblk + blk];
+    uint32_t per_t = per_blk >> 10;
+    uint32_t lo = blk * per_blk + t * per_t, hi = lo + per_t < m ? lo + per_t : m;
+    uint32_t sum_e = 0, sum_i = 0, T = 1u << logT;
+    for (uint32_t k = lo; k < hi; k++) {
+        uint32_t h = hist[k];
+        sum_e += h;
+        sum_i += items_of(h, logT);
+    }
+    pe[t] = sum_e;
+    pi[t] = sum_i;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t xe = t >= d ? pe[t - d] : 0, xi = t >= d ? pi[t - d] : 0;
+        __syncthreads();
+        pe[t] += xe;
+        pi[t] += xi;
+        __syncthreads();
+    }
+    uint32_t run_e = blk_e[blk] + pe[t] - sum_e, run_i = blk_i[blk] + pi[t] - sum_i;
+    for (uint32_t k = lo; k < hi; k++) {
+        uint32_t h = hist[k], it = items_of(h, logT);
+        offsets[k] = run_e;
+        woff[k] = run_i;
+        if (it > 1) {  // full-length chunks of a split bucket: one reservation in the longest class
+            uint32_t pos = atomicAdd(&cur[64], it - 1);
+            uint32_t mp = atomicAdd(&meta[3], it);     // the merge passes only visit the items of split buckets
+            uint32_t slot = it >= HV_MIN ? atomicAdd(&hv_n, 1u) : HV_CAP;
+            if (slot < HV_CAP) {
+                hv_k[slot] = k; hv_run[slot] = run_i; hv_it[slot] = it; hv_pos[slot] = pos; hv_mp[slot] = mp;
+            } else {
+                for (uint32_t j = 0; j + 1 < it; j++) { order[pos + j] = run_i + j; item_bucket[run_i + j] = k; }
+                for (uint32_t j = 0; j < it; j++) merge_list[mp + j] = run_i + j;
+            }
+        }
+        uint32_t last = run_i + it - 1;
+        uint32_t pos = atomicAdd(&cur[class_of(h - (it - 1) * T, logT)], 1u);
+        order[pos] = last;
+        item_bucket[last] = k;
+        run_e += h;
+        run_i += it;
+    }
+    if (blk == nblk - 1 && t == 1023) { offsets[m] = run_e; woff[m] = run_i; }
+    __syncthreads();
+    const uint32_t nh = hv_n < HV_CAP ? hv_n : HV_CAP;
+    for (uint32_t s = 0; s < nh; s++) {
+        const uint32_t k = hv_k[s], r0 = hv_run[s], it = hv_it[s], pos = hv_pos[s], mp = hv_mp[s];
+        for (uint32_t j = t; j < it; j += 1024) {
+            if (j + 1 < it) { order[pos + j] = r0 + j; item_bucket[r0 + j] = k; }
+            merge_list[mp + j] = r0 + j;
+        }
+    }
+}
+
+}  // namespace msmk

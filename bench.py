@@ -320,7 +320,7 @@ def main() -> None:
                               "frac": MADS_PER_POINT[g] * n / (acc_ms * 1e-3) / 1e12 / MAD_PEAK_TLOPS,
                               "note": "integer VALU (v_mad_u64_u32) is the real bound of this path; HBM frac is low by construction"},
             "phases_ms": {k: sum(p[k] for p in prof_acc) / len(prof_acc) for k in
-                          ("digits_ms", "scan_ms", "scatter_ms", "accumulate_ms", "reduce_ms", "d2h_ms", "host_fold_ms", "total_ms")},
+                          ("digits_ms", "scan_ms", "scatter_ms", "accumulate_ms", "reduce_ms", "combine_ms", "d2h_ms", "host_fold_ms", "total_ms")},
             "input_gen_s": gen_s,
             "two_host_threads": two_thread,
             "pairing_2p16": pairing,

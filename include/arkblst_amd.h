@@ -70,8 +70,9 @@ typedef struct {
     double scatter_ms;      /* bucket scatter (sort by bucket) */
     double accumulate_ms;   /* bucket accumulation (dominant kernel) + merge of split buckets */
     double reduce_ms;       /* per-chunk weighted bucket reduction */
-    double d2h_ms;          /* partial sums device->host */
-    double host_fold_ms;    /* CPU tail: chunk combine + Horner fold over windows */
+    double combine_ms;      /* per-window combine of the chunk sums on the GPU */
+    double d2h_ms;          /* window sums device->host (one Jacobian point per window) */
+    double host_fold_ms;    /* CPU tail: Horner fold over the window sums, one thread */
     double total_ms;        /* wall time of the call */
     uint32_t window_bits;   /* c */
     uint32_t num_windows;   /* ceil(256 / c) */
@@ -94,17 +95,29 @@ int mi_msm_num_devices(const mi_ctx *ctx);
 int mi_msm_g1_set_bases(mi_ctx *ctx, const mi_g1_affine *bases, size_t n);
 int mi_msm_g2_set_bases(mi_ctx *ctx, const mi_g2_affine *bases, size_t n);
 
+/* Opt-in variant for a long-lived SRS: besides the bases, keep W = ceil(256 / c) tables T_j[i] = 2^(c j) * bases[i] resident
+ * (W x the memory, built once on the GPU: c doublings per point and table plus one batch inversion).  Every window of a later
+ * MSM over the resident set then feeds ONE bucket set: no per-window bucket reduction, no Horner doublings, and c can be
+ * larger (c = 20 at 2^20 points: 13 additions per point instead of 16).  window_bits = 0 lets the time model choose c.
+ * The reference has no counterpart (it re-uploads plain bases per call, src/gpu.rs:149); results are identical. */
+int mi_msm_g1_set_bases_precomputed(mi_ctx *ctx, const mi_g1_affine *bases, size_t n, unsigned window_bits);
+int mi_msm_g2_set_bases_precomputed(mi_ctx *ctx, const mi_g2_affine *bases, size_t n, unsigned window_bits);
+
 /* out = sum_i scalars[i] * bases[i], i < n.   Replaces gpu::msm::<G1Affine> (src/gpu.rs:226-241) and the CPU
  * multi_exp (src/g1.rs:614-617).  bases == NULL uses the first n resident bases.  Infinity bases contribute
- * nothing (the reference's blst path fails on them, src/g1.rs:682-688).  n == 0 returns infinity.  Blocking. */
+ * nothing (the reference's blst path fails on them, src/g1.rs:682-688).  n == 0 returns infinity.  Blocking.
+ * Any n: more than 2^26 points per device are processed in several passes whose sums are added (the reference's
+ * calc_chunk_size path, src/gpu.rs:64-85,238-239, is unfinished). */
 int mi_msm_g1(mi_ctx *ctx, const mi_g1_affine *bases, const uint8_t *scalars, size_t n, unsigned scalar_fmt,
               mi_g1 *out);
 int mi_msm_g2(mi_ctx *ctx, const mi_g2_affine *bases, const uint8_t *scalars, size_t n, unsigned scalar_fmt,
               mi_g2 *out);
 
-/* Same computation with the scalars ALREADY in device memory of the context's first device (hipMalloc'd or
- * a torch CUDA tensor's data_ptr) and the bases resident: nothing crosses PCIe except the few-KB partial sums.
- * Single-device contexts only. */
+/* Same computation with the scalars ALREADY in device memory (hipMalloc'd or a torch CUDA tensor's data_ptr) and the bases
+ * resident: nothing crosses PCIe except one Jacobian point per window.  The library reads d_scalars on its OWN stream: the
+ * caller must have synchronised the stream that produced them (hipStreamSynchronize / torch.cuda.synchronize) before the
+ * call.  With a multi-device context device k reads its shard [lo_k, hi_k) of the one vector (peer access over xGMI when the
+ * vector lives on another device of the context). */
 int mi_msm_g1_device(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g1 *out);
 int mi_msm_g2_device(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g2 *out);
 
@@ -157,12 +170,10 @@ int mi_g2_sum(const mi_g2 *partials, size_t n, mi_g2 *out);
 /* Tuning / introspection. window_bits = 0 restores the built-in heuristic (cf. calc_window_size, src/gpu.rs:218-223). */
 int mi_msm_set_window_bits(mi_ctx *ctx, unsigned window_bits);
 int mi_msm_last_profile(const mi_ctx *ctx, mi_profile *out);
+/* Text of the CALLING THREAD's most recent failure (thread-local storage: the pointer stays valid until the same thread
+ * fails again, whatever other threads do on the context). */
 const char *mi_msm_last_error(const mi_ctx *ctx);
 const char *mi_msm_strerror(int code);
-
-/* Field-level test hooks (batch Montgomery multiply / add / sub on the device representation, I/O in blst_fp
- * form) — used by the parity tests to pin the device arithmetic against the oracle. op: 0 mul, 1 sqr(a), 2 add, 3 sub */
-int mi_test_fp_op(mi_ctx *ctx, int op, const mi_fp *a, const mi_fp *b, mi_fp *out, size_t n);
 
 #ifdef __cplusplus
 }

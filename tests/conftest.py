@@ -41,3 +41,11 @@ def ctx(pkg):
     c = pkg.Context([0])
     yield c
     c.close()
+
+
+@pytest.fixture(scope="session")
+def tctx(pkg):
+    """Context on the TEST build of the library (libarkblst_amd_test.so: the same sources with -DMI_TEST_HOOKS)."""
+    c = pkg.Context([0], test_hooks=True)
+    yield c
+    c.close()

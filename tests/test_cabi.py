@@ -23,12 +23,27 @@ def test_header_symbols_are_exported(pkg):
         assert hasattr(L, s), f"{s} declared in include/arkblst_amd.h but not exported"
 
 
+def _exported(path):
+    import subprocess
+
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
+    return {l.split()[-1] for l in out.splitlines() if " T " in l}
+
+
+def test_product_library_has_no_test_hooks(pkg):
+    """mi_test_* entry points exist only in the test build (csrc/test_hooks.h); the product exports exactly the header"""
+    prod = {s for s in _exported(pkg.lib_path()) if s.startswith("mi_")}
+    assert prod == set(_declared_symbols()), prod ^ set(_declared_symbols())
+    test = {s for s in _exported(pkg.lib_path(True)) if s.startswith("mi_")}
+    assert test - prod == {"mi_test_fp_op", "mi_test_set_pairing", "mi_test_set_max_part", "mi_test_fail_allocs"}
+
+
 def test_layout_sizes_match_reference_types(pkg):
     # blst_p1_affine 96, blst_p1 144, blst_p2_affine 192, blst_p2 288 (SURVEY Appendix A; src/gpu.rs:69-71)
     from ark_blst_amd import binding as b
 
     assert (b.G1_AFF, b.G1_JAC, b.G2_AFF, b.G2_JAC) == (96, 144, 192, 288)
-    assert C.sizeof(b.Profile) == 10 * 8 + 2 * 4 + 2 * 8 + 2 * 4
+    assert C.sizeof(b.Profile) == 11 * 8 + 2 * 4 + 2 * 8 + 2 * 4
 
 
 def test_strerror_and_invalid_args(pkg):

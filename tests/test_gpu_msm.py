@@ -18,7 +18,7 @@ def _canon(co, group, jac):
     return co.to_affine(group, jac)
 
 
-def test_fp_ops_match_oracle(ctx, co, o):
+def test_fp_ops_match_oracle(tctx, co, o):
     rnd = random.Random(7)
     n = 4096
     va = [rnd.randrange(o.P) for _ in range(n)]
@@ -28,10 +28,10 @@ def test_fp_ops_match_oracle(ctx, co, o):
     vb[:6] = edge[::-1]
     a = b"".join(o.fp_to_mont_bytes(v) for v in va)
     b = b"".join(o.fp_to_mont_bytes(v) for v in vb)
-    assert ctx.test_fp_op(0, a, b) == co.fp_mul(a, b)
-    assert ctx.test_fp_op(1, a, b) == co.fp_mul(a, a)
-    assert ctx.test_fp_op(2, a, b) == b"".join(o.fp_to_mont_bytes((x + y) % o.P) for x, y in zip(va, vb))
-    assert ctx.test_fp_op(3, a, b) == b"".join(o.fp_to_mont_bytes((x - y) % o.P) for x, y in zip(va, vb))
+    assert tctx.test_fp_op(0, a, b) == co.fp_mul(a, b)
+    assert tctx.test_fp_op(1, a, b) == co.fp_mul(a, a)
+    assert tctx.test_fp_op(2, a, b) == b"".join(o.fp_to_mont_bytes((x + y) % o.P) for x, y in zip(va, vb))
+    assert tctx.test_fp_op(3, a, b) == b"".join(o.fp_to_mont_bytes((x - y) % o.P) for x, y in zip(va, vb))
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 10, 500, 1024, 5000])

@@ -121,49 +121,43 @@ def test_pairs_sharded_over_devices(pkg, ctx, co):
         assert c3.multi_pairing(g1[:96], g2[:192]) == ctx.multi_pairing(g1[:96], g2[:192])
 
 
-def test_line_buffer_batches(co):
-    """more pairs than one line-buffer batch (2^17 in production; forced to 100 here through the test hook): a child
-    process, because the library reads MI_PAIRING_BATCH once"""
-    import os
-    import subprocess
-    import sys
+def test_line_buffer_batches(ctx, tctx, co):
+    """more pairs than one line-buffer batch (2^17 in production; forced to 100 through the test build's hook)"""
+    g1 = co.gen_bases("g1", 77, 257, 2)
+    g2 = co.gen_bases("g2", 78, 257, 2)
+    tctx.test_set_pairing(batch=100)
+    try:
+        got = tctx.multi_pairing(g1, g2)
+    finally:
+        tctx.test_set_pairing()
+    assert got == ctx.multi_pairing(g1, g2) and len(got) == 576
 
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys; sys.path.insert(0, %r)\n"
-        "import __graft_entry__ as ge\n"
-        "from oracle import coracle as co\n"
-        "pkg = ge.load_package()\n"
-        "g1 = co.gen_bases('g1', 77, 257, 2); g2 = co.gen_bases('g2', 78, 257, 2)\n"
-        "with pkg.Context([0]) as c: print(c.multi_pairing(g1, g2).hex())\n" % root)
-    env = dict(os.environ)
-    outs = []
-    for batch in ("100", None):
-        if batch:
-            env["MI_PAIRING_BATCH"] = batch
-        else:
-            env.pop("MI_PAIRING_BATCH", None)
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr
-        outs.append(r.stdout.strip().splitlines()[-1])
-    assert outs[0] == outs[1] and len(outs[0]) == 1152
+
+def test_single_lane_first_version_agrees(ctx, tctx, co):
+    """the one-lane-per-pair first version of the Miller loop (test builds only) as a second implementation"""
+    g1 = co.gen_bases("g1", 79, 70, 2)
+    g2 = co.gen_bases("g2", 80, 70, 2)
+    tctx.test_set_pairing(single_lane=True)
+    try:
+        got = tctx.multi_pairing(g1, g2)
+    finally:
+        tctx.test_set_pairing()
+    assert got == ctx.multi_pairing(g1, g2)
 
 
 @pytest.mark.parametrize("share", [2, 3, 8])
-def test_shared_squaring_accumulators(ctx, co, share):
+def test_shared_squaring_accumulators(tctx, co, share):
     """m pairs per accumulator (one Fp12 squaring per Miller step for all of them; production picks m = n / 2^14, capped
     at 8): forced through the test hook on sizes that do and do not divide by m, with infinity pairs, against the C oracle"""
-    import os
-
     for n in (1, share, share + 1, 997):
         g1 = bytearray(co.gen_bases("g1", SEED_P + 11, n, 8))
         g2 = bytearray(co.gen_bases("g2", SEED_Q + 11, n, 8))
         if n > 10:
             g1[96 * 5:96 * 6] = bytes(96)
             g2[192 * (n - 1):192 * n] = bytes(192)
-        os.environ["MI_PAIRING_SHARE"] = str(share)
+        tctx.test_set_pairing(share=share)
         try:
-            got = ctx.multi_pairing(bytes(g1), bytes(g2))
+            got = tctx.multi_pairing(bytes(g1), bytes(g2))
         finally:
-            del os.environ["MI_PAIRING_SHARE"]
+            tctx.test_set_pairing()
         assert got == co.multi_pairing(bytes(g1), bytes(g2), 8), (share, n)
