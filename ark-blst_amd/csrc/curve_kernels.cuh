@@ -312,13 +312,22 @@ __global__ void __launch_bounds__(64, CS::MAX_OCC) k_reduce_coop(const uint32_t*
     Pt run = CS::inf(), acc = CS::inf(), LP = CS::inf();
     const uint32_t s_scan = 2 * L, s_dbl = s_scan + CS::LOG_LL, s_comb = s_dbl + logL, s_end = s_comb + 1 + CS::LOG_LL;
     const bool rider = ll == NLL - 1;
+    // software pipeline of the bucket loads: the bucket of pair p + 1 and the index of pair p + 2 are requested while pair p
+    // is being added (two dependent loads of ~2 us would otherwise sit in front of every other step of the chain)
+    Pt nb = CS::load(partial + (size_t)wp[L - 1] * BK);
+    uint32_t idx2 = L > 1 ? wp[L - 2] : 0u;
 #pragma unroll 1
     for (uint32_t s = 0; s < s_end; s++) {
         Pt A, B;
         uint32_t dst;  // 0 run, 1 acc, 2 LP
         if (s < s_scan) {
             if ((s & 1u) == 0) {
-                A = run; B = CS::load(partial + (size_t)wp[L - 1 - (s >> 1)] * BK); dst = 0;
+                const uint32_t p = s >> 1;
+                A = run; B = nb; dst = 0;
+                if (p + 1 < L) {
+                    nb = CS::load(partial + (size_t)idx2 * BK);
+                    if (p + 2 < L) idx2 = wp[L - 3 - p];
+                }
             } else {
                 A = acc; B = run; dst = 1;
             }

@@ -81,6 +81,7 @@ HT::E12 device_miller(mi_ctx* ctx, DevState& d, const mi_g1_affine* p, const mi_
     (void)ctx;
 #endif
     size_t nvals = 0;   // Fp12 values the Miller kernels leave in lvl[0]
+    bool split_timed = false;
     if (single_lane) {
 #if defined(MI_TEST_HOOKS)
         hipLaunchKernelGGL(msmk::k_miller_loop, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, s, (const uint32_t*)dp.p, (const uint32_t*)dq.p,
@@ -98,10 +99,13 @@ HT::E12 device_miller(mi_ctx* ctx, DevState& d, const mi_g1_affine* p, const mi_
             hipLaunchKernelGGL(msmk::k_miller_lines2, dim3((2 * mm + 63) / 64), dim3(64), 0, s,
                                (const uint32_t*)dp.p + lo * msmk::Geo<msmk::G1C>::RAW_AFF, (const uint32_t*)dq.p + lo * msmk::Geo<msmk::G2C>::RAW_AFF,
                                mm, (uint32_t*)dlines.p);
+            if (lo == 0) HIP_TRY(hipEventRecord(d.ev[4], s));   // first batch: the two kernels timed separately (profile)
             hipLaunchKernelGGL(msmk::k_miller_accumulate, dim3((groups + msmk::MILLER_GROUPS - 1) / msmk::MILLER_GROUPS), dim3(64), 0, s,
                                (const uint32_t*)dlines.p, mm, share, (uint32_t*)lvl[0].p + nvals * msmk::FP12_WORDS);
+            if (lo == 0) HIP_TRY(hipEventRecord(d.ev[5], s));
             nvals += groups;
         }
+        split_timed = true;
     }
     HIP_TRY(hipEventRecord(d.ev[2], s));
     size_t m = nvals;
@@ -123,8 +127,13 @@ HT::E12 device_miller(mi_ctx* ctx, DevState& d, const mi_g1_affine* p, const mi_
     d.prof = mi_profile{};
     d.prof.n = n;
     d.prof.h2d_ms = ev_ms(d.ev[0], d.ev[1]);
-    d.prof.accumulate_ms = ev_ms(d.ev[1], d.ev[2]);   // Miller loops
+    d.prof.accumulate_ms = ev_ms(d.ev[1], d.ev[2]);   // Miller loops (line kernel + accumulate kernel, all batches)
     d.prof.reduce_ms = ev_ms(d.ev[2], d.ev[3]);       // multiplication tree
+    if (split_timed) {                                // first line batch (the whole call up to 2^17 pairs): the two kernels apart
+        d.prof.digits_ms = ev_ms(d.ev[1], d.ev[4]);   // k_miller_lines2
+        d.prof.scatter_ms = ev_ms(d.ev[4], d.ev[5]);  // k_miller_accumulate
+        d.prof.work_items = share;                    // pairs per accumulator
+    }
     return acc;
 }
 

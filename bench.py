@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
 """bench.py — G1 MSM points/sec on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 20] [--group g1]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n L] [--group g1|g2]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
               bench.py --gpus N --steps K --warmup W
 
-A "step" is one full MSM over one batch of 2^log_n synthetic (base, scalar) pairs PER GPU through the C ABI
-(mi_msm_g1_device): digit extraction, bucket sort, bucket accumulation, bucket reduction, host fold — nothing is
-cached between steps.  Inputs are resident in HBM when the timed region starts (bases as the resident SRS,
-scalars in a device buffer).  With N ranks the base set is N * 2^log_n points sharded contiguously (weak scaling,
-no data-path collective); each step ends with the RCCL all-gather of the N 144-byte partial sums and the
-deterministic fold on every rank.  The result of the last step is checked bit-exact (canonical affine bytes)
-against the closed form (sum s_i k_i) G.
+A "step" is one full MSM over one batch of synthetic (base, scalar) pairs through the C ABI (mi_msm_g1_device): digit
+extraction, bucket sort, bucket accumulation, bucket reduction, per-window combine, host Horner fold — nothing is cached
+between steps.  Inputs are resident in HBM when the timed region starts (bases as the resident SRS, scalars in a device
+buffer).
 
+  N = 1   BASELINE config #2: 2^20 points (override with --log-n).  The same JSON line carries, as `secondary`, the other
+          single-GPU configs of BASELINE.json — G1 2^24 (the north-star size), G2 2^20 (config #4), 2^16 pairs of
+          Miller loop + final exponentiation (config #5) — each with its own parity flag, roofline and (pairing) CPU baseline.
+  N > 1   BASELINE config #3: 2^24 points IN TOTAL, the base set sharded contiguously, 2^24 / N per rank (strong scaling;
+          --log-n L switches to 2^L per GPU, weak).  No data-path collective; each step ends with the RCCL all-gather of
+          the N 144-byte partial sums and the deterministic fold on every rank.
+
+The result of the last step is checked bit-exact (canonical affine bytes) against the closed form (sum s_i k_i) G.
 The oracle (oracle/) is used ONLY to generate the synthetic inputs, as the checker, and as the timed CPU baseline
 (`cpu_baseline`, kind "port": the reference's blst path cannot be built in this image).
 """
@@ -21,18 +26,276 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SEED_B, SEED_S = 0xA55E7 + 2, 0x5CA1A5 + 2   # BASELINE.md §3, config #2
+SEED_B, SEED_S = 0xA55E7 + 2, 0x5CA1A5 + 2     # BASELINE.md §3, config #2
 ALG_BYTES_PER_POINT = {"g1": 128, "g2": 224}   # base + scalar, each read once
-MADS_PER_POINT = {"g1": 48_000, "g2": 144_000} # SURVEY.md §8(d) canonical integer-op model
+FP_MULS_PER_ADD = {"g1": 10, "g2": 30}         # XYZZ mixed addition = 10 field multiplications; an Fp2 one = 3 Fp ones
+MADS_PER_FP_MUL = 300                          # 12^2 + 12^2 + 12 32-bit multiply-adds
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8 TB/s spec
-MAD_PEAK_TLOPS = 39.3                          # 1024 SIMD x 64 lanes x 2.4 GHz / 4 cyc (v_mad_u64_u32 is half rate:
-                                               # tools/ubench_valu.hip measured 33.4 T/s incl. loop overhead)
+MAD_PEAK_T = 39.3                              # 1024 SIMD x 64 lanes x 2.4 GHz / 4 cycles (v_mad_u64_u32 theoretical issue rate)
+MAD_MEASURED_T = 33.4                          # tools/ubench_valu.hip on MI355X: what a pure MAD loop reaches (profiles/r01_ubench_valu.txt)
+PAIRING_FP_MULS_PER_PAIR = 63 * (31 + 39) + 5 * (41 + 39)   # line + sparse Fp12 product per step, squarings shared
+
+
+def _host_threads() -> int:
+    """Threads for the CPU legs: the cgroup CPU quota when there is one (a 1-GPU box is given ~16 cores of a
+    256-thread host), else the affinity mask."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return max(1, int(int(quota) / int(period)))
+    except Exception:
+        pass
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    return min(n, 16)
+
+
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _mont_one() -> bytes:
+    """Montgomery form of 1 (R mod p), /root/reference/src/fp.rs:532 — Z coordinate of an affine point lifted to Jacobian."""
+    limbs = [0x760900000002FFFD, 0xEBF4000BC40C0002, 0x5F48985753C758BA, 0x77CE585370525745, 0x5C071A97A256EC6D, 0x15F65EC3FA80E493]
+    return b"".join(l.to_bytes(8, "little") for l in limbs)
+
+
+def _traffic(g: str, log_n, precomputed: bool):
+    """HBM bytes per launch of the accumulate kernel: measured with rocprofv3 PMC passes (tools/profile_bench.sh) on this
+    exact workload and committed under profiles/ (bench.py cannot collect counters itself); None when no summary matches."""
+    try:
+        key = f"msmk::k_accumulate<msmk::{g.upper()}C>"
+        files = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json")), reverse=True)
+        for f in files:
+            pj = json.load(open(os.path.join(ROOT, "profiles", f)))
+            wl = pj.get("workload")
+            if wl is None:   # round-1 summaries carry no workload key: the r01 MSM summaries are the default line
+                wl = {"group": "g1", "log_n": 20, "precomputed": False} if "_msm_" in f or f.startswith("r01_d_") else {}
+            if (wl.get("group"), wl.get("log_n"), bool(wl.get("precomputed"))) != (g, log_n, precomputed):
+                continue
+            if key in pj.get("kernels", {}) and "hbm_bytes_per_launch_corrected" in pj["kernels"][key]:
+                return pj["kernels"][key]["hbm_bytes_per_launch_corrected"], "profiles/" + f
+    except Exception:
+        pass
+    return None, None
+
+
+def _distort(scalars: bytes, n: int, dist: str) -> bytes:
+    if dist == "uniform":
+        return scalars
+    import numpy as np
+    a = np.frombuffer(scalars, dtype=np.uint8).reshape(n, 32).copy()
+    if dist == "zero_one":       # R1CS-like witness: bits
+        a[:, 1:] = 0
+        a[:, 0] &= 1
+    elif dist == "small64":      # 64-bit values
+        a[:, 8:] = 0
+    elif dist == "r1cs_mix":     # witness-like: half zeros, a quarter ones, a quarter full-size values
+        sel = a[:, 0] & 3
+        a[sel < 2] = 0
+        a[sel == 2] = 0
+        a[sel == 2, 0] = 1
+    elif dist == "all_ones":     # every scalar = 1: the plain sum of the bases, one bucket of N entries
+        a[:] = 0
+        a[:, 0] = 1
+    else:                        # every scalar identical: all points in one bucket per window
+        a[:] = a[0]
+    return a.tobytes()
+
+
+def _rooflines(g: str, n: int, log_n, acc_ms: float, nwin: int, precomputed: bool) -> dict:
+    alg_bytes = ALG_BYTES_PER_POINT[g] * n
+    gbs = alg_bytes / (acc_ms * 1e-3) / 1e9
+    traffic, src = _traffic(g, log_n, precomputed) if log_n is not None else (None, None)
+    mads = nwin * FP_MULS_PER_ADD[g] * MADS_PER_FP_MUL       # window-aware: one mixed addition per point and window
+    tmad = mads * n / (acc_ms * 1e-3) / 1e12
+    return {
+        "roofline": {"bound": "hbm", "kernel": f"k_accumulate<{g.upper()}C>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": alg_bytes,
+                     "kernel_ms": acc_ms,
+                     "note": "the bucket method re-reads each device point once per window: traffic ~ windows x algorithmic by "
+                             "design; the kernel is bound by integer VALU issue, see valu_roofline"},
+        "valu_roofline": {"model_mads_per_point": mads, "model": f"{nwin} windows x {FP_MULS_PER_ADD[g]} Fp-mul x {MADS_PER_FP_MUL} MAD",
+                          "achieved_Tmad_s": tmad, "peak_Tmad_s": MAD_PEAK_T, "frac": tmad / MAD_PEAK_T,
+                          "measured_peak_Tmad_s": MAD_MEASURED_T, "frac_of_measured_peak": tmad / MAD_MEASURED_T,
+                          "note": "integer VALU (v_mad_u64_u32) is the real bound of this path; HBM frac is low by construction"},
+    }
+
+
+class MsmLeg:
+    """One MSM workload on this rank's GPU: inputs, resident bases, device scalars, timed steps, parity."""
+
+    def __init__(self, pkg, co, torch, g, n, seed_b, seed_s, ncpu, device, dist="uniform", window_bits=0, precomputed=False):
+        self.pkg, self.co, self.torch, self.g, self.n = pkg, co, torch, g, n
+        self.seed_b, self.seed_s, self.ncpu = seed_b, seed_s, ncpu
+        t0 = time.time()
+        self.bases = co.gen_bases(g, seed_b, n, ncpu)
+        self.scalars = _distort(co.gen_scalars(seed_s, n), n, dist)
+        self.gen_s = time.time() - t0
+        self.ctx = pkg.Context([device])
+        if window_bits and not precomputed:
+            self.ctx.set_window_bits(window_bits)
+        t0 = time.time()
+        if precomputed:
+            self.ctx.set_bases_precomputed(g, self.bases, n, window_bits)
+        else:
+            self.ctx.set_bases(g, self.bases, n)
+        self.set_bases_s = time.time() - t0
+        self.d_scalars = torch.frombuffer(bytearray(self.scalars), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()   # the library reads the scalars on its own stream (include/arkblst_amd.h)
+
+    def call(self) -> bytes:
+        return self.ctx.msm_device(self.g, self.d_scalars.data_ptr(), self.n, self.pkg.SCALAR_CANONICAL)
+
+    def expected_affine(self) -> bytes:
+        return self.co.dlog_expected(self.g, self.scalars, self.seed_b, self.n)
+
+    def run(self, steps: int, warmup: int) -> dict:
+        for _ in range(warmup):
+            self.call()
+        self.torch.cuda.synchronize()
+        profs, result = [], b""
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            result = self.call()
+            profs.append(self.ctx.profile())
+        self.torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        return {"elapsed": elapsed, "result": result, "profs": profs}
+
+    def close(self):
+        self.ctx.close()
+        self.d_scalars = None
+
+
+def _phases(profs) -> dict:
+    keys = ("digits_ms", "scan_ms", "scatter_ms", "accumulate_ms", "reduce_ms", "combine_ms", "d2h_ms", "host_fold_ms", "total_ms")
+    return {k: sum(p[k] for p in profs) / len(profs) for k in keys}
+
+
+def _secondary_msm(pkg, co, torch, g, log_n, seed_off, ncpu, device, steps, precomputed=False, window_bits=0) -> dict:
+    n = 1 << log_n
+    leg = MsmLeg(pkg, co, torch, g, n, SEED_B + seed_off, SEED_S + seed_off, ncpu, device, precomputed=precomputed, window_bits=window_bits)
+    try:
+        r = leg.run(steps, 1)
+        ok = co.to_affine(g, r["result"]) == leg.expected_affine()
+        ph = _phases(r["profs"])
+        p0 = r["profs"][-1]
+        out = {"metric": f"{g.upper()} MSM points/sec", "value": n * steps / r["elapsed"], "unit": "points/s", "ms_per_step": r["elapsed"] / steps * 1e3,
+               "steps": steps, "bit_exact": ok, "workload": f"{g.upper()} MSM, 2^{log_n} random bases+scalars, bases resident"
+               + (" as precomputed 2^(c j) P tables" if precomputed else "") + ", scalars in HBM",
+               "window_bits": p0["window_bits"], "num_windows": p0["num_windows"], "phases_ms": ph, "input_gen_s": leg.gen_s,
+               "set_bases_s": leg.set_bases_s}
+        out.update(_rooflines(g, n, log_n, ph["accumulate_ms"], p0["num_windows"], precomputed))
+        return out
+    finally:
+        leg.close()
+
+
+def _pairing_leg(pkg, co, ncpu, device) -> dict:
+    """BASELINE config #5: 2^16 G1 x G2 pairs through mi_multi_pairing.  Parity: prod e(P_i, Q_i) e(-P_i, Q_i) == 1 at full size
+    and 256 random pairs bit-exact against the C oracle, which is also the timed CPU baseline."""
+    from oracle import pairing as pr_oracle, bls12_381 as o
+    half = 1 << 15
+    p1 = co.gen_bases("g1", SEED_B + 101, half, ncpu)
+    q2 = co.gen_bases("g2", SEED_B + 102, half, ncpu)
+    neg = bytearray(p1)
+    for i in range(half):   # -P: y -> p - y (Montgomery form, y != 0)
+        y = int.from_bytes(p1[96 * i + 48:96 * i + 96], "little")
+        neg[96 * i + 48:96 * i + 96] = (o.P - y).to_bytes(48, "little")
+    P_all, Q_all = p1 + bytes(neg), q2 + q2
+    n = 2 * half
+    with pkg.Context([device]) as ctx:
+        ctx.multi_pairing(P_all[:96 * 64], Q_all[:192 * 64])
+        best, pp = 1e30, None
+        for _ in range(3):
+            t1 = time.perf_counter()
+            gt = ctx.multi_pairing(P_all, Q_all)
+            dt = time.perf_counter() - t1
+            if dt < best:
+                best, pp = dt, ctx.profile()
+        m = 256
+        t1 = time.perf_counter()
+        cpu_gt = co.multi_pairing(p1[:96 * m], q2[:192 * m], ncpu)
+        cpu_s = time.perf_counter() - t1
+        sample_ok = ctx.multi_pairing(p1[:96 * m], q2[:192 * m]) == cpu_gt
+    acc_ms, lines_ms = pp["scatter_ms"], pp["digits_ms"]
+    mads = PAIRING_FP_MULS_PER_PAIR * MADS_PER_FP_MUL
+    tmad = mads * n / (pp["accumulate_ms"] * 1e-3) / 1e12
+    gbs = 288.0 * n / (pp["accumulate_ms"] * 1e-3) / 1e9
+    return {"metric": "pairs/s, batched Miller loop + final exponentiation (host buffers in, Gt out)", "value": n / best, "unit": "pairs/s",
+            "n_pairs": n, "ms": best * 1e3, "miller_kernels_ms": pp["accumulate_ms"], "k_miller_lines2_ms": lines_ms,
+            "k_miller_accumulate_ms": acc_ms, "pairs_per_accumulator": pp["work_items"], "fp12_tree_ms": pp["reduce_ms"], "h2d_ms": pp["h2d_ms"],
+            "host_tail_ms": pp["host_fold_ms"],
+            "product_cancels_to_one": gt == pr_oracle.fp12_to_bytes(pr_oracle.FP12_ONE), "bit_exact_256_pairs_vs_c_oracle": sample_ok,
+            "roofline": {"bound": "hbm", "kernel": "k_miller_lines2 + k_miller_accumulate", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": 288 * n, "kernel_ms": pp["accumulate_ms"],
+                         "note": "288 B per pair in (96 B G1 + 192 B G2 affine); the 26 KB of line coefficients per pair written and "
+                                 "re-read between the two kernels are counted as traffic, not as algorithmic bytes"},
+            "valu_roofline": {"model_mads_per_pair": mads,
+                              "model": f"{PAIRING_FP_MULS_PER_PAIR} Fp-mul per pair (63 doubling + 5 addition steps: line + sparse Fp12 product; "
+                                       f"Fp12 squarings shared by all pairs) x {MADS_PER_FP_MUL} MAD",
+                              "achieved_Tmad_s": tmad, "peak_Tmad_s": MAD_PEAK_T, "frac": tmad / MAD_PEAK_T,
+                              "measured_peak_Tmad_s": MAD_MEASURED_T, "frac_of_measured_peak": tmad / MAD_MEASURED_T},
+            "cpu_baseline": {"value": m / cpu_s, "unit": "pairs/s", "cores": ncpu, "kind": "port", "cpu_model": _cpu_model(),
+                             "sample": f"{m} pairs incl. one final exponentiation; textbook affine Miller loop in portable C "
+                                       "(oracle/pairing_oracle.c), an order of magnitude slower per core than assembly libraries", "seconds": cpu_s}}
+
+
+def _in_process_leg(pkg, co, torch, ncpu, slots: int, log_n: int, steps: int) -> dict:
+    """The in-library multi-device path INTEGRATION.md binds (one context over several devices, persistent per-device host
+    threads, no RCCL): `slots` device slots over the visible GPUs (round-robin; on a one-GPU box device 0 listed `slots`
+    times — a rehearsal of the host plumbing, the slots then share the chip)."""
+    ndev = torch.cuda.device_count()
+    ids = [k % ndev for k in range(slots)]
+    n = 1 << log_n
+    bases = co.gen_bases("g1", SEED_B + 7, n, ncpu)
+    scalars = co.gen_scalars(SEED_S + 7, n)
+    d_sc = torch.frombuffer(bytearray(scalars), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    out = {}
+    with pkg.Context(ids) as c:
+        c.set_bases("g1", bases, n)
+        for name, fn in (("device_scalars", lambda: c.msm_device("g1", d_sc.data_ptr(), n, pkg.SCALAR_CANONICAL)),
+                         ("host_scalars", lambda: c.msm("g1", None, scalars, n, pkg.SCALAR_CANONICAL))):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                r = fn()
+            dt = (time.perf_counter() - t0) / steps
+            out[name] = {"value": n / dt, "unit": "points/s", "ms_per_call": dt * 1e3,
+                         "bit_exact": co.to_affine("g1", r) == co.dlog_expected("g1", scalars, SEED_B + 7, n)}
+    # the same work as `slots` back-to-back single-device calls of n / slots points on device 0
+    per = n // slots
+    with pkg.Context([0]) as c1:
+        c1.set_bases("g1", bases[:96 * per], per)
+        c1.msm_device("g1", d_sc.data_ptr(), per, pkg.SCALAR_CANONICAL)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for _k in range(slots):
+                c1.msm_device("g1", d_sc.data_ptr(), per, pkg.SCALAR_CANONICAL)
+        dt = (time.perf_counter() - t0) / steps
+    out["serial_single_device_calls_ms"] = dt * 1e3
+    out.update({"device_slots": ids, "points": n,
+                "note": "one mi_ctx over several device slots (mi_msm_init with a device list): contiguous shards, one persistent host "
+                        "thread per slot, partial sums added in slot order; compared with the same shards as back-to-back "
+                        "single-device calls"})
+    return out
 
 
 def main() -> None:
@@ -40,16 +303,20 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--log-n", type=int, default=20, help="log2 of points PER GPU")
+    ap.add_argument("--log-n", type=int, default=None,
+                    help="log2 of points PER GPU.  Default: 20 at N = 1 (BASELINE config #2); at N > 1 the 2^24 points of config #3 "
+                         "are split over the ranks instead (strong scaling)")
+    ap.add_argument("--total-log-n", type=int, default=24, help="log2 of the TOTAL points at N > 1 when --log-n is not given")
     ap.add_argument("--group", default="g1", choices=["g1", "g2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--precomputed", action="store_true",
+                    help="opt-in mode: resident 2^(c j) P tables (mi_msm_g1_set_bases_precomputed); never the default headline")
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zero_one", "small64", "all_equal", "all_ones", "r1cs_mix"],
                     help="scalar distribution (secondary robustness figures; the headline is uniform)")
-    ap.add_argument("--concurrency", type=int, default=1,
-                    help="host threads issuing MSM calls concurrently (each with its own context; the trait method is\n"
-                         "re-entrant, SURVEY 8b).  1 = blocking calls back to back (headline).")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the two-host-thread secondary figure (profiling runs)")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--in-process", type=int, default=0, metavar="SLOTS",
+                    help="N = 1 only: device slots of the in-library multi-GPU leg of the secondary set (default 2)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device rehearses the N>1 path on a single-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (rehearsal only)")
@@ -80,42 +347,29 @@ def main() -> None:
 
     pkg = ge.load_package()
     g = args.group
-    n = 1 << args.log_n
     ncpu = _host_threads()
+    if world > 1:
+        ncpu = max(1, min(ncpu, (os.cpu_count() or world) // world))   # the ranks share the node's cores
     aff = 96 if g == "g1" else 192
 
-    # ---- synthetic inputs (seeded): rank r owns global indices [r*n, (r+1)*n)
-    t0 = time.time()
-    seed_b, seed_s = SEED_B + 1000 * rank, SEED_S + 1000 * rank
-    bases = co.gen_bases(g, seed_b, n, ncpu)
-    scalars = co.gen_scalars(seed_s, n)
-    if args.dist != "uniform":
-        import numpy as np
-        a = np.frombuffer(scalars, dtype=np.uint8).reshape(n, 32).copy()
-        if args.dist == "zero_one":      # R1CS-like witness: bits
-            a[:, 1:] = 0
-            a[:, 0] &= 1
-        elif args.dist == "small64":     # 64-bit values
-            a[:, 8:] = 0
-        elif args.dist == "r1cs_mix":    # witness-like: half zeros, a quarter ones, a quarter full-size values
-            sel = a[:, 0] & 3
-            a[sel < 2] = 0
-            a[sel == 2] = 0
-            a[sel == 2, 0] = 1
-        elif args.dist == "all_ones":    # every scalar = 1: the plain sum of the bases, one bucket of N entries
-            a[:] = 0
-            a[:, 0] = 1
-        else:                            # every scalar identical: all points in one bucket per window
-            a[:] = a[0]
-        scalars = a.tobytes()
-    gen_s = time.time() - t0
+    # ---- workload: rank r owns a contiguous shard of the global index range
+    if args.log_n is not None or world == 1:
+        log_n = args.log_n if args.log_n is not None else 20
+        n = 1 << log_n
+        total = n * world
+        scaling = "weak"
+        wl = f"{g.upper()} MSM, 2^{log_n} random bases+scalars per GPU"
+    else:
+        total = 1 << args.total_log_n
+        lo, hi = (total * rank) // world, (total * (rank + 1)) // world
+        n = hi - lo
+        log_n = n.bit_length() - 1 if n & (n - 1) == 0 else None
+        scaling = "strong"
+        wl = f"{g.upper()} MSM, 2^{args.total_log_n} random bases+scalars in total, base set sharded contiguously over {world} GPUs"
+    wl += (", bases resident as precomputed 2^(c j) P tables" if args.precomputed else ", bases resident") + ", scalars in HBM"
 
-    ctx = pkg.Context([local_rank])
-    if args.window_bits:
-        ctx.set_window_bits(args.window_bits)
-    ctx.set_bases(g, bases, n)
-    d_scalars = torch.frombuffer(bytearray(scalars), dtype=torch.uint8).cuda()
-    torch.cuda.synchronize()
+    leg = MsmLeg(pkg, co, torch, g, n, SEED_B + 1000 * rank, SEED_S + 1000 * rank, ncpu, local_rank, dist=args.dist,
+                 window_bits=args.window_bits, precomputed=args.precomputed)
 
     jac_bytes = 144 if g == "g1" else 288
     cdev = "cuda" if on_gpu else "cpu"
@@ -128,7 +382,7 @@ def main() -> None:
         mine_host, gather_host = mine_host.pin_memory(), gather_host.pin_memory()
 
     def step() -> bytes:
-        part = ctx.msm_device(g, d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)
+        part = leg.call()
         if world == 1:
             return part
         mine_host.numpy()[:] = memoryview(part)
@@ -149,112 +403,21 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     prof_acc = []
-    if args.concurrency > 1 and world == 1:
-        # K steps issued from `concurrency` host threads, each with its own context and stream on the same GPU
-        import threading
-        ctxs = [ctx] + [pkg.Context([local_rank]) for _ in range(args.concurrency - 1)]
-        for c in ctxs[1:]:
-            c.set_bases(g, bases, n)
-            c.msm_device(g, d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)
-        results = [b""] * args.steps
-        def worker(t):
-            for k in range(t, args.steps, args.concurrency):
-                results[k] = ctxs[t].msm_device(g, d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)
-        fence()
-        t0 = time.perf_counter()
-        th = [threading.Thread(target=worker, args=(t,)) for t in range(args.concurrency)]
-        for x in th: x.start()
-        for x in th: x.join()
-        fence()
-        elapsed = time.perf_counter() - t0
-        result = results[-1]
-        # equal as curve points (the Jacobian representative depends on the order entries reached their bucket)
-        assert len({co.to_affine(g, r) for r in results}) == 1
-        prof_acc.append(ctx.profile())
-        for c in ctxs[1:]:
-            c.close()
-    else:
-        fence()
-        t0 = time.perf_counter()
-        result = b""
-        for _ in range(args.steps):
-            result = step()
-            prof_acc.append(ctx.profile())
-        fence()
-        elapsed = time.perf_counter() - t0
+    fence()
+    t0 = time.perf_counter()
+    result = b""
+    for _ in range(args.steps):
+        result = step()
+        prof_acc.append(leg.ctx.profile())
+    fence()
+    elapsed = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # ---- secondary figure (N = 1 only): the same K steps issued by TWO host threads on the same context (the trait
-    # method is re-entrant and arkworks calls it from rayon workers): a context has two lanes, so one call's
-    # sort / reduce / host fold overlap the other's accumulate.  Not the headline value.
-    two_thread = None
-    if world == 1 and args.concurrency == 1 and not args.no_secondary:
-        import threading
-        res2 = [b""] * args.steps
-        def worker(t):
-            for k in range(t, args.steps, 2):
-                res2[k] = ctx.msm_device(g, d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)   # same context: its two lanes
-        worker(1)   # first use of the second lane allocates its scratch
-        fence()
-        t1 = time.perf_counter()
-        th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
-        for x in th: x.start()
-        for x in th: x.join()
-        fence()
-        e2 = time.perf_counter() - t1
-        ok2 = len({co.to_affine(g, r) for r in res2 + [result]}) == 1
-        two_thread = {"value": n * args.steps / e2, "unit": "points/s", "ms_per_step": e2 / args.steps * 1e3, "same_result": ok2,
-                      "note": "the same K steps issued by two host threads on ONE context (two lanes, shared resident bases)"}
-
-    # ---- secondary figure (N = 1 only): end-to-end call shapes (SURVEY 8(d) "timing scope"): scalars from host memory per call
-    # with resident bases, and the reference driver's shape — bases AND scalars uploaded on every call (src/gpu.rs:149-150)
-    call_shapes = None
-    if world == 1 and args.concurrency == 1 and not args.no_secondary:
-        def best_of(fn, reps=3):
-            fn()
-            b = 1e30
-            for _ in range(reps):
-                t1 = time.perf_counter(); r = fn(); b = min(b, time.perf_counter() - t1)
-            assert co.to_affine(g, r) == co.to_affine(g, result)
-            return b * 1e3
-        call_shapes = {"resident_bases_host_scalars_ms": best_of(lambda: ctx.msm(g, None, scalars, n, pkg.SCALAR_CANONICAL)),
-                       "host_bases_host_scalars_ms": best_of(lambda: ctx.msm(g, bases, scalars, n, pkg.SCALAR_CANONICAL)),
-                       "note": "per call incl. H2D of the scalars (and bases) from pageable host memory; the headline keeps both in HBM"}
-
-    # ---- secondary figure (N = 1 only): the pairing row (BASELINE config #5): 2^16 G1 x G2 pairs through
-    # mi_multi_pairing; parity = prod e(P_i, Q_i) e(-P_i, Q_i) == 1 at full size (tools/bench_pairing.py has the oracle check)
-    pairing = None
-    if world == 1 and args.concurrency == 1 and not args.no_secondary:
-        try:
-            from oracle import pairing as pr_oracle, bls12_381 as o
-            half = 1 << 15
-            p1 = co.gen_bases("g1", seed_b + 101, half, ncpu)
-            q2 = co.gen_bases("g2", seed_b + 102, half, ncpu)
-            neg = bytearray(p1)
-            for i in range(half):   # -P: y -> p - y (Montgomery form, y != 0)
-                y = int.from_bytes(p1[96 * i + 48:96 * i + 96], "little")
-                neg[96 * i + 48:96 * i + 96] = (o.P - y).to_bytes(48, "little")
-            P_all, Q_all = p1 + bytes(neg), q2 + q2
-            ctx.multi_pairing(P_all[:96 * 64], Q_all[:192 * 64])
-            best = 1e30
-            for _ in range(3):
-                t1 = time.perf_counter()
-                gt = ctx.multi_pairing(P_all, Q_all)
-                best = min(best, time.perf_counter() - t1)
-            pp = ctx.profile()
-            pairing = {"metric": "pairs/s, batched Miller loop + final exponentiation (host buffers in, Gt out)", "value": 2 * half / best,
-                       "n_pairs": 2 * half, "ms": best * 1e3, "miller_kernels_ms": pp["accumulate_ms"], "fp12_tree_ms": pp["reduce_ms"],
-                       "h2d_ms": pp["h2d_ms"], "host_tail_ms": pp["host_fold_ms"],
-                       "product_cancels_to_one": gt == pr_oracle.fp12_to_bytes(pr_oracle.FP12_ONE)}
-        except Exception as e:   # never let a secondary figure break the headline line
-            pairing = {"error": repr(e)}
-
     # ---- parity: closed form over ALL ranks' inputs
-    expected_parts = []
-    mine_expected = co.dlog_expected(g, scalars, seed_b, n)          # affine bytes of this rank's shard
+    mine_expected = leg.expected_affine()          # affine bytes of this rank's shard
     if world > 1:
         buf = [torch.empty(aff, dtype=torch.uint8, device=cdev) for _ in range(world)]
         dist.all_gather(buf, torch.frombuffer(bytearray(mine_expected), dtype=torch.uint8).to(cdev))
@@ -269,28 +432,88 @@ def main() -> None:
         want = co.to_affine(g, co.sum_jac(g, jac, world))
         bit_exact = co.to_affine(g, result) == want
 
+    secondary = {}
+    if world == 1 and not args.no_secondary and rank == 0:
+        # ---- the same K steps issued by TWO host threads on the same context (the trait method is re-entrant and arkworks
+        # calls it from rayon workers): a context has two lanes.  Not the headline value.
+        import threading
+        res2 = [b""] * args.steps
+        def worker(t):
+            for k in range(t, args.steps, 2):
+                res2[k] = leg.call()
+        worker(1)   # first use of the second lane allocates its scratch
+        fence()
+        t1 = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+        for x in th: x.start()
+        for x in th: x.join()
+        fence()
+        e2 = time.perf_counter() - t1
+        secondary["two_host_threads"] = {"value": n * args.steps / e2, "unit": "points/s", "ms_per_step": e2 / args.steps * 1e3,
+                                         "same_result": len({co.to_affine(g, r) for r in res2 + [result]}) == 1,
+                                         "note": "the same K steps issued by two host threads on ONE context (two lanes, shared resident bases)"}
+        # ---- end-to-end call shapes (SURVEY 8(d) "timing scope"): scalars from host memory per call with resident bases, and
+        # the reference driver's shape — bases AND scalars uploaded on every call (src/gpu.rs:149-150)
+        def best_of(fn, reps=3):
+            fn()
+            b = 1e30
+            for _ in range(reps):
+                t1 = time.perf_counter(); r = fn(); b = min(b, time.perf_counter() - t1)
+            assert co.to_affine(g, r) == co.to_affine(g, result)
+            return b * 1e3
+        if not args.precomputed:
+            secondary["call_shapes"] = {
+                "resident_bases_host_scalars_ms": best_of(lambda: leg.ctx.msm(g, None, leg.scalars, n, pkg.SCALAR_CANONICAL)),
+                "host_bases_host_scalars_ms": best_of(lambda: leg.ctx.msm(g, leg.bases, leg.scalars, n, pkg.SCALAR_CANONICAL)),
+                "note": "per call incl. H2D of the scalars (and bases) from pageable host memory; the headline keeps both in HBM"}
+
+    # ---- CPU baseline (rank 0, N = 1): SURVEY 8(d): one warm-up + median of >= 5 runs (3 above 2^20), CPU model and core count in
+    # the result, plus a single-thread figure (on a 2^16-point prefix) for scaling
+    cpu_baseline = None
+    if not args.no_cpu_baseline and world == 1 and rank == 0:
+        runs = 5 if n <= (1 << 20) else (3 if n <= (1 << 22) else 1)
+        if n <= (1 << 22):
+            co.msm(g, leg.bases, leg.scalars, n, 0, ncpu)
+        times = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            cpu = co.msm(g, leg.bases, leg.scalars, n, 0, ncpu)
+            times.append(time.perf_counter() - t0)
+        med = statistics.median(times)
+        assert co.to_affine(g, cpu) == leg.expected_affine()
+        n1 = min(n, 1 << 16)
+        t0 = time.perf_counter()
+        co.msm(g, leg.bases[:aff * n1], leg.scalars[:32 * n1], n1, 0, 1)
+        t_single = time.perf_counter() - t0
+        cpu_baseline = {"value": n / med, "unit": "points/s", "cores": ncpu, "kind": "port", "cpu_model": _cpu_model(),
+                        "sample": f"full workload of one GPU ({n} points), median of {runs} runs after a warm-up, blst-style Pippenger "
+                                  "restatement in C (oracle/msm_oracle.c), not blst assembly",
+                        "seconds": med, "best_seconds": min(times),
+                        "single_thread": {"value": n1 / t_single, "unit": "points/s", "points": n1}}
+
+    headline_n, gen_s = n, leg.gen_s
+    p0 = prof_acc[-1]
+    acc_ms = sum(p["accumulate_ms"] for p in prof_acc) / len(prof_acc)
+    leg.close()
+    del leg
+
+    if world == 1 and not args.no_secondary and rank == 0:
+        # ---- the other single-GPU configs of BASELINE.json, each on a fresh context (never let one break the headline line)
+        def guarded(name, fn):
+            try:
+                secondary[name] = fn()
+            except Exception as e:
+                secondary[name] = {"error": repr(e)}
+        if g == "g1" and log_n == 20 and not args.precomputed and args.dist == "uniform":
+            guarded("g1_2p24", lambda: _secondary_msm(pkg, co, torch, "g1", 24, 24, ncpu, local_rank, 3))
+            guarded("g2_2p20", lambda: _secondary_msm(pkg, co, torch, "g2", 20, 4, ncpu, local_rank, 5))
+            guarded("g1_2p20_precomputed_tables", lambda: _secondary_msm(pkg, co, torch, "g1", 20, 0, ncpu, local_rank, 10, precomputed=True))
+        guarded("pairing_2p16", lambda: _pairing_leg(pkg, co, ncpu, local_rank))
+        guarded("in_process_multi_device", lambda: _in_process_leg(pkg, co, torch, ncpu, args.in_process or 2, 20, 5))
+
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
-        total_points = n * world
-        value = total_points / (elapsed / args.steps)
-        acc_ms = sum(p["accumulate_ms"] for p in prof_acc) / len(prof_acc)
-        p0 = prof_acc[-1]
-        alg_bytes = ALG_BYTES_PER_POINT[g] * n
-        achieved_gbs = alg_bytes / (acc_ms * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel: measured with rocprofv3 PMC passes (tools/profile_bench.sh) on this exact
-        # workload and committed under profiles/; bench.py cannot collect counters itself.
-        traffic, traffic_src = None, None
-        try:
-            key = f"msmk::k_accumulate<msmk::{g.upper()}C>"
-            if args.log_n == 20:   # the committed counters were collected on this exact workload
-                for f in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json")), reverse=True):
-                    pj = json.load(open(os.path.join(ROOT, "profiles", f)))
-                    if key in pj.get("kernels", {}) and "hbm_bytes_per_launch_corrected" in pj["kernels"][key]:
-                        traffic = pj["kernels"][key]["hbm_bytes_per_launch_corrected"]
-                        traffic_src = "profiles/" + f
-                        break
-        except Exception:
-            pass
+        value = total / (elapsed / args.steps)
         out = {
             "metric": f"{g.upper()} MSM points/sec",
             "value": value,
@@ -300,90 +523,30 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "bit_exact": bit_exact,
-            "config": {"workload": f"{g.upper()} MSM, 2^{args.log_n} random bases+scalars per GPU, bases resident, scalars in HBM",
-                       "points_per_gpu": n, "total_points": total_points, "window_bits": p0["window_bits"],
-                       "num_windows": p0["num_windows"], "parallelism": f"base-set sharded x{world}", "scalar_dist": args.dist, "host_threads_issuing": args.concurrency,
+            "config": {"workload": wl, "points_per_gpu": headline_n, "total_points": total, "window_bits": p0["window_bits"],
+                       "num_windows": p0["num_windows"], "parallelism": f"base-set sharded x{world}", "scalar_dist": args.dist,
+                       "precomputed_tables": bool(args.precomputed),
                        "field_repr": "14 x 28-bit limbs in u32, products accumulated with v_mad_u64_u32"},
-            "roofline": {"bound": "hbm", "kernel": f"k_accumulate<{g.upper()}C>", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms,
-                         "note": "the bucket method re-reads each 128-B device point once per window (16x at c=16): "
-                                 "traffic ~ 16 x algorithmic by design; the kernel is VALU-bound, see valu_roofline"},
-            "valu_roofline": {"model_mads_per_point": MADS_PER_POINT[g],
-                              "achieved_Tmad_s": MADS_PER_POINT[g] * n / (acc_ms * 1e-3) / 1e12,
-                              "peak_Tmad_s": MAD_PEAK_TLOPS,
-                              "frac": MADS_PER_POINT[g] * n / (acc_ms * 1e-3) / 1e12 / MAD_PEAK_TLOPS,
-                              "note": "integer VALU (v_mad_u64_u32) is the real bound of this path; HBM frac is low by construction"},
-            "phases_ms": {k: sum(p[k] for p in prof_acc) / len(prof_acc) for k in
-                          ("digits_ms", "scan_ms", "scatter_ms", "accumulate_ms", "reduce_ms", "combine_ms", "d2h_ms", "host_fold_ms", "total_ms")},
+            "phases_ms": _phases(prof_acc),
             "input_gen_s": gen_s,
-            "two_host_threads": two_thread,
-            "pairing_2p16": pairing,
-            "call_shapes": call_shapes,
         }
-        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
-            # one warm-up + median of >= 5 runs (3 at 2^24 and above), CPU model and core count in the result,
-            # plus a single-thread figure (on a 2^16-point prefix) for scaling
-            import statistics
-            runs = 5 if args.log_n <= 20 else (3 if args.log_n <= 24 else 1)
-            if args.log_n <= 22:
-                co.msm(g, bases, scalars, n, 0, ncpu)
-            times = []
-            for _ in range(runs):
-                t0 = time.perf_counter()
-                cpu = co.msm(g, bases, scalars, n, 0, ncpu)
-                times.append(time.perf_counter() - t0)
-            med = statistics.median(times)
-            assert co.to_affine(g, cpu) == co.dlog_expected(g, scalars, seed_b, n)
-            n1 = min(n, 1 << 16)
-            t0 = time.perf_counter()
-            co.msm(g, bases[:aff * n1], scalars[:32 * n1], n1, 0, 1)
-            t_single = time.perf_counter() - t0
-            model = "unknown"
-            try:
-                for line in open("/proc/cpuinfo"):
-                    if line.startswith("model name"):
-                        model = line.split(":", 1)[1].strip()
-                        break
-            except OSError:
-                pass
-            out["cpu_baseline"] = {"value": n / med, "unit": "points/s", "cores": ncpu, "kind": "port", "cpu_model": model,
-                                   "sample": f"full workload of one GPU (2^{args.log_n} points), median of {runs} runs after a warm-up, "
-                                             "blst-style Pippenger restatement in portable C (oracle/msm_oracle.c), not blst assembly",
-                                   "seconds": med, "best_seconds": min(times),
-                                   "single_thread": {"value": n1 / t_single, "unit": "points/s", "points": n1}}
+        out.update(_rooflines(g, headline_n, log_n, acc_ms, p0["num_windows"], args.precomputed))
+        if cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline
+        if secondary:
+            out["secondary"] = secondary
+            for k in ("two_host_threads", "pairing_2p16", "call_shapes"):   # round-1 field names kept at the top level
+                if k in secondary:
+                    out[k] = secondary[k]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
-
-
-def _host_threads() -> int:
-    """Threads for the CPU legs: the cgroup CPU quota when there is one (a 1-GPU box is given ~16 cores of a
-    256-thread host), else the affinity mask."""
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            return max(1, int(int(quota) / int(period)))
-    except Exception:
-        pass
-    try:
-        n = len(os.sched_getaffinity(0))
-    except Exception:
-        n = os.cpu_count() or 1
-    return min(n, 16)
-
-
-def _mont_one() -> bytes:
-    """Montgomery form of 1 (R mod p), /root/reference/src/fp.rs:532 — Z coordinate of an affine point lifted to Jacobian."""
-    limbs = [0x760900000002FFFD, 0xEBF4000BC40C0002, 0x5F48985753C758BA, 0x77CE585370525745, 0x5C071A97A256EC6D, 0x15F65EC3FA80E493]
-    return b"".join(l.to_bytes(8, "little") for l in limbs)
 
 
 if __name__ == "__main__":

@@ -14,6 +14,15 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def pkg():
+    # torch first: its bundled HIP runtime must be the one the process initialises (tests that hand torch device buffers to
+    # the library found "No HIP GPUs are available" when the library's own runtime had been loaded before torch's)
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
     import __graft_entry__ as g
 
     return g.load_package()

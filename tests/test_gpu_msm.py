@@ -529,3 +529,204 @@ def test_bench_json_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port"
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE sizes
+def test_g1_msm_2_24_closed_form(pkg, co):
+    """BASELINE config #3's size on ONE device (the north-star target): 2^24 random bases + scalars, resident bases, scalars
+    from host memory, against the closed form (sum s_i k_i) G; then the same through device-resident scalars."""
+    import torch
+
+    n = 1 << 24
+    bases = co.gen_bases("g1", SEED_B + 24, n, 16)
+    scalars = co.gen_scalars(SEED_S + 24, n)
+    want = co.dlog_expected("g1", scalars, SEED_B + 24, n)
+    with pkg.Context([0]) as c:
+        c.set_bases("g1", bases, n)
+        del bases
+        assert _canon(co, "g1", c.msm("g1", None, scalars, n, pkg.SCALAR_CANONICAL)) == want
+        prof = c.profile()
+        assert prof["n"] == n and prof["window_bits"] >= 16
+        d = torch.frombuffer(bytearray(scalars), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        assert _canon(co, "g1", c.msm_device("g1", d.data_ptr(), n, pkg.SCALAR_CANONICAL)) == want
+        # a prefix of the resident set (2^24 - 12345 points): the shard shapes an 8-way split produces are not powers of two
+        m = n - 12345
+        assert _canon(co, "g1", c.msm("g1", None, scalars[:32 * m], m, pkg.SCALAR_CANONICAL)) == co.dlog_expected("g1", scalars[:32 * m], SEED_B + 24, m)
+
+
+def test_g2_msm_2_20_closed_form(pkg, co):
+    """BASELINE config #4: G2, 2^20 random bases + scalars on one device, against the closed form."""
+    n = 1 << 20
+    bases = co.gen_bases("g2", SEED_B + 4, n, 16)
+    scalars = co.gen_scalars(SEED_S + 4, n)
+    with pkg.Context([0]) as c:
+        c.set_bases("g2", bases, n)
+        got = c.msm("g2", None, scalars, n, pkg.SCALAR_CANONICAL)
+    assert _canon(co, "g2", got) == co.dlog_expected("g2", scalars, SEED_B + 4, n)
+
+
+def _mixed_scalars(o, rnd, n):
+    """uniform, 0/1, small, equal and edge values mixed in one vector"""
+    out = []
+    same = rnd.randrange(o.R_ORDER)
+    for i in range(n):
+        k = i % 7
+        out.append(rnd.randrange(o.R_ORDER) if k < 2 else rnd.randrange(2) if k == 2 else rnd.randrange(1 << 40) if k == 3 else same if k == 4
+                   else rnd.choice([0, 1, 2, o.R_ORDER - 1, o.R_ORDER - 2]) if k == 5 else rnd.randrange(1 << 200))
+    return out
+
+
+@pytest.mark.parametrize("c", [17, 18, 19, 20, 21, 22])
+def test_large_window_sizes_small_inputs(ctx, co, o, pkg, c):
+    """window sizes 17..22 (static k_coarse instantiations with their own top-window shapes; the plan only picks them for
+    millions of points) forced on small inputs, both groups, with edge / skewed scalars, infinity and repeated bases"""
+    rnd = random.Random(1700 + c)
+    for group, n in (("g1", 777), ("g1", 5000), ("g2", 300)):
+        aff = 96 if group == "g1" else 192
+        bases = bytearray(co.gen_bases(group, SEED_B + 170 + c, n, 8))
+        for k in range(0, n, 97):
+            bases[aff * k:aff * (k + 1)] = bytes(aff)                          # infinity
+        for k in range(5, n, 53):
+            bases[aff * k:aff * (k + 1)] = bases[aff * 1:aff * 2]              # repeated point
+        sc = _mixed_scalars(o, rnd, n)
+        canon = b"".join(o.fr_to_canon_bytes(x) for x in sc)
+        ctx.set_window_bits(c)
+        try:
+            got = ctx.msm(group, bytes(bases), canon, n, pkg.SCALAR_CANONICAL)
+            got_m = ctx.msm(group, bytes(bases), co.fr_to_mont(canon), n, pkg.SCALAR_MONTGOMERY)
+            assert ctx.profile()["window_bits"] == c
+        finally:
+            ctx.set_window_bits(0)
+        want = _canon(co, group, co.msm(group, bytes(bases), canon, n, 0, 4))
+        assert _canon(co, group, got) == want, (group, n, c)
+        assert _canon(co, group, got_m) == want, (group, n, c, "montgomery")
+
+
+# ------------------------------------------------------------------------------------------------ precomputed tables (opt-in)
+@pytest.mark.parametrize("group,n,c", [("g1", 1, 0), ("g1", 300, 8), ("g1", 5000, 0), ("g1", 5000, 13), ("g1", 40000, 16), ("g2", 900, 0), ("g2", 900, 11)])
+def test_precomputed_tables_match_plain(pkg, co, o, group, n, c):
+    """mi_msm_g{1,2}_set_bases_precomputed: resident 2^(c j) P tables, all windows share one bucket set.  Same results as the
+    plain resident set and the oracle: uniform and skewed scalars, both scalar formats, infinity and repeated bases,
+    a prefix of the resident set."""
+    rnd = random.Random(4242 + n + c)
+    aff = 96 if group == "g1" else 192
+    bases = bytearray(co.gen_bases(group, SEED_B + 200 + n, n, 8))
+    for k in range(3, n, 61):
+        bases[aff * k:aff * (k + 1)] = bytes(aff)
+    for k in range(7, n, 41):
+        bases[aff * k:aff * (k + 1)] = bases[aff * 2:aff * 3]
+    bases = bytes(bases)
+    with pkg.Context([0]) as cp:
+        cp.set_bases_precomputed(group, bases, n, c)
+        for kind in ("uniform", "mixed", "ones"):
+            sc = ([rnd.randrange(o.R_ORDER) for _ in range(n)] if kind == "uniform" else _mixed_scalars(o, rnd, n) if kind == "mixed" else [1] * n)
+            canon = b"".join(o.fr_to_canon_bytes(x) for x in sc)
+            want = _canon(co, group, co.msm(group, bases, canon, n, 0, 4))
+            got = cp.msm(group, None, canon, n, pkg.SCALAR_CANONICAL)
+            assert _canon(co, group, got) == want, (group, n, c, kind)
+            prof = cp.profile()
+            if c:
+                assert prof["window_bits"] == c
+            assert _canon(co, group, cp.msm(group, None, co.fr_to_mont(canon), n, pkg.SCALAR_MONTGOMERY)) == want
+            m = max(1, n // 3)
+            assert _canon(co, group, cp.msm(group, None, canon[:32 * m], m, pkg.SCALAR_CANONICAL)) == \
+                _canon(co, group, co.msm(group, bases, canon, m, 0, 4))
+        # a call that brings its own bases ignores the tables; plain set_bases afterwards replaces them
+        sc = b"".join(o.fr_to_canon_bytes(rnd.randrange(o.R_ORDER)) for _ in range(n))
+        want = _canon(co, group, co.msm(group, bases, sc, n, 0, 4))
+        assert _canon(co, group, cp.msm(group, bases, sc, n, pkg.SCALAR_CANONICAL)) == want
+        cp.set_bases(group, bases, n)
+        assert _canon(co, group, cp.msm(group, None, sc, n, pkg.SCALAR_CANONICAL)) == want
+
+
+def test_precomputed_tables_2_20(pkg, co):
+    """the opt-in mode at BASELINE config #2's size against the closed form"""
+    n = 1 << 20
+    bases = co.gen_bases("g1", SEED_B + 220, n, 16)
+    scalars = co.gen_scalars(SEED_S + 220, n)
+    with pkg.Context([0]) as cp:
+        cp.set_bases_precomputed("g1", bases, n, 0)
+        got = cp.msm("g1", None, scalars, n, pkg.SCALAR_CANONICAL)
+        assert cp.profile()["window_bits"] >= 16
+    assert _canon(co, "g1", got) == co.dlog_expected("g1", scalars, SEED_B + 220, n)
+
+
+# ------------------------------------------------------------------------------------------------ long inputs, failure injection
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_calls_longer_than_one_pass_are_split(pkg, co, group):
+    """more points than one pass of the pipeline takes (2^26 per device in production; 1000 through the test build's hook):
+    the parts are processed one after the other and added — host bases, resident bases, device scalars, precomputed tables"""
+    import torch
+
+    n = 4321
+    aff = 96 if group == "g1" else 192
+    bases = co.gen_bases(group, SEED_B + 230, n, 8)
+    scalars = co.gen_scalars(SEED_S + 230, n)
+    want = co.dlog_expected(group, scalars, SEED_B + 230, n)
+    with pkg.Context([0], test_hooks=True) as c:
+        c.test_set_max_part(1000)
+        assert _canon(co, group, c.msm(group, bases, scalars, n, pkg.SCALAR_CANONICAL)) == want
+        c.set_bases(group, bases, n)
+        assert _canon(co, group, c.msm(group, None, scalars, n, pkg.SCALAR_CANONICAL)) == want
+        d = torch.frombuffer(bytearray(scalars), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        assert _canon(co, group, c.msm_device(group, d.data_ptr(), n, pkg.SCALAR_CANONICAL)) == want
+        c.set_bases_precomputed(group, bases, n, 9)
+        assert _canon(co, group, c.msm(group, None, scalars, n, pkg.SCALAR_CANONICAL)) == want
+        m = 2500
+        assert _canon(co, group, c.msm(group, None, scalars[:32 * m], m, pkg.SCALAR_CANONICAL)) == co.dlog_expected(group, scalars[:32 * m], SEED_B + 230, m)
+    with pkg.Context([0, 0, 0], test_hooks=True) as c3:   # three device slots, each splitting its shard
+        c3.test_set_max_part(700)
+        c3.set_bases(group, bases, n)
+        assert _canon(co, group, c3.msm(group, None, scalars, n, pkg.SCALAR_CANONICAL)) == want
+        assert _canon(co, group, c3.msm(group, bases, scalars, n, pkg.SCALAR_CANONICAL)) == want
+
+
+def test_allocation_failure_is_an_error_code_not_an_abort(pkg, co):
+    """a failing device allocation — on the calling thread or inside a per-device worker of a multi-device context — comes
+    back as MI_E_NOMEM across the C ABI (nothing throws or terminates), and the context works afterwards"""
+    n = 3000
+    bases = co.gen_bases("g1", SEED_B + 240, n, 8)
+    scalars = co.gen_scalars(SEED_S + 240, n)
+    want = co.dlog_expected("g1", scalars, SEED_B + 240, n)
+    for ids in ([0], [0, 0]):
+        with pkg.Context(ids, test_hooks=True) as c:
+            for k in (1, 2, 5):
+                c.test_fail_allocs(k)
+                with pytest.raises(pkg.MsmError) as e:
+                    c.msm("g1", bases, scalars, n, pkg.SCALAR_CANONICAL)
+                assert e.value.code == -4, e.value        # MI_E_NOMEM
+                assert "out of memory" in str(e.value)
+            c.test_fail_allocs(0)
+            assert _canon(co, "g1", c.msm("g1", bases, scalars, n, pkg.SCALAR_CANONICAL)) == want
+            c.test_fail_allocs(1)
+            with pytest.raises(pkg.MsmError) as e:
+                c.set_bases("g1", bases, n)
+            assert e.value.code == -4
+            c.test_fail_allocs(0)
+            c.set_bases("g1", bases, n)
+            assert _canon(co, "g1", c.msm("g1", None, scalars, n, pkg.SCALAR_CANONICAL)) == want
+            c.test_fail_allocs(1)
+            with pytest.raises(pkg.MsmError) as e:
+                c.multi_pairing(bases[:96 * 40], co.gen_bases("g2", 3, 40, 2))
+            assert e.value.code == -4
+            c.test_fail_allocs(0)
+
+
+def test_multi_device_context_device_resident_scalars(pkg, co):
+    """a context over several device slots reads its shard of ONE device-resident scalar vector per slot"""
+    import torch
+
+    n = 10001
+    bases = co.gen_bases("g1", SEED_B + 250, n, 8)
+    scalars = co.gen_scalars(SEED_S + 250, n)
+    d = torch.frombuffer(bytearray(scalars), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    with pkg.Context([0, 0, 0]) as c3:
+        c3.set_bases("g1", bases, n)
+        got = c3.msm_device("g1", d.data_ptr(), n, pkg.SCALAR_CANONICAL)
+        m = 7000
+        got_m = c3.msm_device("g1", d.data_ptr(), m, pkg.SCALAR_CANONICAL)
+    assert _canon(co, "g1", got) == co.dlog_expected("g1", scalars, SEED_B + 250, n)
+    assert _canon(co, "g1", got_m) == co.dlog_expected("g1", scalars[:32 * m], SEED_B + 250, m)

@@ -161,3 +161,23 @@ def test_shared_squaring_accumulators(tctx, co, share):
         finally:
             tctx.test_set_pairing()
         assert got == co.multi_pairing(bytes(g1), bytes(g2), 8), (share, n)
+
+
+def test_pairing_2_16_pairs_cancellation_and_sample(pkg, co, o):
+    """BASELINE config #5's size: 2^16 G1 x G2 pairs.  Size-independent property at full size — the second half is the first
+    with P negated, so prod e(P_i, Q_i) e(-P_i, Q_i) == 1 — and 1024 of the pairs bit-exact against the C oracle."""
+    from oracle import pairing as pr
+
+    half = 1 << 15
+    p1 = co.gen_bases("g1", SEED_P + 160, half, 16)
+    q2 = co.gen_bases("g2", SEED_Q + 160, half, 16)
+    neg = bytearray(p1)
+    for i in range(half):
+        y = int.from_bytes(p1[96 * i + 48:96 * i + 96], "little")
+        neg[96 * i + 48:96 * i + 96] = (o.P - y).to_bytes(48, "little")
+    with pkg.Context([0]) as c:
+        assert c.multi_pairing(p1 + bytes(neg), q2 + q2) == pr.fp12_to_bytes(pr.FP12_ONE)
+        half_gt = c.multi_pairing(p1, q2)
+        assert half_gt != pr.fp12_to_bytes(pr.FP12_ONE)
+        m = 1024
+        assert c.multi_pairing(p1[:96 * m], q2[:192 * m]) == co.multi_pairing(p1[:96 * m], q2[:192 * m], 16)
