@@ -1,27 +1,34 @@
 #!/usr/bin/env python3
-"""Condense a tools/profile_bench.sh run (gpurun_out/prof) into profiles/<tag>_*: the kernel-trace stats CSV as is,
-and per-kernel means of the PMC passes with the HBM traffic corrected as MI355X_MICROARCH.md §HBM prescribes
-(FETCH_SIZE and WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane reads -> doubled)."""
+"""Condense a tools/profile_bench.sh run (gpurun_out/prof_<tag>) into profiles/<tag>_*: the kernel-trace stats CSV as is,
+the bench line printed under rocprof, and per-kernel means of the PMC passes with the HBM traffic corrected as
+MI355X_MICROARCH.md §HBM prescribes (FETCH_SIZE and WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports half the bytes of
+16-B-per-lane reads -> doubled).  The summary names its workload so that bench.py's roofline.traffic picks the matching one.
+    python tools/summarize_profile.py <dir> <tag> <group> <log_n> [precomputed]"""
 import collections
-import os
 import csv
 import glob
 import json
+import os
 import shutil
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
-what = sys.argv[3] if len(sys.argv) > 3 else "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary` (G1, 2^20, c=16)"
+src, tag, group, log_n = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+precomputed = len(sys.argv) > 5 and sys.argv[5] == "precomputed"
+cmd = open(f"{src}/command.txt").read().strip() if os.path.exists(f"{src}/command.txt") else "bench.py"
+
+
 def newest(pattern):   # gpurun merges runs into the same directory: take the latest file
-    return max(glob.glob(pattern), key=os.path.getmtime)
+    return max(glob.glob(pattern, recursive=True), key=os.path.getmtime)
 
 
-shutil.copy(newest(f"{src}/stats/runc/*kernel_stats.csv"), f"profiles/{tag}_kernel_stats.csv")
+shutil.copy(newest(f"{src}/stats/**/*kernel_stats.csv"), f"profiles/{tag}_kernel_stats.csv")
+line = [l for l in open(f"{src}/bench_line_under_rocprof.json") if l.startswith("{")]
+if line:
+    open(f"profiles/{tag}_bench_line_under_rocprof.json", "w").write(line[-1])
 out = collections.defaultdict(dict)
 for name in ("fetch", "write", "sq"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(newest(f"{src}/{name}/runc/*counter_collection.csv"))):
+    for r in csv.DictReader(open(newest(f"{src}/{name}/**/*counter_collection.csv"))):
         acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         for c, xs in v.items():
@@ -34,6 +41,8 @@ for k, v in out.items():
         v["hbm_bytes_per_launch_raw"] = (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
     if "GRBM_GUI_ACTIVE" in v:
         v["gpu_cycles_per_launch"] = v["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
-json.dump({"source": "rocprofv3 --pmc passes of `" + what + " (means over all launches of a kernel in the run, warm-up launches included)",
+json.dump({"source": f"rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*, one pass each) of `python3 {cmd}` "
+                     "(means over all launches of a kernel in the run, warm-up launches included)",
+           "workload": {"group": group, "log_n": log_n, "precomputed": precomputed},
            "kernels": out}, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
 print("wrote profiles/%s_kernel_stats.csv, profiles/%s_pmc_summary.json" % (tag, tag))
