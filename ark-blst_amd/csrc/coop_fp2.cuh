@@ -26,12 +26,15 @@ struct CoopF2 {
     }
     static __device__ __forceinline__ E zero() { return fp28::fp_zero(); }
     static __device__ __forceinline__ E one() { return fp28::fp_select(hi(), fp28::fp_one(), fp28::fp_zero()); }
+    // 32p - b without a carry pass (b in N-form, < 31p): limbs < 2^29, still a legal multiplier operand next to N-form
+    // partners (two products + the reduction stay below 2^62 per column; four below 2^62.6)
+    static __device__ __forceinline__ Fp neg32_lazy(const Fp& b) { return fp28::fp_sub_lazy<32>(fp28::fp_zero(), b); }
     static __device__ __forceinline__ E mul(const E& a, const E& b) {
+        // own a times s1 plus partner's a times s2:  even lane  a0 b0 + a1 (32p - b1),  odd lane  a1 b0 + a0 b1
         Fp pa = partner(a), pb = partner(b);
-        Fp x = fp28::fp_select(hi(), a, pa);                       // a0
-        Fp z = fp28::fp_select(hi(), pa, a);                       // a1
-        Fp w = fp28::fp_select(hi(), fp28::fp_neg<32>(pb), pb);    // even: 32p - b1, odd: b0
-        return fp28::fp_mul2add(x, b, z, w);
+        Fp s1 = fp28::fp_select(hi(), b, pb);
+        Fp s2 = fp28::fp_select(hi(), neg32_lazy(pb), b);
+        return fp28::fp_mul2add(a, s1, pa, s2);
     }
     static __device__ __forceinline__ E sqr(const E& a) {          // (a0 + a1)(a0 - a1) | (2 a0) a1
         Fp pa = partner(a);
@@ -52,6 +55,32 @@ struct CoopF2 {
     static __device__ __forceinline__ E dbl(const E& a) { return fp28::fp_add(a, a); }
     static __device__ __forceinline__ Fp fp_neg4(const Fp& a) { return fp28::fp_neg<4>(a); }
     static __device__ __forceinline__ E select(bool take_b, const E& a, const E& b) { return fp28::fp_select(take_b, a, b); }
+};
+
+// The same lane-pair field with the hooks ec::xyzz_madd needs, for the G2 accumulate hot loop: every value is ONE Fp per lane
+// (half the registers of an Fp2 per lane: the one-lane-per-item G2 loop kept 1.3 KB of scratch per lane), the two-product
+// sum is one fused four-product reduction per lane, zero tests are pair-wide.  The linear hooks are the normalising ones, as
+// in ec::Fp2OpsT, so the value bounds machine-checked for G2 (tests/host/msm_bounds.cpp) carry over component-wise.
+struct CoopF2A : CoopF2 {
+    static __device__ __forceinline__ bool pair_and(bool v) {
+        int mine = v ? 1 : 0;
+        return (mine & __builtin_amdgcn_mov_dpp(mine, 0xB1, 0xF, 0xF, true)) != 0;
+    }
+    static __device__ __forceinline__ E mul2add(const E& a, const E& b, const E& c, const E& d) {   // a b + c d ; b, d <= 31p
+        Fp pa = partner(a), pb = partner(b), pc = partner(c), pd = partner(d);
+        Fp b1 = fp28::fp_select(hi(), b, pb), b2 = fp28::fp_select(hi(), neg32_lazy(pb), b);
+        Fp d1 = fp28::fp_select(hi(), d, pd), d2 = fp28::fp_select(hi(), neg32_lazy(pd), d);
+        return fp28::fp_mul4add(a, b1, pa, b2, c, d1, pc, d2);      // even: a0 b0 - a1 b1 + c0 d0 - c1 d1 ; odd: a1 b0 + a0 b1 + c1 d0 + c0 d1
+    }
+    static __device__ __forceinline__ E add_l(const E& a, const E& b) { return fp28::fp_add(a, b); }
+    template <int K>
+    static __device__ __forceinline__ E sub_l(const E& a, const E& b) { return fp28::fp_sub<K>(a, b); }
+    template <int K>
+    static __device__ __forceinline__ E neg_l(const E& a) { return fp28::fp_neg<K>(a); }
+    static __device__ __forceinline__ E sub8_wide(const E& a, const E& b) { return fp28::fp_sub<8>(a, b); }
+    static __device__ __forceinline__ E norm(const E& a) { return a; }
+    static __device__ __forceinline__ bool is_zero_2p(const E& a) { return pair_and(fp28::fp_is_zero_2p(a)); }
+    static __device__ __forceinline__ bool limbs_all_zero(const E& a) { return pair_and(ec::FpOps::limbs_all_zero(a)); }
 };
 
 }  // namespace msmk

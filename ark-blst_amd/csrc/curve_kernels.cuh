@@ -92,6 +92,67 @@ __global__ void __launch_bounds__(256, C::OCC) k_accumulate(const uint32_t* __re
     store_bucket<C>(partial + (size_t)i * Geo<C>::BK_WORDS, out);
 }
 
+// G2 accumulate with TWO lanes per work item (CoopF2A: the even lane holds c0 and the odd lane c1 of every Fp2 value; a product
+// exchanges the partner's components by DPP and is one fused reduction per lane).  Same schedule, same entries and the same
+// formulas as k_accumulate<G2C>; the accumulator is 4 x 14 registers per lane instead of 8 x 14, so the hot loop runs without
+// scratch.  Cold path (exceptional pairs): complete additions on the same lane pair through ONE out-of-line body.
+static __device__ __noinline__ void coop_add_inplace(ec::Proj<CoopF2>& a, const ec::Proj<CoopF2>& b) { ec::proj_add<CoopF2>(a, b); }
+
+template <class C>   // C = G2C (a template so that only the G2 translation unit instantiates it)
+__global__ void __launch_bounds__(256, 2) k_accumulate_g2_coop(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                               const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ woff,
+                                                               const uint32_t* __restrict__ order, const uint32_t* __restrict__ item_bucket,
+                                                               uint32_t nitems, uint32_t logT, uint32_t* __restrict__ partial) {
+    using FA = CoopF2A;
+    const uint32_t h = threadIdx.x & 1u;
+    uint32_t j = (blockIdx.x * 256 + threadIdx.x) >> 1;
+    if (j >= nitems) return;        // pairs never straddle the bound (even block size)
+    uint32_t i = order[j];
+    uint32_t b = item_bucket[i];
+    uint32_t k = i - woff[b];
+    uint32_t e = offsets[b] + (k << logT), bend = offsets[b + 1];
+    uint32_t end = e + (1u << logT) < bend ? e + (1u << logT) : bend;
+    auto load_comp = [&](Fp& x, Fp& y, uint32_t ent) {   // this lane's component of x and y: slots x.c0 | x.c1 | y.c0 | y.c1
+        const uint32_t* p = bases + (size_t)(ent & 0x7fffffffu) * G2_PT_WORDS + 16 * h;
+        load_fp16(x, p);
+        load_fp16(y, p + 32);
+    };
+    ec::Xyzz<FA> acc;
+    acc.x = FA::zero(); acc.y = FA::zero(); acc.zz = FA::zero(); acc.zzz = FA::zero();
+    bool inf = true;
+    uint32_t nent = e < end ? sorted[e] : 0u;
+    while (e < end) {
+        uint32_t ent = nent;
+        Fp x, y;
+        load_comp(x, y, ent);
+        if (e + 1 < end) {
+            nent = sorted[e + 1];
+            __builtin_prefetch(bases + (size_t)(nent & 0x7fffffffu) * G2_PT_WORDS + 16 * h, 0, 1);
+        }
+        y = fp28::fp_select((ent >> 31) != 0, y, fp28::fp_neg<4>(y));
+        if (inf) {
+            acc.x = x; acc.y = y; acc.zz = FA::one(); acc.zzz = FA::one();
+            inf = false;
+        } else if (ec::xyzz_madd<FA>(acc, x, y)) {
+            break;  // exceptional pair at entry e (pair-wide decision): acc untouched
+        }
+        e++;
+    }
+    ec::Proj<CoopF2> out = ec::proj_inf<CoopF2>();
+    if (!inf) out = ec::xyzz_to_proj<CoopF2>(reinterpret_cast<const ec::Xyzz<CoopF2>&>(acc));
+    while (e < end) {  // cold path (never taken on random inputs): complete additions
+        uint32_t ent = sorted[e];
+        Fp x, y;
+        load_comp(x, y, ent);
+        y = fp28::fp_select((ent >> 31) != 0, y, fp28::fp_neg<4>(y));
+        ec::Proj<CoopF2> q = ec::proj_from_affine<CoopF2>(x, y);
+        coop_add_inplace(out, q);
+        e++;
+    }
+    uint32_t* o = partial + (size_t)i * G2_BK_WORDS + 16 * h;   // x | y | z, each (c0, c1) in 16-word slots
+    store_fp16(o, out.x); store_fp16(o + 32, out.y); store_fp16(o + 64, out.z);
+}
+
 // One binary-tree level of the per-bucket merge of split buckets: partial[i] += partial[i + d] for the items whose
 // chunk index is a multiple of 2d.  After ceil(log2(max items)) levels partial[woff[b]] is bucket b.  Launched only
 // when some bucket was split (meta[1] > 1), over the items of split buckets only (merge_list, meta[3] entries).

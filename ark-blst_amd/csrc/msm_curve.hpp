@@ -106,6 +106,19 @@ J horner(const J* win, const Plan& pl) {
     return r;
 }
 
+// the dominant kernel: one lane per work item for G1, a lane pair per work item for G2 (k_accumulate_g2_coop)
+template <class C>
+void launch_accumulate(hipStream_t s, const uint32_t* bases, const uint32_t* sorted, const uint32_t* offsets, const uint32_t* woff,
+                       const uint32_t* order, const uint32_t* item_bucket, uint32_t nitems, uint32_t logT, uint32_t* partial) {
+    if constexpr (std::is_same<C, msmk::G2C>::value) {
+        hipLaunchKernelGGL(msmk::k_accumulate_g2_coop<C>, dim3((2 * nitems + 255) / 256), dim3(256), 0, s, bases, sorted, offsets, woff, order,
+                           item_bucket, nitems, logT, partial);
+    } else {
+        hipLaunchKernelGGL(msmk::k_accumulate<C>, dim3((nitems + 255) / 256), dim3(256), 0, s, bases, sorted, offsets, woff, order, item_bucket,
+                           nitems, logT, partial);
+    }
+}
+
 // The pipeline on one device.  d_bases: device-form points (tables of `stride` points when shared); d_scalars: n x 32 B on device.
 template <class C>
 typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint8_t* d_flags, const uint32_t* d_scalars,
@@ -128,10 +141,8 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     hipStream_t s = d.stream;
     const uint32_t nitems = so.nitems, max_items = so.max_items;
     d.partial.ensure((size_t)nitems * BK * 4);
-    uint32_t grid_items = (nitems + 255) / 256;
-    hipLaunchKernelGGL(msmk::k_accumulate<C>, dim3(grid_items), dim3(256), 0, s, d_bases, (const uint32_t*)d.sorted.p,
-                       (const uint32_t*)d.offsets.p, (const uint32_t*)d.woff.p, (const uint32_t*)d.order.p,
-                       (const uint32_t*)d.item_bucket.p, nitems, pl.logT, (uint32_t*)d.partial.p);
+    launch_accumulate<C>(s, d_bases, (const uint32_t*)d.sorted.p, (const uint32_t*)d.offsets.p, (const uint32_t*)d.woff.p,
+                         (const uint32_t*)d.order.p, (const uint32_t*)d.item_bucket.p, nitems, pl.logT, (uint32_t*)d.partial.p);
     uint32_t nlist = so.nlist;
     for (uint32_t dd = 1; dd < max_items && nlist; dd <<= 1)
         hipLaunchKernelGGL(msmk::k_merge<C>, dim3((nlist + 255) / 256), dim3(256), 0, s, (uint32_t*)d.partial.p,
