@@ -85,10 +85,76 @@ using CTower = pairing::Tower<CoopF2>;
 
 // Two lanes per pair (see CoopF2).  Lines of a pair with P or Q at infinity are overwritten with (1, 0, 0) at store time,
 // so every lane runs the same instruction stream (the DPP exchange needs both lanes of a pair anyway).
+//
+// Register diet (the first version of this kernel spilled 442 registers: 1.4 KB of scratch per lane, half of its HBM traffic):
+// the loop-invariant values (-xP, yP of the pair; this lane's component of xQ, yQ) live in LDS and are read where a formula
+// uses them, every line coefficient is stored the moment it is computed, and the formulas (the same as
+// pairing::Tower::line_dbl / line_add, whose bounds tests/host/pairing_bounds.cpp checks) are ordered so that T's old
+// coordinates die early.  What stays in registers across a step is T (3 x 14 limbs per lane).
+constexpr int LINES_LDS_WORDS = 64 * 2 * 16 + 32 * 2 * 16;   // per block of 64 lanes: (xQ, yQ) component per lane, (-xP, yP) per pair
+
+struct LineSink {   // where the three coefficients of one line go: [line][pair][3] Fp2 slots of 32 words, this lane's half
+    uint32_t* o;
+    bool valid, inf;
+    uint32_t h;
+    __device__ __forceinline__ void put(int slot, const Fp& c) const {
+        if (!valid) return;
+        Fp dflt = slot == 0 ? CoopF2::one() : fp28::fp_zero();
+        store_fp16(o + 32 * slot, fp28::fp_select(inf, c, dflt));
+    }
+};
+
+// tangent line at T (scaled by 2YZ) evaluated at P, then T <- 2T (RCB16 Alg. 9, a = 0): 3 S + 7 M.  T <= 6p in, < 4p out.
+__device__ __forceinline__ void coop_line_dbl(ec::Proj<CoopF2>& T, const uint32_t* lds_p, const LineSink& out) {
+    using F2 = CoopF2;
+    Fp t0 = F2::sqr(T.y);                                                    // Y^2
+    Fp t1 = F2::mul(T.y, T.z);                                               // Y Z
+    {
+        Fp yp;
+        load_fp16(yp, lds_p + 16);
+        out.put(2, F2::mul_fp(F2::dbl(t1), yp));                             // c4 = 2 Y Z yP
+    }
+    Fp t2 = F2::mul_b3(F2::sqr(T.z));                                        // b3 Z^2 = 3b' Z^2
+    out.put(0, F2::sub<4>(t0, t2));                                          // c0 = Y^2 - 3b' Z^2     < 6p
+    {
+        Fp nx;
+        load_fp16(nx, lds_p);
+        out.put(1, F2::mul_fp(F2::mul3(F2::sqr(T.x)), nx));                  // c1 = -3 X^2 xP
+    }
+    Fp xy = F2::mul(T.x, T.y);
+    Fp z8 = F2::dbl(F2::dbl(F2::dbl(t0)));                                   // 8 Y^2                  < 16p
+    T.z = F2::mul(t1, z8);                                                   // 8 Y^3 Z
+    Fp x3 = F2::mul(t2, z8);
+    Fp d = F2::sub<8>(t0, F2::add(F2::add(t2, t2), t2));                     // Y^2 - 3 b3 Z^2         < 10p
+    Fp y3 = F2::add(t0, t2);                                                 // Y^2 + b3 Z^2           < 4p
+    T.y = F2::add(x3, F2::mul(d, y3));
+    T.x = F2::dbl(F2::mul(d, xy));
+}
+// line through T and Q (scaled by X - xQ Z) evaluated at P, then T <- T + Q
+__device__ __forceinline__ void coop_line_add(ec::Proj<CoopF2>& T, const uint32_t* lds_q, const uint32_t* lds_p, const LineSink& out) {
+    using F2 = CoopF2;
+    Fp xq, yq;
+    load_fp16(xq, lds_q);
+    load_fp16(yq, lds_q + 16);
+    Fp N = F2::sub<4>(T.y, F2::mul(yq, T.z));                                // < 10p
+    Fp D = F2::sub<4>(T.x, F2::mul(xq, T.z));
+    out.put(0, F2::sub<4>(F2::mul(N, xq), F2::mul(D, yq)));                  // N xQ - D yQ            < 6p
+    {
+        Fp nx, yp;
+        load_fp16(nx, lds_p);
+        load_fp16(yp, lds_p + 16);
+        out.put(1, F2::mul_fp(N, nx));
+        out.put(2, F2::mul_fp(D, yp));
+    }
+    ec::Proj<CoopF2> q = ec::proj_from_affine<CoopF2>(xq, yq);
+    ec::proj_add<CoopF2>(T, q);
+}
+
 __global__ void __launch_bounds__(64, 2) k_miller_lines2(const uint32_t* __restrict__ g1_raw, const uint32_t* __restrict__ g2_raw, uint32_t n,
                                                          uint32_t* __restrict__ lines) {
-    const uint32_t h = threadIdx.x & 1u;
-    const uint32_t pair = (blockIdx.x * 64 + threadIdx.x) >> 1;
+    __shared__ uint32_t cst[LINES_LDS_WORDS];
+    const uint32_t lane = threadIdx.x, h = lane & 1u;
+    const uint32_t pair = (blockIdx.x * 64 + lane) >> 1;
     const bool valid = pair < n;
     const uint32_t i = valid ? pair : n - 1;
     const uint32_t* pr = g1_raw + (size_t)i * Geo<G1C>::RAW_AFF;
@@ -98,31 +164,33 @@ __global__ void __launch_bounds__(64, 2) k_miller_lines2(const uint32_t* __restr
     for (int k = 0; k < Geo<G1C>::RAW_AFF; k++) anyp |= pr[k];
 #pragma unroll 4
     for (int k = 0; k < Geo<G2C>::RAW_AFF; k++) anyq |= qr[k];
-    const bool inf = anyp == 0 || anyq == 0;
-    Fp x, y, xq, yq;
-    fp_from_raw(x, pr);
-    fp_from_raw(y, pr + 12);
-    fp_from_raw(xq, qr + 12 * h);              // this lane's component of x_Q, y_Q
-    fp_from_raw(yq, qr + 24 + 12 * h);
-    CTower::G1Pt p{fp28::fp_neg<4>(x), y};
-    CTower::PT T = ec::proj_from_affine<CoopF2>(xq, yq);
-    const Fp id = CoopF2::one();               // component of the Fp2 one
-    auto put = [&](int line, const Fp& c0, const Fp& c1, const Fp& c4) {
-        if (!valid) return;
-        uint32_t* o = lines + ((size_t)line * n + pair) * 3 * 32 + 16 * h;
-        store_fp16(o, fp28::fp_select(inf, c0, id));              // c0 < 6p in N-form: the accumulate kernel allows for it
-        store_fp16(o + 32, fp28::fp_select(inf, c1, fp28::fp_zero()));
-        store_fp16(o + 64, fp28::fp_select(inf, c4, fp28::fp_zero()));
-    };
+    uint32_t* lds_q = cst + lane * 32;                       // this lane's component of xQ | yQ
+    uint32_t* lds_p = cst + 64 * 32 + (lane >> 1) * 32;      // -xP | yP of the pair (both lanes write the same values)
+    ec::Proj<CoopF2> T;
+    {
+        Fp x, y, xq, yq;
+        fp_from_raw(x, pr);
+        fp_from_raw(y, pr + 12);
+        fp_from_raw(xq, qr + 12 * h);              // this lane's component of x_Q, y_Q
+        fp_from_raw(yq, qr + 24 + 12 * h);
+        store_fp16(lds_p, fp28::fp_neg<4>(x));
+        store_fp16(lds_p + 16, y);
+        store_fp16(lds_q, xq);
+        store_fp16(lds_q + 16, yq);
+        T = ec::proj_from_affine<CoopF2>(xq, yq);
+    }
+    __syncthreads();
+    LineSink out{nullptr, valid, anyp == 0 || anyq == 0, h};
     int line = 0;
 #pragma unroll 1
     for (int b = 62; b >= 0; b--) {
-        Fp c0, c1, c4;
-        CTower::line_dbl(T, p, c0, c1, c4);
-        put(line++, c0, c1, c4);
+        out.o = lines + ((size_t)line * n + pair) * 3 * 32 + 16 * h;
+        coop_line_dbl(T, lds_p, out);
+        line++;
         if ((fp28c::Z_ABS >> b) & 1) {
-            CTower::line_add(T, xq, yq, p, c0, c1, c4);
-            put(line++, c0, c1, c4);
+            out.o = lines + ((size_t)line * n + pair) * 3 * 32 + 16 * h;
+            coop_line_add(T, lds_q, lds_p, out);
+            line++;
         }
     }
 }
