@@ -345,9 +345,80 @@ struct PairG2 {
         for (int t = 0; t < 12; t++) o[48 + t] = any != 0 ? zw[t] : 0u;
     }
 };
+// G2 with EIGHT lanes per logical lane: lane = 8 l + 2 q + h holds component h (c0 / c1) of coordinate q (X, Y, Z; q = 3 idles on
+// bounded garbage).  The Fp2 products run on lane pairs (CoopF2), the coordinates are exchanged across the eight lanes by
+// ds_bpermute.  Per step and lane: two Fp2 products + two multiplications by b3 + one fused pair, ~3800 instructions instead of
+// the ~9500 of PairG2, and a third of the registers (two waves per SIMD); 8 logical lanes per wave.
+struct OctG2 {
+    using C = G2C;
+    using F = CoopF2;
+    static constexpr int LOG_LL = 3, LPL = 8, MAX_OCC = 2;
+    struct Pt { Fp c; };
+    static __device__ __forceinline__ uint32_t h() { return threadIdx.x & 1u; }
+    static __device__ __forceinline__ uint32_t q() { return (threadIdx.x >> 1) & 3u; }
+    static __device__ __forceinline__ uint32_t ll() { return (threadIdx.x & 63u) >> 3; }
+    static __device__ __forceinline__ Fp from_lane(const Fp& a, int src) {
+        Fp r;
+#pragma unroll
+        for (int k = 0; k < NL; k++) r.l[k] = __shfl(a.l[k], src, 64);
+        return r;
+    }
+    static __device__ __forceinline__ int lane_of(uint32_t coord) { return (int)((threadIdx.x & 56u) | (coord << 1) | h()); }   // same group, same component
+    static __device__ __forceinline__ Fp coord(const Fp& a, uint32_t k) { return from_lane(a, lane_of(k)); }
+    static __device__ __forceinline__ Fp next(const Fp& a) { uint32_t qq = q() < 2 ? q() + 1 : 0; return from_lane(a, lane_of(qq)); }
+    static __device__ __forceinline__ Pt inf() { return Pt{fp28::fp_select(q() == 1 && h() == 0, fp28::fp_zero(), fp28::fp_one())}; }   // (0 : 1 : 0)
+    static __device__ __forceinline__ Pt select(bool take_b, const Pt& a, const Pt& b) { return Pt{fp28::fp_select(take_b, a.c, b.c)}; }
+    static __device__ __forceinline__ Pt load(const uint32_t* bucket) {   // x | y | z, each (c0, c1) in 16-word slots
+        uint32_t s = q() < 2 ? q() : 2;
+        Pt r;
+        load_fp16(r.c, bucket + 32 * s + 16 * h());
+        return r;
+    }
+    static __device__ __forceinline__ void store(uint32_t* bucket, const Pt& p) {
+        if (q() < 3) store_fp16(bucket + 32 * q() + 16 * h(), p.c);
+    }
+    static __device__ __forceinline__ Pt shfl_down(const Pt& a, int d) { return Pt{shfl_down_fp(a.c, 8 * d)}; }
+    static __device__ __forceinline__ Pt from_ll(const Pt& a, int src) { return Pt{from_lane(a.c, 8 * src + (int)(threadIdx.x & 7u))}; }
+    // a <- a + b, complete (RCB16 Alg. 7): the structure of QuadG1::add over Fp2 components
+    static __device__ __forceinline__ void add(Pt& a, const Pt& b) {
+        const bool is2 = q() >= 2, is0 = q() == 0;
+        Fp an = next(a.c), bn = next(b.c);
+        Fp own = F::mul(a.c, b.c);                                           // t0 | t1 | t2
+        Fp cross = F::mul(F::add(a.c, an), F::add(b.c, bn));                 // t3 | t4 | t5
+        cross = F::sub<8>(cross, F::add(own, next(own)));                    // X1Y2+X2Y1 | Y1Z2+Y2Z1 | X1Z2+X2Z1
+        Fp t0 = F::mul3(coord(own, 0));                                      // 3 X1X2
+        Fp t1 = coord(own, 1);
+        Fp t2 = F::mul_b3(coord(own, 2));                                    // b3 Z1Z2
+        Fp u = F::add(t1, t2);
+        Fp t1m = F::sub<32>(t1, t2);
+        Fp t3 = coord(cross, 0), t4 = coord(cross, 1);
+        Fp t5 = F::mul_b3(coord(cross, 2));
+        // X3 = t1m t3 - t5 t4 ; Y3 = t1m u + t5 t0 ; Z3 = u t4 + t0 t3
+        Fp A1 = fp28::fp_select(is2, t1m, u);
+        Fp B1v = fp28::fp_select(is0, fp28::fp_select(is2, u, t4), t3);
+        Fp A2 = fp28::fp_select(is2, t5, t0);
+        Fp B2v = fp28::fp_select(is0, fp28::fp_select(is2, t0, t3), F::neg<16>(t4));
+        a.c = CoopF2A::mul2add(A1, B1v, A2, B2v);
+    }
+    static __device__ __forceinline__ void store_jac_raw(uint32_t* out, const Pt& p) {   // (X Z, Y Z^2, Z), this lane's component
+        Fp z = coord(p.c, 2);
+        Fp zz = F::sqr(z);
+        Fp v = fp28::fp_select(q() >= 2, F::mul(p.c, fp28::fp_select(q() == 0, zz, z)), p.c);
+        uint32_t w[12], any = 0;
+        fp28::fp_to_blst(w, v);
+#pragma unroll
+        for (int k = 0; k < 12; k++) any |= w[k];
+        any |= (uint32_t)__builtin_amdgcn_mov_dpp((int)any, 0xB1, 0xF, 0xF, true);   // either component
+        any = (uint32_t)__shfl((int)any, lane_of(2), 64);                              // of Z
+        if (q() < 3) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) out[24 * q() + 12 * h() + k] = any != 0 ? w[k] : 0u;
+        }
+    }
+};
 template <class C> struct CoopOf;
-template <> struct CoopOf<G1C> { using CS = QuadG1; };
-template <> struct CoopOf<G2C> { using CS = PairG2; };
+template <> struct CoopOf<G1C> { using RS = QuadG1; using CS = QuadG1; };
+template <> struct CoopOf<G2C> { using RS = PairG2; using CS = OctG2; };   // throughput-bound reduce, latency-bound combine
 
 // One wave per chunk of K = NLL * L consecutive buckets of one window (NLL = 2^LOG_LL logical lanes, L = 2^logL).  Logical lane l
 // owns buckets [l L, l L + L) of the chunk.  Output per chunk, in the device bucket layout: pairs[2 chunk] = K * S with

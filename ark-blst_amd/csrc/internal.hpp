@@ -11,11 +11,13 @@ namespace mi {
 
 // ---- msm_sort.hip
 struct CurveCost {        // what the plan needs to know about the curve's kernels (microseconds, measured)
-    int log_ll;           // log2 logical lanes per reduce wave (coop scheme)
+    int log_ll;           // log2 logical lanes per reduce wave (coop scheme of k_reduce_coop)
+    int comb_log_ll;      // log2 logical lanes per combine wave (k_combine may use a narrower, lower-latency scheme)
     uint32_t max_chunks;  // reduce waves that run at once (1024 SIMDs x occupancy)
     double add_per_us;    // mixed additions per microsecond of the accumulate kernel at full occupancy
     double lane_add_us;   // one lane's time per mixed addition (latency view)
-    double step_us;       // one complete addition of the reduce / combine chain
+    double step_us;       // one complete addition of the reduce chain
+    double comb_step_us;  // one complete addition of the combine chain
     double merge_us;      // one level of the split-bucket merge
 };
 // shared = false: one bucket set per window (plain bases).  shared = true: resident 2^(c j) P tables — every window feeds ONE

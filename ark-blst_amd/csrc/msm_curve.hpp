@@ -13,12 +13,13 @@ template <> struct HostCurve<msmk::G1C> {
     using J = hostec::G1;
     static constexpr int IDX = 0;
     // accumulate 7.1e9 additions/s, 11 us per addition and lane; quad-lane complete addition ~6 us per step, two waves per SIMD
-    static CurveCost cost() { return CurveCost{msmk::QuadG1::LOG_LL, 2048, 7100.0, 11.0, 6.0, 60.0}; }
+    static CurveCost cost() { return CurveCost{msmk::QuadG1::LOG_LL, msmk::QuadG1::LOG_LL, 2048, 7100.0, 11.0, 9.5, 5.6, 60.0}; }
 };
 template <> struct HostCurve<msmk::G2C> {
     using J = hostec::G2;
     static constexpr int IDX = 1;
-    static CurveCost cost() { return CurveCost{msmk::PairG2::LOG_LL, 1024, 1950.0, 36.0, 30.0, 150.0}; }
+    // lane pairs for the reduce (throughput), eight lanes per logical lane for the combine (latency)
+    static CurveCost cost() { return CurveCost{msmk::PairG2::LOG_LL, msmk::OctG2::LOG_LL, 1024, 2200.0, 33.0, 28.0, 14.0, 150.0}; }
 };
 template <class C> constexpr size_t aff_bytes() { return (size_t)msmk::Geo<C>::RAW_AFF * 4; }
 template <class C> constexpr size_t jac_bytes() { return (size_t)msmk::Geo<C>::RAW_JAC * 4; }
@@ -124,7 +125,8 @@ template <class C>
 typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint8_t* d_flags, const uint32_t* d_scalars,
                                  size_t n, unsigned fmt, bool shared, unsigned table_c, size_t stride, int ev0) {
     using J = typename HostCurve<C>::J;
-    using CS = typename msmk::CoopOf<C>::CS;
+    using RS = typename msmk::CoopOf<C>::RS;   // lane scheme of the reduce kernel
+    using CS = typename msmk::CoopOf<C>::CS;   // lane scheme of the combine levels
     constexpr int BK = msmk::Geo<C>::BK_WORDS;
     Plan pl = make_plan(n, shared ? table_c : ctx->forced_c, HostCurve<C>::cost(), shared, stride);
     if (pl.c == 0) throw HipFail{"window_bits not usable for this n (sort geometry)"};
@@ -150,7 +152,7 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     HIP_TRY(hipEventRecord(d.ev[ev0 + 4], s));
     // bucket reduction: one wave per chunk of 2^chunk_log buckets -> (K S, T) pairs; then the per-window combine, 2^LOG_LL pairs per
     // wave and level, down to one Jacobian point per window
-    hipLaunchKernelGGL(msmk::k_reduce_coop<CS>, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
+    hipLaunchKernelGGL(msmk::k_reduce_coop<RS>, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
                        (const uint32_t*)d.woff.p, (uint32_t*)d.pairs.p, pl.logL);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 5], s));
     uint32_t* jac_dev = (uint32_t*)((char*)d.pairs2.p + d.pairs2.cap - (size_t)pl.bwin * jac_bytes<C>());

@@ -55,10 +55,10 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         const double item_len = std::min(T, std::max(mean, std::min(per_bucket, T)));   // entries a lane walks serially
         const double rounds = (double)((p.nchunks + cc.max_chunks - 1) / cc.max_chunks);
         int levels = 0;
-        for (uint32_t m = p.chunks_per_win; m > 1; m = (m + (1u << log_ll) - 1) >> log_ll) levels++;
+        for (uint32_t m = p.chunks_per_win; m > 1; m = (m + (1u << cc.comb_log_ll) - 1) >> cc.comb_log_ll) levels++;
         double cost = std::max(entries / cc.add_per_us, item_len * cc.lane_add_us) + merge_levels * cc.merge_us +
                       rounds * (2.0 * (1u << p.logL) + 2.0 * log_ll + p.logL + 1.0) * cc.step_us +
-                      std::max(1, levels) * ((2.0 * log_ll + 1.0) * cc.step_us + 8.0) + entries / 41000.0 + (double)p.nbuckets / 1e4 +
+                      std::max(1, levels) * ((2.0 * cc.comb_log_ll + 1.0) * cc.comb_step_us + 8.0) + entries / 41000.0 + (double)p.nbuckets / 1e4 +
                       (shared ? 20.0 : 100.0);
         if (cost < best_cost) {
             best_cost = cost;
