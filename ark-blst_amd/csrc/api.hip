@@ -8,11 +8,25 @@ namespace mi { std::atomic<int> g_fail_allocs{0}; }
 
 using namespace mi;
 
+namespace {
+// The host tail (Horner fold, partial-sum fold, final exponentiation) is compiled for BMI2 + ADX (Intel since Broadwell, AMD
+// since Zen): on anything older the entry points that run it return MI_E_UNSUPPORTED instead of faulting.
+bool cpu_ok() {
+#if defined(__x86_64__) && defined(__ADX__)
+    static const bool ok = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx");
+    return ok;
+#else
+    return true;
+#endif
+}
+}  // namespace
+
 extern "C" {
 
 int mi_msm_init(mi_ctx** out, const int* device_ids, int n_devices) {
     if (!out || n_devices < 0) return MI_E_INVALID;
     *out = nullptr;
+    if (!cpu_ok()) return MI_E_UNSUPPORTED;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MI_E_NO_DEVICE;
     if (n_devices == 0) n_devices = device_ids ? 0 : count;
@@ -135,10 +149,11 @@ int mi_multi_miller_loop(mi_ctx* ctx, const mi_g1_affine* p, const mi_g2_affine*
 int mi_multi_pairing(mi_ctx* ctx, const mi_g1_affine* p, const mi_g2_affine* q, size_t n, mi_fp12* out) {
     return miller(ctx, p, q, n, out, true);
 }
-int mi_final_exponentiation(const mi_fp12* f, mi_fp12* out) { return final_exponentiation(f, out); }
+int mi_final_exponentiation(const mi_fp12* f, mi_fp12* out) { return cpu_ok() ? final_exponentiation(f, out) : MI_E_UNSUPPORTED; }
 
 int mi_g1_sum(const mi_g1* partials, size_t n, mi_g1* out) {
     if (!out || (n && !partials)) return MI_E_INVALID;
+    if (!cpu_ok()) return MI_E_UNSUPPORTED;
     hostec::G1 r = hostec::G1::inf();
     for (size_t i = 0; i < n; i++) {
         hostec::G1 p;
@@ -151,6 +166,7 @@ int mi_g1_sum(const mi_g1* partials, size_t n, mi_g1* out) {
 
 int mi_g2_sum(const mi_g2* partials, size_t n, mi_g2* out) {
     if (!out || (n && !partials)) return MI_E_INVALID;
+    if (!cpu_ok()) return MI_E_UNSUPPORTED;
     hostec::G2 r = hostec::G2::inf();
     for (size_t i = 0; i < n; i++) {
         hostec::G2 p;
@@ -189,7 +205,7 @@ const char* mi_msm_strerror(int code) {
         case MI_E_HIP: return "HIP runtime error";
         case MI_E_NOMEM: return "out of memory";
         case MI_E_NO_BASES: return "no resident base set";
-        case MI_E_UNSUPPORTED: return "not supported in this build";
+        case MI_E_UNSUPPORTED: return "not supported on this host (the library needs an x86-64 CPU with BMI2 and ADX)";
         default: return "unknown error";
     }
 }

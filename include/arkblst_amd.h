@@ -57,7 +57,7 @@ enum {
     MI_E_HIP = -3,          /* a HIP runtime call failed; mi_msm_last_error() has the text */
     MI_E_NOMEM = -4,        /* device or host allocation failed */
     MI_E_NO_BASES = -5,     /* bases == NULL but no resident base set was uploaded */
-    MI_E_UNSUPPORTED = -6   /* entry point not available in this build */
+    MI_E_UNSUPPORTED = -6   /* host CPU lacks BMI2 / ADX (the host tail is built for them) */
 };
 
 /* Per-call timing of the last MSM on this context, milliseconds, measured with HIP events on the

@@ -1,0 +1,123 @@
+// Host-only test of the library's threading and error plumbing (ark-blst_amd/csrc/common.hpp): the persistent per-device
+// workers, the lane lock, and the rule that nothing crosses the C ABI as an exception — an allocation failure inside a worker
+// thread comes back as MI_E_NOMEM instead of std::terminate.  Needs no GPU: without a device hipMalloc itself fails (MI_E_HIP),
+// and the test build's hook injects the out-of-memory case.  Built three times by tests/test_host_threads.py: plain,
+// -fsanitize=thread, -fsanitize=address,undefined.
+#define MI_TEST_HOOKS 1
+#include "../../ark-blst_amd/csrc/common.hpp"
+
+#include <cassert>
+#include <stdexcept>
+
+namespace mi { std::atomic<int> g_fail_allocs{0}; }
+using namespace mi;
+
+#define CHECK(x) do { if (!(x)) { fprintf(stderr, "CHECK failed: %s (%s:%d)\n", #x, __FILE__, __LINE__); return 1; } } while (0)
+
+int main() {
+    // 1. persistent workers: every job runs exactly once per round on its own thread, rounds do not overlap
+    {
+        const size_t G = 8;
+        DeviceWorkers w(G);
+        std::vector<long> count(G, 0);
+        std::atomic<int> inside{0};
+        std::atomic<bool> overlap{false};
+        for (int round = 0; round < 2000; round++) {
+            std::function<void(size_t)> fn = [&](size_t k) {
+                inside.fetch_add(1);
+                count[k]++;   // slot k is only ever touched by worker k inside a round, and by this thread between rounds
+                if (inside.load() > (int)G) overlap = true;
+                inside.fetch_sub(1);
+            };
+            w.run(fn);
+            for (size_t k = 0; k < G; k++) CHECK(count[k] == round + 1);
+        }
+        CHECK(!overlap.load());
+    }
+    // 2. failures inside workers become codes: injected out-of-memory -> MI_E_NOMEM, bad_alloc -> MI_E_NOMEM, anything else -> MI_E_HIP
+    {
+        const size_t G = 6;
+        DeviceWorkers w(G);
+        for (int rep = 0; rep < 50; rep++) {
+            std::vector<PartErr> errs(G);
+            g_fail_allocs.store(3);
+            std::function<void(size_t)> fn = [&](size_t k) {
+                guarded_part(errs[k], [&] {
+                    DevBuf b;
+                    b.ensure(1 << 20);   // injected failure for three of the workers; the others reach hipMalloc
+                    b.release();
+                });
+            };
+            w.run(fn);
+            int nomem = 0;
+            for (auto& e : errs) {
+                if (e.code == MI_E_NOMEM) { nomem++; CHECK(e.msg.find("out of memory") != std::string::npos); }
+                else CHECK(e.code == MI_OK || e.code == MI_E_HIP);   // OK with a GPU, "no device" without
+            }
+            CHECK(nomem == 3);
+            g_fail_allocs.store(0);
+            std::vector<PartErr> e2(G);
+            std::function<void(size_t)> fn2 = [&](size_t k) {
+                guarded_part(e2[k], [&] {
+                    if (k == 0) throw std::bad_alloc();
+                    if (k == 1) throw std::runtime_error("boom");
+                    if (k == 2) throw 42;
+                    if (k == 3) throw HipFail{"hipFoo failed: out of memory", false};
+                });
+            };
+            w.run(fn2);
+            CHECK(e2[0].code == MI_E_NOMEM && e2[1].code == MI_E_HIP && e2[2].code == MI_E_HIP && e2[3].code == MI_E_NOMEM && e2[4].code == MI_OK);
+            CHECK(e2[1].msg.find("boom") != std::string::npos);
+        }
+    }
+    // 3. guarded(): the same mapping on the calling thread, text kept per thread and per context
+    {
+        mi_ctx ctx;
+        CHECK(guarded(&ctx, []() -> int { throw std::bad_alloc(); }) == MI_E_NOMEM);
+        CHECK(guarded(&ctx, []() -> int { throw HipFail{"x failed", true}; }) == MI_E_NOMEM);
+        CHECK(guarded(&ctx, []() -> int { throw HipFail{"y failed", false}; }) == MI_E_HIP);
+        CHECK(tls_error() == "y failed" && ctx.err == "y failed");
+        CHECK(guarded(&ctx, []() -> int { return MI_OK; }) == MI_OK);
+        std::thread t([&] { (void)guarded(&ctx, []() -> int { throw HipFail{"from another thread", false}; }); });
+        t.join();
+        CHECK(tls_error() == "y failed");   // this thread's text is its own
+    }
+    // 4. lane lock: at most two shared holders, an exclusive holder is alone
+    {
+        mi_ctx ctx;
+        std::atomic<int> shared_in{0}, excl_in{0}, bad{0};
+        auto body = [&](int t) {
+            for (int i = 0; i < 3000; i++) {
+                if ((i + t) % 7 == 0) {
+                    LaneLock lk(&ctx, true);
+                    if (excl_in.fetch_add(1) != 0 || shared_in.load() != 0) bad++;
+                    excl_in.fetch_sub(1);
+                } else {
+                    LaneLock lk(&ctx, false);
+                    int s = shared_in.fetch_add(1) + 1;
+                    if (s > NLANES || excl_in.load() != 0 || lk.lane < 0 || lk.lane >= NLANES) bad++;
+                    shared_in.fetch_sub(1);
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 0; t < 6; t++) th.emplace_back(body, t);
+        for (auto& t : th) t.join();
+        CHECK(bad.load() == 0);
+    }
+    // 5. shards cover [0, n) exactly once
+    for (size_t n : {0ul, 1ul, 7ul, 1000ul, 16777216ul}) {
+        for (size_t g : {1ul, 2ul, 3ul, 8ul}) {
+            size_t next = 0;
+            for (size_t k = 0; k < g; k++) {
+                size_t lo, hi;
+                shard_range(n, g, k, lo, hi);
+                CHECK(lo == std::min(next, n) && hi >= lo);
+                next = hi;
+            }
+            CHECK(next == n);
+        }
+    }
+    printf("workers OK\n");
+    return 0;
+}
