@@ -37,9 +37,10 @@ __device__ __forceinline__ void load_point(typename C::F::E& x, typename C::F::E
 // One lane per WORK ITEM = (bucket, chunk): item i of bucket b covers entries
 // sorted[offsets[b] + k*T .. min(offsets[b] + (k+1)*T, offsets[b+1])), k = i - woff[b]; entries are (index | sign<<31).
 // Hot loop: XYZZ mixed additions.  Register budget is the constraint (256 VGPRs at 2 waves/SIMD), so the next
-// point is not staged in registers: its index is fetched one iteration ahead and its line(s) touched early so the
-// real load hits L2; the other resident wave covers what latency is left (staging the next point in 28 more
-// registers was measured slower: 3.06 vs 2.88 ms, it pushes the loop into scratch spills).
+// point is not staged in registers (28 more registers spill: 3.06 vs 2.88 ms); its index is fetched one iteration ahead and
+// the other resident wave covers the load latency — completely, as it turned out: routing the next point through LDS
+// with global_load_lds_dwordx4 (no registers, load overlapped with the running addition; tools/probe/lds_load_probe.hip)
+// left the kernel time unchanged (2.38 vs 2.38 ms), the SIMDs are issue-bound either way.
 // A lane that meets an exceptional pair (same x) leaves the hot loop and finishes on the complete formulas.
 // Output: partial[i] (projective), i = natural item id.
 template <class C>
@@ -67,7 +68,6 @@ __global__ void __launch_bounds__(256, C::OCC) k_accumulate(const uint32_t* __re
         load_point<C>(x, y, bases, ent);
         if (e + 1 < end) {
             nent = sorted[e + 1];
-            __builtin_prefetch(bases + (size_t)(nent & 0x7fffffffu) * Geo<C>::PT_WORDS, 0, 1);
         }
         y = F::select((ent >> 31) != 0, y, FA::template neg_l<4>(y));
         if (inf) {
@@ -127,7 +127,6 @@ __global__ void __launch_bounds__(256, 2) k_accumulate_g2_coop(const uint32_t* _
         load_comp(x, y, ent);
         if (e + 1 < end) {
             nent = sorted[e + 1];
-            __builtin_prefetch(bases + (size_t)(nent & 0x7fffffffu) * G2_PT_WORDS + 16 * h, 0, 1);
         }
         y = fp28::fp_select((ent >> 31) != 0, y, fp28::fp_neg<4>(y));
         if (inf) {

@@ -40,16 +40,19 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         p.chunk_log = log_ll + p.logL;
         p.chunks_per_win = p.nb >> p.chunk_log;
         p.nchunks = (uint64_t)p.chunks_per_win * p.bwin;
-        // work-item size: twice the mean bucket load (uniform scalars then never split), at least 32 entries
+        // The top window holds only 255 - c (nwin - 1) significant bits: its n entries share 2^top_bits buckets (on top of the
+        // others' entries when all windows share one bucket set)
         const double entries = (double)n * p.nwin;
         double mean = entries / (double)p.nbuckets;
-        p.logT = 5;
-        while ((double)(1u << p.logT) < 2.0 * mean && p.logT < 20) p.logT++;
-        const double T = (double)(1u << p.logT);
-        // The top window holds only 255 - c (nwin - 1) significant bits: its n entries share 2^top_bits buckets, and
-        // buckets beyond T entries are split and merged by a binary tree
         int top_bits = std::max(0, std::min<int>(255 - (int)c * ((int)p.nwin - 1), (int)c - 1));
         double per_bucket = (double)n / (double)(1u << top_bits) + (shared ? mean : 0.0);
+        // work-item size: twice the mean bucket load (uniform scalars then never split), at least 32 entries; the fuller buckets
+        // of the top window count as the mean while they are within 4x of it (splitting them would cost a merge launch for
+        // nothing); buckets beyond T entries are split and merged by a binary tree
+        const double typical = per_bucket > mean && per_bucket <= 4.0 * mean ? per_bucket : mean;
+        p.logT = 5;
+        while ((double)(1u << p.logT) < 2.0 * typical && p.logT < 20) p.logT++;
+        const double T = (double)(1u << p.logT);
         int merge_levels = 0;
         for (double x = per_bucket; x > T; x *= 0.5) merge_levels++;
         const double item_len = std::min(T, std::max(mean, std::min(per_bucket, T)));   // entries a lane walks serially
