@@ -9,6 +9,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -47,10 +48,32 @@ using G2Affine = mi_g2_affine;
 
 // One process-wide context, created on first use — the reference rebuilds program and kernel on every call
 // (src/gpu.rs:233-237) and panics if that fails (`.expect`, gpu.rs:235,237); here creation failure throws.
+// Devices: GPU 0 by default, like the reference's `Device::all()[0]` (src/gpu.rs:233-234).  ARKBLST_AMD_DEVICES selects
+// others: a comma-separated list of device ids ("0,1,2,3"), or "all".  The multi-device path (bases sharded contiguously,
+// one persistent host thread per device) is opt-in: it has been rehearsed on one GPU listed several times and in
+// multi-process form, not yet run on a multi-GPU node.
 inline mi_ctx* context() {
     static mi_ctx* ctx = [] {
         mi_ctx* c = nullptr;
-        int rc = mi_msm_init(&c, nullptr, 0);
+        std::vector<int> ids{0};
+        bool all = false;
+        if (const char* e = std::getenv("ARKBLST_AMD_DEVICES")) {
+            std::string v(e);
+            if (v == "all") {
+                all = true;
+            } else {
+                ids.clear();
+                size_t pos = 0;
+                while (pos <= v.size()) {
+                    size_t q = v.find(',', pos);
+                    if (q == std::string::npos) q = v.size();
+                    if (q > pos) ids.push_back(std::atoi(v.substr(pos, q - pos).c_str()));
+                    pos = q + 1;
+                }
+                if (ids.empty()) ids.push_back(0);
+            }
+        }
+        int rc = all ? mi_msm_init(&c, nullptr, 0) : mi_msm_init(&c, ids.data(), (int)ids.size());
         if (rc != MI_OK) throw std::runtime_error(std::string("Cannot initialize MI355X MSM context: ") + mi_msm_strerror(rc));
         return c;
     }();
