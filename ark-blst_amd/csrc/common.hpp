@@ -53,7 +53,8 @@ struct Plan {
     uint32_t bwin;        // bucket sets: nwin, or 1 when all windows share one (precomputed tables)
     uint32_t nb, logL, chunks_per_win, logT, lo_bits;
     uint64_t nbuckets, nchunks;
-    uint32_t chunk_log;   // log2 of the buckets one reduce wave covers
+    uint32_t chunk_log;   // log2 of the buckets one reduce wave (or, serial form, one reduce lane) covers
+    bool serial_reduce;   // throughput form: one lane per 64 buckets (k_reduce_serial)
 };
 
 struct DevBuf {

@@ -493,6 +493,68 @@ __global__ void __launch_bounds__(64, CS::MAX_OCC) k_reduce_coop(const uint32_t*
     if (ll == 0) CS::store(pairs + (size_t)(2 * chunk + 1) * BK, acc);
 }
 
+// Throughput form of the bucket reduction for millions of buckets (>= 2^21: 2^24 points at c = 20 have 6.8 M): ONE lane per 64
+// consecutive buckets, single-lane complete additions (5200 instructions per addition instead of 4 x 1864 on a quad), two
+// waves per SIMD.  Only the running sum lives in registers across a step: the weighted sum `acc` is parked in LDS (168 B per
+// lane) while run += B is computed and fetched for acc += run, so the one inlined addition site fits 256 VGPRs without
+// spilling (the round-1 kernel kept run, acc and a third point live: 512 VGPRs, one wave per SIMD, half the issue rate).
+// Lane g leaves the pair (64 S, T) of its 64 buckets in the layout k_reduce_coop uses: k_combine takes it from there.
+template <class C>
+__global__ void __launch_bounds__(64, 2) k_reduce_serial(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ woff,
+                                                        uint32_t nlanes, uint32_t* __restrict__ pairs) {
+    using F = typename C::F;
+    using FR = typename C::FR;
+    using E = typename F::E;
+    using PJ = ec::Proj<F>;
+    using PR = ec::Proj<FR>;
+    constexpr int BK = Geo<C>::BK_WORDS, SLOT = Geo<C>::SLOT;
+    constexpr uint32_t L = 64;
+    __shared__ uint32_t park[64 * BK];   // acc of every lane, slot-interleaved: [coordinate][lane][SLOT words]
+    const uint32_t lane = threadIdx.x;
+    uint32_t g = blockIdx.x * 64 + lane;
+    const bool live = g < nlanes;
+    if (!live) g = nlanes - 1;             // idle lanes of the last wave repeat the last lane's work and store nothing
+    const uint32_t* wp = woff + (size_t)g * L;
+    auto park_store = [&](const PJ& p) {
+        ElemIO<E>::store(park + (0 * 64 + lane) * SLOT, p.x);
+        ElemIO<E>::store(park + (1 * 64 + lane) * SLOT, p.y);
+        ElemIO<E>::store(park + (2 * 64 + lane) * SLOT, p.z);
+    };
+    auto park_load = [&]() {
+        PJ p;
+        ElemIO<E>::load(p.x, park + (0 * 64 + lane) * SLOT);
+        ElemIO<E>::load(p.y, park + (1 * 64 + lane) * SLOT);
+        ElemIO<E>::load(p.z, park + (2 * 64 + lane) * SLOT);
+        return p;
+    };
+    PJ run = ec::proj_inf<F>();
+    park_store(ec::proj_inf<F>());
+    uint32_t idx = wp[L - 1];
+#pragma unroll 1
+    for (uint32_t s = 0; s < 2 * L + 6; s++) {   // 2 L running-sum steps, then six doublings of run (64 S)
+        PJ A, B;
+        const bool even = (s & 1u) == 0, dbl = s >= 2 * L;
+        if (dbl) {
+            A = run; B = run;
+        } else if (even) {
+            A = run;
+            B = load_bucket<C>(partial + (size_t)idx * BK);
+            const uint32_t t = s >> 1;
+            if (t + 1 < L) idx = wp[L - 2 - t];
+        } else {
+            A = park_load();
+            B = run;
+        }
+        ec::proj_add<FR>(reinterpret_cast<PR&>(A), reinterpret_cast<const PR&>(B));
+        if (dbl || even) run = A;
+        else park_store(A);
+    }
+    if (live) {
+        store_bucket<C>(pairs + (size_t)(2 * g) * BK, run);
+        store_bucket<C>(pairs + (size_t)(2 * g + 1) * BK, park_load());
+    }
+}
+
 // One level of the per-window combine: a wave takes NLL consecutive pairs (S'_j, T_j) of one window (S'_j = K S_j already
 // scaled by the element size K of this level) and leaves ONE pair for the next level:
 //   T_out = sum_j T_j + sum_{j >= 1} P'_j,  P'_j = sum_{i >= j} S'_i  (= sum_j (T_j + j K S_j)),   S'_out = NLL * P'_0.

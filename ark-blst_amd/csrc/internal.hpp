@@ -19,6 +19,8 @@ struct CurveCost {        // what the plan needs to know about the curve's kerne
     double step_us;       // one complete addition of the reduce chain
     double comb_step_us;  // one complete addition of the combine chain
     double merge_us;      // one level of the split-bucket merge
+    uint64_t serial_buckets;  // bucket count from which the one-lane-per-64-buckets reduce is used (0 = never)
+    double serial_step_us;    // one single-lane complete addition at two waves per SIMD
 };
 // shared = false: one bucket set per window (plain bases).  shared = true: resident 2^(c j) P tables — every window feeds ONE
 // bucket set; `stride` = points per table (entry index = w * stride + i).  forced_c = 0 lets the time model choose.

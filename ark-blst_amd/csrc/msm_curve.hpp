@@ -13,13 +13,13 @@ template <> struct HostCurve<msmk::G1C> {
     using J = hostec::G1;
     static constexpr int IDX = 0;
     // accumulate 7.1e9 additions/s, 11 us per addition and lane; quad-lane complete addition ~6 us per step, two waves per SIMD
-    static CurveCost cost() { return CurveCost{msmk::QuadG1::LOG_LL, msmk::QuadG1::LOG_LL, 2048, 7100.0, 11.0, 9.5, 5.6, 60.0}; }
+    static CurveCost cost() { return CurveCost{msmk::QuadG1::LOG_LL, msmk::QuadG1::LOG_LL, 2048, 7400.0, 11.0, 9.5, 5.6, 60.0, 1ull << 21, 25.0}; }
 };
 template <> struct HostCurve<msmk::G2C> {
     using J = hostec::G2;
     static constexpr int IDX = 1;
     // lane pairs for the reduce (throughput), eight lanes per logical lane for the combine (latency)
-    static CurveCost cost() { return CurveCost{msmk::PairG2::LOG_LL, msmk::OctG2::LOG_LL, 1024, 2200.0, 33.0, 28.0, 14.0, 150.0}; }
+    static CurveCost cost() { return CurveCost{msmk::PairG2::LOG_LL, msmk::OctG2::LOG_LL, 1024, 2300.0, 33.0, 28.0, 14.0, 150.0, 0, 0.0}; }
 };
 template <class C> constexpr size_t aff_bytes() { return (size_t)msmk::Geo<C>::RAW_AFF * 4; }
 template <class C> constexpr size_t jac_bytes() { return (size_t)msmk::Geo<C>::RAW_JAC * 4; }
@@ -152,8 +152,19 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     HIP_TRY(hipEventRecord(d.ev[ev0 + 4], s));
     // bucket reduction: one wave per chunk of 2^chunk_log buckets -> (K S, T) pairs; then the per-window combine, 2^LOG_LL pairs per
     // wave and level, down to one Jacobian point per window
-    hipLaunchKernelGGL(msmk::k_reduce_coop<RS>, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
-                       (const uint32_t*)d.woff.p, (uint32_t*)d.pairs.p, pl.logL);
+    bool reduced = false;
+    if constexpr (std::is_same<C, msmk::G1C>::value) {   // the throughput form exists for G1 only (HostCurve<G2C>::cost() never asks for it)
+        if (pl.serial_reduce) {
+            hipLaunchKernelGGL(msmk::k_reduce_serial<C>, dim3((uint32_t)((pl.nchunks + 63) / 64)), dim3(64), 0, s, (const uint32_t*)d.partial.p,
+                               (const uint32_t*)d.woff.p, (uint32_t)pl.nchunks, (uint32_t*)d.pairs.p);
+            reduced = true;
+        }
+    }
+    if (!reduced) {
+        if (pl.serial_reduce) throw HipFail{"serial reduce requested for a curve without it"};
+        hipLaunchKernelGGL(msmk::k_reduce_coop<RS>, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
+                           (const uint32_t*)d.woff.p, (uint32_t*)d.pairs.p, pl.logL);
+    }
     HIP_TRY(hipEventRecord(d.ev[ev0 + 5], s));
     uint32_t* jac_dev = (uint32_t*)((char*)d.pairs2.p + d.pairs2.cap - (size_t)pl.bwin * jac_bytes<C>());
     {

@@ -1,5 +1,6 @@
 // Window-size plan, two-level LDS-staged bucket sort and work-item schedule of one MSM call (curve independent).
 // Plays the role of calc_window_size / work_units / calc_chunk_size of the reference driver (/root/reference/src/gpu.rs:37-92,218-223).
+#include <cmath>
 #include "internal.hpp"
 #include "sort_kernels.cuh"
 
@@ -38,6 +39,8 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         p.logL = 0;
         while (p.logL < 6 && p.logL + log_ll < c - 1 && (p.nbuckets >> (log_ll + p.logL)) > cc.max_chunks) p.logL++;
         p.chunk_log = log_ll + p.logL;
+        p.serial_reduce = cc.serial_buckets != 0 && p.nbuckets >= cc.serial_buckets && c - 1 >= 6;
+        if (p.serial_reduce) { p.chunk_log = 6; p.logL = 6; }
         p.chunks_per_win = p.nb >> p.chunk_log;
         p.nchunks = (uint64_t)p.chunks_per_win * p.bwin;
         // The top window holds only 255 - c (nwin - 1) significant bits: its n entries share 2^top_bits buckets (on top of the
@@ -59,10 +62,16 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         const double rounds = (double)((p.nchunks + cc.max_chunks - 1) / cc.max_chunks);
         int levels = 0;
         for (uint32_t m = p.chunks_per_win; m > 1; m = (m + (1u << cc.comb_log_ll) - 1) >> cc.comb_log_ll) levels++;
-        double cost = std::max(entries / cc.add_per_us, item_len * cc.lane_add_us) + merge_levels * cc.merge_us +
-                      rounds * (2.0 * (1u << p.logL) + 2.0 * log_ll + p.logL + 1.0) * cc.step_us +
-                      std::max(1, levels) * ((2.0 * cc.comb_log_ll + 1.0) * cc.comb_step_us + 8.0) + entries / 41000.0 + (double)p.nbuckets / 1e4 +
-                      (shared ? 20.0 : 100.0);
+        const double reduce_us = p.serial_reduce ? std::ceil((double)p.nchunks / 131072.0) * 134.0 * cc.serial_step_us
+                                                 : rounds * (2.0 * (1u << p.logL) + 2.0 * log_ll + p.logL + 1.0) * cc.step_us;
+        // combine: one latency chain per level; the first level of a long pair list runs in several rounds of 2048 waves
+        const double comb_chain = (2.0 * cc.comb_log_ll + 1.0) * cc.comb_step_us;
+        const double comb_us = std::max(1, levels) * (comb_chain + 8.0) +
+                               std::max(0.0, std::ceil((double)(p.nchunks >> cc.comb_log_ll) / 2048.0) - 1.0) * comb_chain;
+        // accumulate: every work item also pays ~1.4 additions' worth of set-up and XYZZ -> projective conversion
+        const double acc_adds = entries + 1.4 * (double)p.nbuckets;
+        double cost = std::max(acc_adds / cc.add_per_us, item_len * cc.lane_add_us) + merge_levels * cc.merge_us + reduce_us + comb_us +
+                      entries / 41000.0 + (double)p.nbuckets / 1e4 + (shared ? 20.0 : 100.0);
         if (cost < best_cost) {
             best_cost = cost;
             best = p;
