@@ -143,15 +143,16 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
     d.seg_cnt.ensure((size_t)g.nbins * 4);
     d.seg_base.ensure((size_t)(g.nbins + 1) * 4);
     d.segcnt.ensure((size_t)segs_cap * (1u << g.lo_bits) * 4);
+    d.segoff.ensure((size_t)segs_cap * (1u << g.lo_bits) * 4);
     hipLaunchKernelGGL(msmk::k_seg_count, dim3((g.nbins + 255) / 256), dim3(256), 0, s, (const uint32_t*)d.bin_base.p, g.nbins,
                        (uint32_t*)d.seg_cnt.p);
     hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.seg_cnt.p, g.nbins, (uint32_t*)d.seg_base.p);
     hipLaunchKernelGGL(msmk::k_fine_count, dim3(segs_cap), dim3(256), 0, s, (const uint32_t*)d.coarse.p, (const uint32_t*)d.bin_base.p,
                        (const uint32_t*)d.seg_base.p, g, (uint32_t*)d.segcnt.p);
-    hipLaunchKernelGGL(msmk::k_fine_scan, dim3(g.nbins), dim3(256), 0, s, (const uint32_t*)d.seg_base.p, g, (uint32_t*)d.segcnt.p,
-                       (uint32_t*)d.hist.p);
+    hipLaunchKernelGGL(msmk::k_fine_scan, dim3(g.nbins), dim3(256), 0, s, (const uint32_t*)d.seg_base.p, g, (const uint32_t*)d.segcnt.p,
+                       (uint32_t*)d.segoff.p, (uint32_t*)d.hist.p);
     hipLaunchKernelGGL(msmk::k_fine_scatter, dim3(segs_cap), dim3(256), 0, s, (const uint32_t*)d.coarse.p, (const uint32_t*)d.bin_base.p,
-                       (const uint32_t*)d.seg_base.p, g, (const uint32_t*)d.segcnt.p, (uint32_t*)d.sorted.p);
+                       (const uint32_t*)d.seg_base.p, g, (const uint32_t*)d.segcnt.p, (const uint32_t*)d.segoff.p, (uint32_t*)d.sorted.p);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 2], s));
     // ---- schedule: <= 256 blocks of 1024 lanes, each lane owning per_blk/1024 consecutive buckets
     uint32_t per_blk = 4096;

@@ -162,9 +162,9 @@ __global__ void __launch_bounds__(256) k_fine_count(const uint32_t* __restrict__
     if (t < F) segcnt[(size_t)seg * F + t] = cnt[t];
 }
 
-// one workgroup per bin, lane = lo.  segcnt[seg][lo] <- offset of (seg, lo) relative to the bin start.
-__global__ void __launch_bounds__(256) k_fine_scan(const uint32_t* __restrict__ seg_base, SortGeom g, uint32_t* __restrict__ segcnt,
-                                                   uint32_t* __restrict__ hist) {
+// one workgroup per bin, lane = lo.  segoff[seg][lo] <- offset of (seg, lo) relative to the bin start.
+__global__ void __launch_bounds__(256) k_fine_scan(const uint32_t* __restrict__ seg_base, SortGeom g, const uint32_t* __restrict__ segcnt,
+                                                   uint32_t* __restrict__ segoff, uint32_t* __restrict__ hist) {
     __shared__ uint32_t scan[256];
     uint32_t bin = blockIdx.x, t = threadIdx.x;
     uint32_t F = 1u << g.lo_bits;
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256) k_fine_scan(const uint32_t* __restrict__ 
     if (t < F)
         for (uint32_t sg = s0; sg < s1; sg++) {
             uint32_t v = segcnt[(size_t)sg * F + t];
-            segcnt[(size_t)sg * F + t] = tot;   // exclusive over the segments of this (bin, lo)
+            segoff[(size_t)sg * F + t] = tot;   // exclusive over the segments of this (bin, lo); the counts stay in segcnt
             tot += v;
         }
     scan[t] = t < F ? tot : 0;
@@ -187,14 +187,20 @@ __global__ void __launch_bounds__(256) k_fine_scan(const uint32_t* __restrict__ 
     if (t < F) {
         hist[(size_t)bin * F + t] = tot;                 // bucket (window, hi, lo) has index bin * F + lo
         uint32_t lo_base = scan[t] - tot;                // start of fine bucket lo inside the bin
-        for (uint32_t sg = s0; sg < s1; sg++) segcnt[(size_t)sg * F + t] += lo_base;
+        for (uint32_t sg = s0; sg < s1; sg++) segoff[(size_t)sg * F + t] += lo_base;
     }
 }
 
+// LDS-staged: the segment's entries are first counting-sorted by `lo` inside LDS (positions from the segment's own counts),
+// then written out in order, so consecutive lanes store consecutive words of a (segment, lo) run — a bin that fits one segment
+// is written as ONE contiguous range.  (The first version scattered every 4-byte entry straight to its global position through
+// an LDS cursor: 16.8 M single-word stores at 2^20.)
 __global__ void __launch_bounds__(256) k_fine_scatter(const uint32_t* __restrict__ coarse, const uint32_t* __restrict__ bin_base,
                                                       const uint32_t* __restrict__ seg_base, SortGeom g,
-                                                      const uint32_t* __restrict__ segcnt, uint32_t* __restrict__ sorted) {
-    __shared__ uint32_t cur[256];
+                                                      const uint32_t* __restrict__ segcnt, const uint32_t* __restrict__ segoff,
+                                                      uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t stage[FINE_SEG];
+    __shared__ uint32_t lstart[257], cur[256], goff[256];
     __shared__ uint32_t sb[4];
     uint32_t t = threadIdx.x, seg = blockIdx.x;
     if (t == 0) {
@@ -204,15 +210,38 @@ __global__ void __launch_bounds__(256) k_fine_scatter(const uint32_t* __restrict
     }
     __syncthreads();
     if (!sb[2]) return;
-    uint32_t beg = sb[0], end = sb[1], bin_beg = sb[3];
-    uint32_t F = 1u << g.lo_bits, lo_mask = F - 1u;
-    cur[t] = t < F ? bin_beg + segcnt[(size_t)seg * F + t] : 0u;
+    const uint32_t beg = sb[0], end = sb[1], bin_beg = sb[3];
+    const uint32_t F = 1u << g.lo_bits, lo_mask = F - 1u;
+    const uint32_t mine = t < F ? segcnt[(size_t)seg * F + t] : 0u;
+    goff[t] = t < F ? bin_beg + segoff[(size_t)seg * F + t] : 0u;
+    cur[t] = mine;
     __syncthreads();
-    uint32_t sh = g.lo_bits + 1;
+    for (uint32_t d = 1; d < 256; d <<= 1) {   // inclusive scan of the 256 counts
+        uint32_t v = t >= d ? cur[t - d] : 0;
+        __syncthreads();
+        cur[t] += v;
+        __syncthreads();
+    }
+    const uint32_t excl = cur[t] - mine;
+    __syncthreads();
+    lstart[t] = excl;
+    cur[t] = excl;
+    if (t == 255) lstart[256] = excl + mine;
+    __syncthreads();
+    const uint32_t sh = g.lo_bits + 1;
     for (uint32_t i = beg + t; i < end; i += 256) {
         uint32_t e = coarse[i];
         uint32_t pos = atomicAdd(&cur[e & lo_mask], 1u);
-        sorted[pos] = (e >> sh) | (((e >> g.lo_bits) & 1u) << 31);
+        stage[pos] = (e >> sh) | (((e >> g.lo_bits) & 1u) << 31);
+    }
+    __syncthreads();
+    const uint32_t len = end - beg;
+    for (uint32_t j = t; j < len; j += 256) {
+        uint32_t lo = 0;   // largest lo with lstart[lo] <= j (empty buckets share a start: take the last one that begins at or before j and is non-empty)
+#pragma unroll
+        for (uint32_t step = 128; step >= 1; step >>= 1)
+            if (lstart[lo + step] <= j) lo += step;
+        sorted[goff[lo] + (j - lstart[lo])] = stage[j];
     }
 }
 
