@@ -97,7 +97,7 @@ struct DevState {
     Resident* res = nullptr;   // -> mi_ctx::residents[device][2]
     // scratch
     DevBuf raw, call_bases, call_flags, scalars, hist, offsets, woff, meta, sched, sorted, partial, order, item_bucket, pairs, pairs2;
-    DevBuf tilecnt, bin_tot, bin_base, coarse, seg_cnt, seg_base, segcnt, segoff, merge_list;
+    DevBuf tilecnt, tileoff, bin_tot, bin_base, coarse, seg_cnt, seg_base, segcnt, segoff, merge_list;
     DevBuf pr_p, pr_q, pr_lvl[2], pr_raw, pr_lines;   // pairing: inputs, tree levels, top values, line coefficients
     void* h_pairs = nullptr;   // pinned host staging: window sums (D2H) and the schedule's item counts
     size_t h_pairs_cap = 0;
@@ -114,7 +114,7 @@ struct DevState {
     }
     template <class Fn> void for_each_buf(Fn fn) {
         for (DevBuf* b : {&raw, &call_bases, &call_flags, &scalars, &hist, &offsets, &woff, &meta, &sched, &sorted, &partial, &order, &item_bucket,
-                          &pairs, &pairs2, &tilecnt, &bin_tot, &bin_base, &coarse, &seg_cnt, &seg_base, &segcnt, &segoff, &merge_list, &pr_p, &pr_q, &pr_lvl[0],
+                          &pairs, &pairs2, &tilecnt, &tileoff, &bin_tot, &bin_base, &coarse, &seg_cnt, &seg_base, &segcnt, &segoff, &merge_list, &pr_p, &pr_q, &pr_lvl[0],
                           &pr_lvl[1], &pr_raw, &pr_lines})
             fn(*b);
     }

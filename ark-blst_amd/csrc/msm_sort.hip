@@ -85,14 +85,27 @@ namespace {
 // k_coarse is compiled per window size (static digit extraction): dispatch on c = 7..22
 template <bool SCATTER, int CB = 7>
 void launch_coarse(uint32_t c, dim3 grid, dim3 block, hipStream_t s, const uint32_t* scalars, const uint8_t* flags, const msmk::SortGeom& g,
-                   uint32_t* tilecnt, const uint32_t* bin_base, uint32_t* coarse) {
+                   uint32_t* tilecnt, const uint32_t* tileoff, const uint32_t* bin_base, uint32_t* coarse) {
     if constexpr (CB > 22) {
         throw HipFail{"window_bits out of range"};
     } else {
         if (c == CB)
-            hipLaunchKernelGGL((msmk::k_coarse<SCATTER, CB>), grid, block, 0, s, scalars, flags, g, tilecnt, bin_base, coarse);
+            hipLaunchKernelGGL((msmk::k_coarse<SCATTER, CB>), grid, block, 0, s, scalars, flags, g, tilecnt, tileoff, bin_base, coarse);
         else
-            launch_coarse<SCATTER, CB + 1>(c, grid, block, s, scalars, flags, g, tilecnt, bin_base, coarse);
+            launch_coarse<SCATTER, CB + 1>(c, grid, block, s, scalars, flags, g, tilecnt, tileoff, bin_base, coarse);
+    }
+}
+// the LDS-staged scatter exists for the window sizes whose coarse bins allow it (H <= 128: c <= 16)
+template <int CB = 7>
+void launch_coarse_staged(uint32_t c, dim3 grid, hipStream_t s, const uint32_t* scalars, const uint8_t* flags, const msmk::SortGeom& g,
+                          const uint32_t* tilecnt, const uint32_t* tileoff, const uint32_t* bin_base, uint32_t* coarse) {
+    if constexpr (CB > 16) {
+        throw HipFail{"staged coarse scatter: window_bits out of range"};
+    } else {
+        if (c == CB)
+            hipLaunchKernelGGL((msmk::k_coarse_staged<CB>), grid, dim3(512), 0, s, scalars, flags, g, tilecnt, tileoff, bin_base, coarse);
+        else
+            launch_coarse_staged<CB + 1>(c, grid, s, scalars, flags, g, tilecnt, tileoff, bin_base, coarse);
     }
 }
 
@@ -119,24 +132,39 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
     g.H = pl.nb >> g.lo_bits;
     // A tile contributes tile_pts / H entries to each coarse bin of a window, written as one contiguous run: keep
     // runs >= 64 entries (256 B) or the 4-byte scatter is write-amplified (9.5 ms at n = 2^24 with 16-entry runs).
-    size_t want = std::max<size_t>(std::max<size_t>(4096, n / 512), (size_t)64 * g.H / (shared_buckets ? pl.nwin : 1));
-    g.tile_pts = (uint32_t)((std::min(want, n) + 1023) / 1024 * 1024);
+    // With few coarse bins per window (H <= 128, i.e. c <= 16) the scatter is staged through LDS instead: a workgroup takes
+    // as many windows as keep wgroup * H <= 512 bins and as many points as keep its entries within 64 KB of LDS.
+    const bool staged = !shared_buckets && g.H <= 128 && pl.c <= 16 && n >= 4096;
+    uint32_t coarse_block;
+    if (staged) {
+        g.wgroup = std::min<uint32_t>(std::min<uint32_t>(pl.nwin, 16), msmk::COARSE_STAGE_BINS / g.H);
+        g.tile_pts = (msmk::COARSE_STAGE / g.wgroup) / 512 * 512;   // >= 1024 points; tile_pts * wgroup entries fit the staging buffer
+        coarse_block = 512;
+    } else {
+        size_t want = std::max<size_t>(std::max<size_t>(4096, n / 512), (size_t)64 * g.H / (shared_buckets ? pl.nwin : 1));
+        g.tile_pts = (uint32_t)((std::min(want, n) + 1023) / 1024 * 1024);
+        coarse_block = g.tile_pts >= 16384 ? 1024 : 256;
+        g.wgroup = shared_buckets ? pl.nwin : std::max<uint32_t>(1, std::min<uint32_t>(pl.nwin, msmk::SORT_MAX_COUNTERS / g.H));
+    }
     g.tiles = (uint32_t)((n + g.tile_pts - 1) / g.tile_pts);
-    const uint32_t coarse_block = g.tile_pts >= 16384 ? 1024 : 256;
-    g.wgroup = shared_buckets ? pl.nwin : std::max<uint32_t>(1, std::min<uint32_t>(pl.nwin, msmk::SORT_MAX_COUNTERS / g.H));
     g.ngroups = (pl.nwin + g.wgroup - 1) / g.wgroup;
     g.nbins = pl.bwin * g.H;
     d.tilecnt.ensure((size_t)g.tiles * g.nbins * 4);
+    d.tileoff.ensure((size_t)g.tiles * g.nbins * 4);
     d.bin_tot.ensure((size_t)g.nbins * 4);
     d.bin_base.ensure((size_t)(g.nbins + 1) * 4);
     d.coarse.ensure(entries_cap * 4);
     launch_coarse<false>(pl.c, dim3(g.tiles, g.ngroups), dim3(coarse_block), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
-                         (const uint32_t*)nullptr, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(msmk::k_colscan, dim3((g.nbins + 255) / 256), dim3(256), 0, s, (uint32_t*)d.tilecnt.p, g.nbins, g.tiles,
-                       (uint32_t*)d.bin_tot.p);
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(msmk::k_colscan, dim3((g.nbins + 255) / 256), dim3(256), 0, s, (const uint32_t*)d.tilecnt.p, g.nbins, g.tiles,
+                       (uint32_t*)d.tileoff.p, (uint32_t*)d.bin_tot.p);
     hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.bin_tot.p, g.nbins, (uint32_t*)d.bin_base.p);
-    launch_coarse<true>(pl.c, dim3(g.tiles, g.ngroups), dim3(coarse_block), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
-                        (const uint32_t*)d.bin_base.p, (uint32_t*)d.coarse.p);
+    if (staged)
+        launch_coarse_staged(pl.c, dim3(g.tiles, g.ngroups), s, d_scalars, d_flags, g, (const uint32_t*)d.tilecnt.p, (const uint32_t*)d.tileoff.p,
+                             (const uint32_t*)d.bin_base.p, (uint32_t*)d.coarse.p);
+    else
+        launch_coarse<true>(pl.c, dim3(g.tiles, g.ngroups), dim3(coarse_block), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
+                            (const uint32_t*)d.tileoff.p, (const uint32_t*)d.bin_base.p, (uint32_t*)d.coarse.p);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 1], s));
     // fine sort over bin segments (upper bound on the segment count: one per bin plus one per FINE_SEG entries)
     uint32_t segs_cap = g.nbins + (uint32_t)(entries_cap / msmk::FINE_SEG) + 1;

@@ -30,8 +30,8 @@ constexpr uint32_t SORT_MAX_COUNTERS = 16384;  // 64 KB of LDS counters per work
 // entry in `coarse`: (point index << (lo_bits+1)) | (negative << lo_bits) | lo
 template <bool SCATTER, int CB>
 __global__ void __launch_bounds__(1024) k_coarse(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flags, SortGeom g,
-                                                 uint32_t* __restrict__ tilecnt, const uint32_t* __restrict__ bin_base,
-                                                 uint32_t* __restrict__ coarse) {
+                                                 uint32_t* __restrict__ tilecnt, const uint32_t* __restrict__ tileoff,
+                                                 const uint32_t* __restrict__ bin_base, uint32_t* __restrict__ coarse) {
     __shared__ uint32_t cnt[SORT_MAX_COUNTERS];
     const uint32_t tile = blockIdx.x, grp = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
     uint32_t w0 = grp * g.wgroup, w1 = w0 + g.wgroup < g.nwin ? w0 + g.wgroup : g.nwin;
@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(1024) k_coarse(const uint32_t* __restrict__ sc
     for (uint32_t k = t; k < ncnt; k += nt) {
         if (SCATTER) {
             uint32_t bin = bin0 + k;
-            cnt[k] = bin_base[bin] + tilecnt[(size_t)tile * g.nbins + bin];  // where this tile's run of the bin starts
+            cnt[k] = bin_base[bin] + tileoff[(size_t)tile * g.nbins + bin];  // where this tile's run of the bin starts
         } else {
             cnt[k] = 0;
         }
@@ -65,15 +65,80 @@ __global__ void __launch_bounds__(1024) k_coarse(const uint32_t* __restrict__ sc
     }
 }
 
-// per bin: exclusive scan over the tiles (in place) and the bin total.  One lane per bin: coalesced across bins.
-__global__ void __launch_bounds__(256) k_colscan(uint32_t* __restrict__ tilecnt, uint32_t nbins, uint32_t tiles,
-                                                 uint32_t* __restrict__ bin_tot) {
+// LDS-staged form of the coarse scatter for H <= 128 coarse bins per window (c <= 16): a workgroup takes a tile of points and a
+// group of windows small enough that ALL its entries fit in LDS (<= 16384 entries, 64 KB), counting-sorts them by bin there
+// (positions from the tile's own counts) and writes them out in order: every (tile, bin) run — >= 32 entries — leaves as
+// consecutive words instead of one 4-byte store per entry through an LDS cursor.
+constexpr uint32_t COARSE_STAGE = 16384;
+constexpr uint32_t COARSE_STAGE_BINS = 512;
+template <int CB>
+__global__ void __launch_bounds__(512) k_coarse_staged(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flags, SortGeom g,
+                                                       const uint32_t* __restrict__ tilecnt, const uint32_t* __restrict__ tileoff,
+                                                       const uint32_t* __restrict__ bin_base, uint32_t* __restrict__ coarse) {
+    __shared__ uint32_t stage[COARSE_STAGE];
+    __shared__ uint32_t lstart[COARSE_STAGE_BINS + 1], cur[COARSE_STAGE_BINS], goff[COARSE_STAGE_BINS];
+    const uint32_t tile = blockIdx.x, grp = blockIdx.y, t = threadIdx.x, nt = 512;
+    const uint32_t w0 = grp * g.wgroup, w1 = w0 + g.wgroup < g.nwin ? w0 + g.wgroup : g.nwin;
+    const uint32_t bin0 = w0 * g.H, ncnt = (w1 - w0) * g.H;   // ncnt <= COARSE_STAGE_BINS
+    const uint32_t mine = t < ncnt ? tilecnt[(size_t)tile * g.nbins + bin0 + t] : 0u;
+    goff[t] = t < ncnt ? bin_base[bin0 + t] + tileoff[(size_t)tile * g.nbins + bin0 + t] : 0u;
+    cur[t] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < COARSE_STAGE_BINS; d <<= 1) {   // inclusive scan of the counts
+        uint32_t v = t >= d ? cur[t - d] : 0;
+        __syncthreads();
+        cur[t] += v;
+        __syncthreads();
+    }
+    const uint32_t excl = cur[t] - mine;
+    __syncthreads();
+    lstart[t] = excl;
+    cur[t] = excl;
+    if (t == COARSE_STAGE_BINS - 1) lstart[COARSE_STAGE_BINS] = excl + mine;
+    __syncthreads();
+    const uint32_t total = lstart[COARSE_STAGE_BINS];
+    const uint32_t lo_mask = (1u << g.lo_bits) - 1u;
+    const uint32_t p0 = tile * g.tile_pts, p1 = p0 + g.tile_pts < g.n ? p0 + g.tile_pts : g.n;
+    for (uint32_t i = p0 + t; i < p1; i += nt) {
+        if (inf_flags[i] != 0) continue;
+        uint32_t s[8];
+        load_scalar(s, scalars, i, g.fmt);
+        for_each_digit_static<CB>(s, w0, w1, [&](uint32_t w, uint32_t b, bool neg) {
+            uint32_t k = (w - w0) * g.H + (b >> g.lo_bits);
+            uint32_t pos = atomicAdd(&cur[k], 1u);
+            stage[pos] = (i << (g.lo_bits + 1)) | ((neg ? 1u : 0u) << g.lo_bits) | (b & lo_mask);
+        });
+    }
+    __syncthreads();
+    for (uint32_t j = t; j < total; j += nt) {
+        uint32_t k = 0;   // the bin whose run holds position j
+#pragma unroll
+        for (uint32_t step = COARSE_STAGE_BINS / 2; step >= 1; step >>= 1)
+            if (lstart[k + step] <= j) k += step;
+        coarse[goff[k] + (j - lstart[k])] = stage[j];
+    }
+}
+
+// per bin: exclusive scan over the tiles (tilecnt keeps the counts, tileoff gets the offsets) and the bin total.  One lane per
+// bin: coalesced across bins; eight tiles' loads in flight per lane.
+__global__ void __launch_bounds__(256) k_colscan(const uint32_t* __restrict__ tilecnt, uint32_t nbins, uint32_t tiles,
+                                                 uint32_t* __restrict__ tileoff, uint32_t* __restrict__ bin_tot) {
     uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nbins) return;
-    uint32_t run = 0;
-    for (uint32_t k = 0; k < tiles; k++) {
+    uint32_t run = 0, k = 0;
+    for (; k + 8 <= tiles; k += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = tilecnt[(size_t)(k + u) * nbins + b];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            tileoff[(size_t)(k + u) * nbins + b] = run;
+            run += v[u];
+        }
+    }
+    for (; k < tiles; k++) {
         uint32_t v = tilecnt[(size_t)k * nbins + b];
-        tilecnt[(size_t)k * nbins + b] = run;
+        tileoff[(size_t)k * nbins + b] = run;
         run += v;
     }
     bin_tot[b] = run;
