@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time-boxed randomized parity soak on one MI355X: MSM (G1/G2) and multi-pairing through the C ABI against the C
-oracles, over random sizes, window sizes, scalar formats/distributions, repeated / opposite / infinity bases.
+oracles, over random sizes, window sizes (7..22), scalar formats/distributions, repeated / opposite / infinity bases, resident
+plain and precomputed-table base sets, and (single-threaded runs, through the test build's hook) calls split into several passes.
 Prints a progress line every ~20 s and a final JSON summary; exits non-zero on the first mismatch.
     python tools/soak.py [seconds=300] [seed=1] [threads=1]
 With threads > 1 the same loop runs from several host threads on ONE context (two lanes + exclusive entry points); the batch
@@ -38,7 +39,32 @@ def loop(ctx, rnd, tid):
     global last
     while time.time() - t0 < budget and not failed:
         r = rnd.random()
-        if r < 0.04 and nthreads == 1:   # batch entry point over a resident base set (two MSMs in flight on the context's lanes)
+        if r < 0.03 and nthreads == 1:   # precomputed 2^(c j) P tables: resident set, several calls over prefixes of it
+            g = rnd.choice(["g1", "g1", "g2"])
+            aff, lim = AFF[g], POOL[g] // 3
+            n = rnd.randrange(1, lim)
+            start = rnd.randrange(0, POOL[g] - n + 1)
+            bases = bytearray(pools[g][aff * start:aff * (start + n)])
+            for k in range(min(n, 8)):
+                if rnd.random() < 0.5: bases[aff * rnd.randrange(n):][:aff] = bytes(aff)
+            j = rnd.randrange(n)
+            bases[aff * j:aff * (j + 1)] = bytes(aff)
+            bases = bytes(bases)
+            ctx.set_bases_precomputed(g, bases, n, rnd.choice([0, 0, 8, 9, 11, 13, 14, 16]))
+            for _ in range(rnd.randrange(1, 4)):
+                m = rnd.choice([n, n, rnd.randrange(1, n + 1)])
+                kind = rnd.choice(["uniform", "bits", "small", "edge"])
+                if kind == "uniform": sc = [rnd.randrange(o.R_ORDER) for _ in range(m)]
+                elif kind == "bits": sc = [rnd.randrange(2) for _ in range(m)]
+                elif kind == "small": sc = [rnd.randrange(1 << rnd.choice([8, 40, 128])) for _ in range(m)]
+                else: sc = [rnd.choice([0, 1, 2, o.R_ORDER - 1, o.R_ORDER - 2, 1 << 254]) for _ in range(m)]
+                canon = b"".join(o.fr_to_canon_bytes(x) for x in sc)
+                got = ctx.msm(g, None, canon, m, pkg.SCALAR_CANONICAL)
+                if co.to_affine(g, got) != co.to_affine(g, co.msm(g, bases, canon, m, 0, ncpu)):
+                    print("PRECOMPUTED MISMATCH", seed, g, n, m, kind); failed.append(1); return
+                stats["precomputed"] = stats.get("precomputed", 0) + 1; stats["points"] += m
+            ctx.set_bases(g, bases[:aff], 1)   # drop the tables
+        elif r < 0.06 and nthreads == 1:   # batch entry point over a resident base set (two MSMs in flight on the context's lanes)
             g = rnd.choice(["g1", "g1", "g2"])
             aff, lim = AFF[g], POOL[g]
             n = rnd.randrange(1, lim)
@@ -91,14 +117,17 @@ def loop(ctx, rnd, tid):
             canon = b"".join(o.fr_to_canon_bytes(x) for x in sc)
             fmt = rnd.choice([pkg.SCALAR_CANONICAL, pkg.SCALAR_MONTGOMERY])
             data = canon if fmt == pkg.SCALAR_CANONICAL else co.fr_to_mont(canon)
-            c = rnd.choice([0, 0, 0, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]) if nthreads == 1 else 0   # the setting is per context
+            c = rnd.choice([0, 0, 0, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, rnd.randrange(17, 23)]) if nthreads == 1 else 0   # the setting is per context
+            part = rnd.choice([0] * 9 + [rnd.randrange(200, 5000)]) if nthreads == 1 else 0   # passes per call (test hook)
             if nthreads == 1:
                 ctx.set_window_bits(c)
+                ctx.test_set_max_part(part)
             try:
                 got = ctx.msm(g, bytes(bases), data, n, fmt)
             finally:
                 if nthreads == 1:
                     ctx.set_window_bits(0)
+                    ctx.test_set_max_part(0)
             want = co.msm(g, bytes(bases), canon, n, 0, ncpu)
             if co.to_affine(g, got) != co.to_affine(g, want):
                 print("MSM MISMATCH", seed, g, n, kind, c, fmt); failed.append(1); return
@@ -108,7 +137,7 @@ def loop(ctx, rnd, tid):
             print("soak", round(last - t0), "s", stats, flush=True)
 
 
-with pkg.Context([0]) as ctx:
+with pkg.Context([0], test_hooks=True) as ctx:   # the test build: the same sources plus the mi_test_* hooks
     ths = [threading.Thread(target=loop, args=(ctx, random.Random(seed * 1000 + t), t)) for t in range(nthreads)]
     for t in ths: t.start()
     for t in ths: t.join()
