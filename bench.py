@@ -79,7 +79,7 @@ def _traffic(g: str, log_n, precomputed: bool):
     """HBM bytes per launch of the accumulate kernel: measured with rocprofv3 PMC passes (tools/profile_bench.sh) on this
     exact workload and committed under profiles/ (bench.py cannot collect counters itself); None when no summary matches."""
     try:
-        key = f"msmk::k_accumulate<msmk::{g.upper()}C>"
+        key = "msmk::k_accumulate<msmk::G1C>" if g == "g1" else "msmk::k_accumulate_g2_coop<msmk::G2C>"
         files = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json")), reverse=True)
         for f in files:
             pj = json.load(open(os.path.join(ROOT, "profiles", f)))
@@ -125,7 +125,7 @@ def _rooflines(g: str, n: int, log_n, acc_ms: float, nwin: int, precomputed: boo
     mads = nwin * FP_MULS_PER_ADD[g] * MADS_PER_FP_MUL       # window-aware: one mixed addition per point and window
     tmad = mads * n / (acc_ms * 1e-3) / 1e12
     return {
-        "roofline": {"bound": "hbm", "kernel": f"k_accumulate<{g.upper()}C>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "k_accumulate<G1C>" if g == "g1" else "k_accumulate_g2_coop<G2C>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": alg_bytes,
                      "kernel_ms": acc_ms,
                      "note": "the bucket method re-reads each device point once per window: traffic ~ windows x algorithmic by "
