@@ -257,26 +257,32 @@ struct QuadG1 {
         for (int k = 0; k < NL; k++) r.c.l[k] = __shfl(a.c.l[k], 4 * src + (int)q(), 64);
         return r;
     }
-    // a <- a + b, complete (RCB16 Alg. 7, the formulas of ec::proj_add; the same values, hence the same bounds)
+    // a <- a + b, complete (RCB16 Alg. 7, the formulas of ec::proj_add; the same values, hence the same value bounds).
+    // Linear operations are lazy where the limb sizes allow (coordinates come in with exact limbs < 2^28, every multiplier
+    // output is exact): a carry pass costs 42 instructions and the first version spent ten of them per addition, four remain.
+    // Limb sizes (column sums of the 64-bit accumulators must stay below 2^63): sums of two exact values < 2^29; 3x < 2^29.6;
+    // a - b + 32p with b in N-form < 2^29.6; 16p - b < 2^29; N-form <= 2^28 + 64.  Largest accumulation: t1m t3 + t5 (16p - t4)
+    // = 14 (2^57.6 + 2^57) + 2^59.8 < 2^62.2.
     static __device__ __forceinline__ void add(Pt& a, const Pt& b) {
         using namespace fp28;
         const bool is2 = q() >= 2, is0 = q() == 0;
         Fp an = dpp<NEXT>(a.c), bn = dpp<NEXT>(b.c);
-        Fp own = fp_mul(a.c, b.c);                                        // t0 | t1 | t2
-        Fp cross = fp_mul(fp_add(a.c, an), fp_add(b.c, bn));              // t3 | t4 | t5
-        cross = fp_sub<8>(cross, fp_add(own, dpp<NEXT>(own)));            // X1Y2+X2Y1 | Y1Z2+Y2Z1 | X1Z2+X2Z1
-        Fp t0 = fp_mul_small<3>(dpp<B0>(own));                            // 3 X1X2
+        Fp own = fp_mul(a.c, b.c);                                                       // t0 | t1 | t2                          exact
+        Fp cross = fp_mul(fp_add_lazy(a.c, an), fp_add_lazy(b.c, bn));                   // t3 | t4 | t5    (2^29 x 2^29 limbs)   exact
+        cross = fp_norm(fp_sub8_lazy_wide(cross, fp_add_lazy(own, dpp<NEXT>(own))));     // X1Y2+X2Y1 | Y1Z2+Y2Z1 | X1Z2+X2Z1     N-form, < 10p
+        Fp t0 = dpp<B0>(own);
+        t0 = fp_add_lazy(fp_add_lazy(t0, t0), t0);                                       // 3 X1X2                                < 2^29.6, < 6p
         Fp t1 = dpp<B1>(own);
-        Fp t2 = fp_mul_small<12>(dpp<B2>(own));                           // b3 Z1Z2
-        Fp u = fp_add(t1, t2);
-        Fp t1m = fp_sub<32>(t1, t2);
+        Fp t2 = fp_mul_small<12>(dpp<B2>(own));                                          // b3 Z1Z2                               N-form, < 24p
+        Fp u = fp_add(t1, t2);                                                           // Y1Y2 + b3 Z1Z2                        N-form
+        Fp t1m = fp_sub_lazy<32>(t1, t2);                                                // Y1Y2 - b3 Z1Z2                        < 2^29.6, < 34p
         Fp t3 = dpp<B0>(cross), t4 = dpp<B1>(cross);
-        Fp t5 = fp_mul_small<12>(dpp<B2>(cross));
+        Fp t5 = fp_mul_small<12>(dpp<B2>(cross));                                        // b3 (X1Z2 + X2Z1)                      N-form
         // X3 = t1m t3 - t5 t4 ; Y3 = t1m u + t5 t0 ; Z3 = u t4 + t0 t3
         Fp A1 = fp_select(is2, t1m, u);
         Fp B1v = fp_select(is0, fp_select(is2, u, t4), t3);
         Fp A2 = fp_select(is2, t5, t0);
-        Fp B2v = fp_select(is0, fp_select(is2, t0, t3), fp_neg<16>(t4));
+        Fp B2v = fp_select(is0, fp_select(is2, t0, t3), fp_sub_lazy<16>(fp_zero(), t4));
         a.c = fp_mul2add(A1, B1v, A2, B2v);
     }
     // logical lane's point -> Jacobian in the reference's form (X Z, Y Z^2, Z); infinity (Z == 0 mod p) -> all-zero
