@@ -39,6 +39,8 @@ for k, v in out.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         v["hbm_bytes_per_launch_corrected"] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
         v["hbm_bytes_per_launch_raw"] = (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
+        # the largest launch of the run (runs that also launch the kernel on small warm-up / sample inputs: the pairing bench)
+        v["hbm_bytes_largest_launch_corrected"] = (2.0 * v["FETCH_SIZE_max"] + v["WRITE_SIZE_max"]) * 1024.0
     if "GRBM_GUI_ACTIVE" in v:
         v["gpu_cycles_per_launch"] = v["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
 json.dump({"source": f"rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*, one pass each) of `python3 {cmd}` "
