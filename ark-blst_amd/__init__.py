@@ -15,6 +15,7 @@ from .binding import (  # noqa: F401
     SCALAR_CANONICAL,
     SCALAR_MONTGOMERY,
     final_exponentiation,
+    test_plan,
     g1_sum,
     g2_sum,
     lib_path,

@@ -70,6 +70,7 @@ def load_library(test_hooks: bool = False):
             L.mi_test_set_max_part.argtypes = [vp, sz]
             L.mi_test_fail_allocs.argtypes = [i]
             L.mi_test_fail_allocs.restype = None
+            L.mi_test_plan.argtypes = [sz, u, i, i, sz, C.POINTER(C.c_uint32)]
         _LIBS[test_hooks] = L
     return _LIBS[test_hooks]
 
@@ -229,6 +230,19 @@ class Context:
 
     def test_fail_allocs(self, count: int):
         self._L.mi_test_fail_allocs(count)
+
+
+def test_plan(n: int, forced_c: int = 0, group: str = "g1", shared: bool = False, stride: int = 0) -> dict:
+    """The window-size plan of an n-point call (test build; host only, needs no device)."""
+    out = (C.c_uint32 * 12)()
+    rc = load_library(True).mi_test_plan(n, forced_c, 0 if group == "g1" else 1, int(shared), stride, out)
+    if rc != 0:
+        raise MsmError(rc, "mi_test_plan")
+    keys = ("c", "nwin", "bwin", "logL", "chunk_log", "logT", "lo_bits", "serial", "chunks_per_win")
+    d = {k: int(out[i]) for i, k in enumerate(keys)}
+    d["nbuckets"] = (int(out[9]) << 32) | int(out[10])
+    d["nchunks"] = int(out[11])
+    return d
 
 
 def final_exponentiation(f: bytes) -> bytes:

@@ -12,4 +12,6 @@ int g1_msm_batch(mi_ctx* ctx, const uint8_t* const* scalars, size_t k, size_t n,
 }
 int g1_normalize(mi_ctx* ctx, const mi_g1* in, size_t n, mi_g1_affine* out) { return normalize_impl<msmk::G1C>(ctx, in, n, out); }
 
+CurveCost g1_cost() { return HostCurve<msmk::G1C>::cost(); }
+
 }  // namespace mi

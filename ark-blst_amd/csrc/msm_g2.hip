@@ -12,4 +12,6 @@ int g2_msm_batch(mi_ctx* ctx, const uint8_t* const* scalars, size_t k, size_t n,
 }
 int g2_normalize(mi_ctx* ctx, const mi_g2* in, size_t n, mi_g2_affine* out) { return normalize_impl<msmk::G2C>(ctx, in, n, out); }
 
+CurveCost g2_cost() { return HostCurve<msmk::G2C>::cost(); }
+
 }  // namespace mi

@@ -35,7 +35,7 @@ def test_product_library_has_no_test_hooks(pkg):
     prod = {s for s in _exported(pkg.lib_path()) if s.startswith("mi_")}
     assert prod == set(_declared_symbols()), prod ^ set(_declared_symbols())
     test = {s for s in _exported(pkg.lib_path(True)) if s.startswith("mi_")}
-    assert test - prod == {"mi_test_fp_op", "mi_test_set_pairing", "mi_test_set_max_part", "mi_test_fail_allocs"}
+    assert test - prod == {"mi_test_fp_op", "mi_test_set_pairing", "mi_test_set_max_part", "mi_test_fail_allocs", "mi_test_plan"}
 
 
 def test_layout_sizes_match_reference_types(pkg):
@@ -88,3 +88,44 @@ def test_reference_style_length_mismatch_error(pkg):
     with pytest.raises(pkg.msm.MsmErr) as e:
         pkg.G1Projective.msm(bytes(96 * 3), bytes(32 * 2))
     assert e.value.value == 2
+
+
+def test_plan_geometry_invariants(pkg):
+    """The window-size plan (make_plan: the role of calc_window_size / calc_chunk_size, /root/reference/src/gpu.rs:64-92,218-223) over
+    sizes from 1 point to the 2^26 per-pass limit, free and forced window sizes, both groups, plain and shared bucket sets: the
+    geometry every kernel launch relies on (32-bit entry offsets, index + sign + fine bits in one word, coarse bins within the
+    LDS counter array, power-of-two chunks inside a window, staged-sort limits)."""
+    import random
+
+    rnd = random.Random(5)
+    sizes = [1, 2, 63, 64, 65, 1000, 4095, 4096, 4097] + [1 << k for k in range(10, 27)] + [(1 << k) - 12345 for k in (20, 21, 24, 26)] + \
+            [rnd.randrange(1, 1 << 26) for _ in range(40)]
+    for group in ("g1", "g2"):
+        for n in sizes:
+            for shared in (False, True):
+                for c in [0] + list(range(7, 23)):
+                    stride = n if shared else 0
+                    p = pkg.test_plan(n, c, group, shared, stride)
+                    if p["c"] == 0:
+                        assert c != 0 or shared, (group, n, "the free plan must exist for every size")   # a forced c may not fit the geometry
+                        continue
+                    cc = p["c"]
+                    assert 7 <= cc <= 22 and (c == 0 or cc == c)
+                    assert p["nwin"] == (256 + cc - 1) // cc and p["bwin"] == (1 if shared else p["nwin"])
+                    assert n * p["nwin"] < 1 << 32                                            # entry offsets are 32-bit
+                    nb = 1 << (cc - 1)
+                    assert p["nbuckets"] == nb * p["bwin"]
+                    idx_bits = max(1, ((max(stride, n) * p["nwin"]) if shared else n) - 1).bit_length()
+                    assert idx_bits + 1 + p["lo_bits"] <= 32 and p["lo_bits"] <= min(8, cc - 1)   # index | sign | fine bits in one word
+                    assert (nb >> p["lo_bits"]) <= 16384                                      # coarse bins of a window fit the LDS counters
+                    assert p["chunk_log"] <= cc - 1 and p["chunks_per_win"] == nb >> p["chunk_log"]
+                    assert p["nchunks"] == p["chunks_per_win"] * p["bwin"]
+                    assert 5 <= p["logT"] <= 20
+                    if p["serial"]:
+                        assert group == "g1" and p["chunk_log"] == 6 and p["nbuckets"] >= 1 << 21
+                    else:
+                        assert p["chunk_log"] == p["logL"] + (4 if group == "g1" else 5) and p["logL"] <= 6
+    # the sizes the benchmark configs use keep their measured choices
+    assert pkg.test_plan(1 << 20)["c"] == 16 and pkg.test_plan(1 << 21)["c"] == 16 and pkg.test_plan(1 << 23)["c"] == 16
+    assert pkg.test_plan(1 << 24)["c"] == 20 and pkg.test_plan(1 << 24)["serial"] == 1
+    assert pkg.test_plan(1 << 20, 0, "g2")["c"] == 16

@@ -681,6 +681,12 @@ def test_calls_longer_than_one_pass_are_split(pkg, co, group):
         c3.set_bases(group, bases, n)
         assert _canon(co, group, c3.msm(group, None, scalars, n, pkg.SCALAR_CANONICAL)) == want
         assert _canon(co, group, c3.msm(group, bases, scalars, n, pkg.SCALAR_CANONICAL)) == want
+        c3.set_bases_precomputed(group, bases, n, 0)     # every slot builds the tables of its own shard
+        assert _canon(co, group, c3.msm(group, None, scalars, n, pkg.SCALAR_CANONICAL)) == want
+        m = 3000                                         # a prefix that ends inside the last slot's shard
+        assert _canon(co, group, c3.msm(group, None, scalars[:32 * m], m, pkg.SCALAR_CANONICAL)) == co.dlog_expected(group, scalars[:32 * m], SEED_B + 230, m)
+        got = c3.msm_batch(group, [scalars, scalars], n, pkg.SCALAR_CANONICAL)
+        assert [_canon(co, group, x) for x in got] == [want, want]
 
 
 def test_allocation_failure_is_an_error_code_not_an_abort(pkg, co):
