@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 from oracle import coracle as co
 pkg = ge.load_package()

@@ -1,24 +1,35 @@
 #!/bin/bash
 # One GPU-box call that reproduces every number quoted in DESIGN.md section 8 (takes ~4 minutes):
 #   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/repro_all.sh'
+# The default bench line carries every single-GPU BASELINE config (secondary.g1_2p24, g2_2p20, pairing_2p16, precomputed tables,
+# in-process multi-device); the size sweep and the row (f) timings follow.
 set -e
 mkdir -p gpurun_out/repro
 python -m pytest tests -m gpu -x -q 2>&1 | tail -1
 python -c "import __graft_entry__ as g; g.smoke()"
-python bench.py > gpurun_out/repro/g1_2p20.json
-python bench.py --group g2 --no-secondary > gpurun_out/repro/g2_2p20.json
-python bench.py --log-n 16 --no-secondary > gpurun_out/repro/g1_2p16.json
-python bench.py --log-n 24 --steps 3 --warmup 1 --no-secondary > gpurun_out/repro/g1_2p24.json
-python tools/bench_pairing.py 16 5 > gpurun_out/repro/pairing_2p16.json
+python bench.py > gpurun_out/repro/bench_default.json
+python tools/sweep_sizes.py g1 14 24 > gpurun_out/repro/sweep_g1.jsonl 2>/dev/null
+python tools/sweep_sizes.py g2 14 21 > gpurun_out/repro/sweep_g2.jsonl 2>/dev/null
 python tools/bench_normalize.py > gpurun_out/repro/normalize.txt 2>&1 || true
 python tools/bench_deserialize.py 20 > gpurun_out/repro/deserialize.txt 2>&1 || true
 python - <<'PY'
 import json
-for f in ("g1_2p16", "g1_2p20", "g1_2p24", "g2_2p20"):
-    d = json.loads(open(f"gpurun_out/repro/{f}.json").read().strip().splitlines()[-1])
-    print(f, "%.3g points/s" % d["value"], "%.2f ms" % d["ms_per_step"], "bit_exact", d["bit_exact"], "c", d["config"]["window_bits"],
-          "cpu_baseline %.3g" % d["cpu_baseline"]["value"] if "cpu_baseline" in d else "")
-d = json.loads(open("gpurun_out/repro/pairing_2p16.json").read().strip().splitlines()[-1])
-print("pairing_2p16", "%.3g pairs/s" % d["value"], "%.2f ms" % d["ms"], "exact", d["bit_exact_1024_pairs_vs_c_oracle"], "cpu_baseline %.3g" % d["cpu_baseline"]["value"])
+d = json.loads([l for l in open("gpurun_out/repro/bench_default.json") if l.startswith("{")][-1])
+print("g1_2p20", "%.3g points/s" % d["value"], "%.2f ms" % d["ms_per_step"], "bit_exact", d["bit_exact"], "valu frac %.2f" % d["valu_roofline"]["frac"],
+      "cpu_baseline %.3g" % d["cpu_baseline"]["value"])
+for k, v in d["secondary"].items():
+    if "error" in v:
+        print(k, v["error"]); continue
+    if "ms_per_step" in v and "value" in v:
+        print(k, "%.3g %s" % (v["value"], v.get("unit", "")), "%.2f ms" % v["ms_per_step"], "bit_exact", v.get("bit_exact", v.get("same_result")))
+    elif k == "pairing_2p16":
+        print(k, "%.3g pairs/s" % v["value"], "%.2f ms" % v["ms"], "cancels", v["product_cancels_to_one"], "exact", v["bit_exact_256_pairs_vs_c_oracle"],
+              "cpu_baseline %.3g" % v["cpu_baseline"]["value"])
+    else:
+        print(k, {a: b for a, b in v.items() if not isinstance(b, (dict, str))})
+for f in ("sweep_g1", "sweep_g2"):
+    for l in open(f"gpurun_out/repro/{f}.jsonl"):
+        r = json.loads(l)
+        print(r["group"], "2^%d" % r["log_n"], "c", r["c"], "%.3f ms" % r["ms"], "%.3g points/s" % r["points_per_s"], "ok", r["ok"])
 PY
 tail -2 gpurun_out/repro/normalize.txt; tail -3 gpurun_out/repro/deserialize.txt
