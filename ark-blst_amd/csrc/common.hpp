@@ -52,6 +52,7 @@ struct Plan {
     uint32_t c, nwin;     // window bits, digit windows = ceil(256 / c)
     uint32_t bwin;        // bucket sets: nwin, or 1 when all windows share one (precomputed tables)
     uint32_t nb, logL, chunks_per_win, logT, lo_bits;
+    uint32_t cls_shift;   // log2 of the width of a length class of the schedule (follows the typical item, not T)
     uint64_t nbuckets, nchunks;
     uint32_t chunk_log;   // log2 of the buckets one reduce wave (or, serial form, one reduce lane) covers
     bool serial_reduce;   // throughput form: one lane per 64 buckets (k_reduce_serial)
@@ -97,7 +98,7 @@ struct DevState {
     Resident* res = nullptr;   // -> mi_ctx::residents[device][2]
     // scratch
     DevBuf raw, call_bases, call_flags, scalars, hist, offsets, woff, meta, sched, sorted, partial, order, item_bucket, pairs, pairs2;
-    DevBuf tilecnt, tileoff, bin_tot, bin_base, coarse, seg_cnt, seg_base, segcnt, segoff, merge_list;
+    DevBuf tilecnt, tileoff, bin_tot, bin_base, binA_base, coarse, coarseA, seg_cnt, seg_base, segcnt, segoff, merge_list;
     DevBuf pr_p, pr_q, pr_lvl[2], pr_raw, pr_lines;   // pairing: inputs, tree levels, top values, line coefficients
     void* h_pairs = nullptr;   // pinned host staging: window sums (D2H) and the schedule's item counts
     size_t h_pairs_cap = 0;
@@ -114,7 +115,7 @@ struct DevState {
     }
     template <class Fn> void for_each_buf(Fn fn) {
         for (DevBuf* b : {&raw, &call_bases, &call_flags, &scalars, &hist, &offsets, &woff, &meta, &sched, &sorted, &partial, &order, &item_bucket,
-                          &pairs, &pairs2, &tilecnt, &tileoff, &bin_tot, &bin_base, &coarse, &seg_cnt, &seg_base, &segcnt, &segoff, &merge_list, &pr_p, &pr_q, &pr_lvl[0],
+                          &pairs, &pairs2, &tilecnt, &tileoff, &bin_tot, &bin_base, &binA_base, &coarse, &coarseA, &seg_cnt, &seg_base, &segcnt, &segoff, &merge_list, &pr_p, &pr_q, &pr_lvl[0],
                           &pr_lvl[1], &pr_raw, &pr_lines})
             fn(*b);
     }

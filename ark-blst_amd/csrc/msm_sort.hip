@@ -55,6 +55,11 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         const double typical = per_bucket > mean && per_bucket <= 4.0 * mean ? per_bucket : mean;
         p.logT = 5;
         while ((double)(1u << p.logT) < 2.0 * typical && p.logT < 20) p.logT++;
+        // ... and an item may be as long as a lane walks in a fifth of the kernel's time anyway: at 2^24 points (c = 20) the top window's
+        // 512-entry buckets then stay whole (8 items each and three merge launches, 0.5 ms, for nothing: the kernel runs 30 ms)
+        p.cls_shift = p.logT > 6 ? p.logT - 6 : 0;
+        const double walk = 0.2 * ((entries + 1.4 * (double)p.nbuckets) / cc.add_per_us) / cc.lane_add_us;
+        while (p.logT < 20 && (double)(2u << p.logT) <= walk) p.logT++;
         const double T = (double)(1u << p.logT);
         int merge_levels = 0;
         for (double x = per_bucket; x > T; x *= 0.5) merge_levels++;
@@ -95,6 +100,19 @@ void launch_coarse(uint32_t c, dim3 grid, dim3 block, hipStream_t s, const uint3
             launch_coarse<SCATTER, CB + 1>(c, grid, block, s, scalars, flags, g, tilecnt, tileoff, bin_base, coarse);
     }
 }
+// level A of the three-level sort (c = 17..22)
+template <bool SCATTER, int CB = 17>
+void launch_coarseA(uint32_t c, dim3 grid, hipStream_t s, const uint32_t* scalars, const uint8_t* flags, const msmk::SortGeom& g,
+                    uint32_t* tilecnt, const uint32_t* tileoff, const uint32_t* binA_base, uint2* coarseA) {
+    if constexpr (CB > 22) {
+        throw HipFail{"three-level sort: window_bits out of range"};
+    } else {
+        if (c == CB)
+            hipLaunchKernelGGL((msmk::k_coarseA<SCATTER, CB>), grid, dim3(1024), 0, s, scalars, flags, g, tilecnt, tileoff, binA_base, coarseA);
+        else
+            launch_coarseA<SCATTER, CB + 1>(c, grid, s, scalars, flags, g, tilecnt, tileoff, binA_base, coarseA);
+    }
+}
 // the LDS-staged scatter exists for the window sizes whose coarse bins allow it (H <= 128: c <= 16)
 template <int CB = 7>
 void launch_coarse_staged(uint32_t c, dim3 grid, hipStream_t s, const uint32_t* scalars, const uint8_t* flags, const msmk::SortGeom& g,
@@ -130,6 +148,59 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
     g.stride = (uint32_t)stride;
     g.lo_bits = pl.lo_bits;
     g.H = pl.nb >> g.lo_bits;
+    g.nbins = pl.bwin * g.H;
+    d.bin_base.ensure((size_t)(g.nbins + 1) * 4);
+    d.coarse.ensure(entries_cap * 4);
+    // fine-level scratch (upper bound on the segment count: one per bin plus one per FINE_SEG entries); sized here, with the needs of
+    // level B below, so that no buffer grows between two launches of a call
+    const uint32_t segs_cap = g.nbins + (uint32_t)(entries_cap / msmk::FINE_SEG) + 1;
+    const bool three_level = !shared_buckets && pl.c >= 17;
+    {
+        size_t seg_words = (size_t)segs_cap * (1u << g.lo_bits), bins = g.nbins;
+        if (three_level) {
+            const uint32_t nbinsA = pl.nwin * msmk::A_BINS;
+            const size_t segs_capA = nbinsA + entries_cap / msmk::FINE_SEG + 1;
+            seg_words = std::max(seg_words, segs_capA << ((pl.c - 1 - msmk::A_BITS) - pl.lo_bits));
+            bins = std::max<size_t>(bins, nbinsA);
+        }
+        d.seg_cnt.ensure(bins * 4);
+        d.seg_base.ensure((bins + 1) * 4);
+        d.segcnt.ensure(seg_words * 4);
+        d.segoff.ensure(seg_words * 4);
+    }
+    if (three_level) {
+        // ---- c >= 17: level A (window, top 5 bits: all windows in one pass, 8-byte entries), level B (LDS-staged split by the next
+        // MID bits into the 4-byte entries and (window, hi) bins of the one-step pass); see sort_kernels.cuh
+        const uint32_t nbinsA = pl.nwin * msmk::A_BINS;
+        const uint32_t mid_bits = (pl.c - 1 - msmk::A_BITS) - pl.lo_bits, M = 1u << mid_bits;
+        if (nbinsA > 512 || M > msmk::MID_MAX || nbinsA * M != g.nbins) throw HipFail{"three-level sort: geometry"};
+        g.wgroup = pl.nwin; g.ngroups = 1;
+        g.tile_pts = (uint32_t)std::min<size_t>(8192, (n + 1023) / 1024 * 1024);
+        g.tiles = (uint32_t)((n + g.tile_pts - 1) / g.tile_pts);
+        const uint32_t segs_capA = nbinsA + (uint32_t)(entries_cap / msmk::FINE_SEG) + 1;
+        d.tilecnt.ensure((size_t)g.tiles * nbinsA * 4);
+        d.tileoff.ensure((size_t)g.tiles * nbinsA * 4);
+        d.bin_tot.ensure((size_t)nbinsA * 4);
+        d.binA_base.ensure((size_t)(nbinsA + 1) * 4);
+        d.coarseA.ensure(entries_cap * 8);
+        launch_coarseA<false>(pl.c, dim3(g.tiles), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p, (const uint32_t*)nullptr,
+                              (const uint32_t*)nullptr, (uint2*)nullptr);
+        hipLaunchKernelGGL(msmk::k_colscan, dim3((nbinsA + 255) / 256), dim3(256), 0, s, (const uint32_t*)d.tilecnt.p, nbinsA, g.tiles,
+                           (uint32_t*)d.tileoff.p, (uint32_t*)d.bin_tot.p);
+        hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.bin_tot.p, nbinsA, (uint32_t*)d.binA_base.p);
+        launch_coarseA<true>(pl.c, dim3(g.tiles), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p, (const uint32_t*)d.tileoff.p,
+                             (const uint32_t*)d.binA_base.p, (uint2*)d.coarseA.p);
+        hipLaunchKernelGGL(msmk::k_seg_count, dim3((nbinsA + 255) / 256), dim3(256), 0, s, (const uint32_t*)d.binA_base.p, nbinsA,
+                           (uint32_t*)d.seg_cnt.p);
+        hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.seg_cnt.p, nbinsA, (uint32_t*)d.seg_base.p);
+        hipLaunchKernelGGL(msmk::k_mid_count, dim3(segs_capA), dim3(256), 0, s, (const uint2*)d.coarseA.p, (const uint32_t*)d.binA_base.p,
+                           (const uint32_t*)d.seg_base.p, nbinsA, pl.lo_bits, mid_bits, (uint32_t*)d.segcnt.p);
+        hipLaunchKernelGGL(msmk::k_mid_scan, dim3(nbinsA), dim3(512), 0, s, (const uint32_t*)d.binA_base.p, (const uint32_t*)d.seg_base.p, mid_bits,
+                           (const uint32_t*)d.segcnt.p, (uint32_t*)d.segoff.p, (uint32_t*)d.bin_base.p, nbinsA);
+        hipLaunchKernelGGL(msmk::k_mid_scatter, dim3(segs_capA), dim3(256), 0, s, (const uint2*)d.coarseA.p, (const uint32_t*)d.binA_base.p,
+                           (const uint32_t*)d.seg_base.p, nbinsA, pl.lo_bits, mid_bits, (const uint32_t*)d.segcnt.p, (const uint32_t*)d.segoff.p,
+                           (uint32_t*)d.coarse.p);
+    } else {
     // A tile contributes tile_pts / H entries to each coarse bin of a window, written as one contiguous run: keep
     // runs >= 64 entries (256 B) or the 4-byte scatter is write-amplified (9.5 ms at n = 2^24 with 16-entry runs).
     // With few coarse bins per window (H <= 128, i.e. c <= 16) the scatter is staged through LDS instead: a workgroup takes
@@ -148,12 +219,9 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
     }
     g.tiles = (uint32_t)((n + g.tile_pts - 1) / g.tile_pts);
     g.ngroups = (pl.nwin + g.wgroup - 1) / g.wgroup;
-    g.nbins = pl.bwin * g.H;
     d.tilecnt.ensure((size_t)g.tiles * g.nbins * 4);
     d.tileoff.ensure((size_t)g.tiles * g.nbins * 4);
     d.bin_tot.ensure((size_t)g.nbins * 4);
-    d.bin_base.ensure((size_t)(g.nbins + 1) * 4);
-    d.coarse.ensure(entries_cap * 4);
     launch_coarse<false>(pl.c, dim3(g.tiles, g.ngroups), dim3(coarse_block), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
                          (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     hipLaunchKernelGGL(msmk::k_colscan, dim3((g.nbins + 255) / 256), dim3(256), 0, s, (const uint32_t*)d.tilecnt.p, g.nbins, g.tiles,
@@ -165,13 +233,9 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
     else
         launch_coarse<true>(pl.c, dim3(g.tiles, g.ngroups), dim3(coarse_block), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
                             (const uint32_t*)d.tileoff.p, (const uint32_t*)d.bin_base.p, (uint32_t*)d.coarse.p);
+    }
     HIP_TRY(hipEventRecord(d.ev[ev0 + 1], s));
-    // fine sort over bin segments (upper bound on the segment count: one per bin plus one per FINE_SEG entries)
-    uint32_t segs_cap = g.nbins + (uint32_t)(entries_cap / msmk::FINE_SEG) + 1;
-    d.seg_cnt.ensure((size_t)g.nbins * 4);
-    d.seg_base.ensure((size_t)(g.nbins + 1) * 4);
-    d.segcnt.ensure((size_t)segs_cap * (1u << g.lo_bits) * 4);
-    d.segoff.ensure((size_t)segs_cap * (1u << g.lo_bits) * 4);
+    // fine sort over bin segments
     hipLaunchKernelGGL(msmk::k_seg_count, dim3((g.nbins + 255) / 256), dim3(256), 0, s, (const uint32_t*)d.bin_base.p, g.nbins,
                        (uint32_t*)d.seg_cnt.p);
     hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.seg_cnt.p, g.nbins, (uint32_t*)d.seg_base.p);
@@ -195,11 +259,11 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
     uint32_t* blk_i = blk_e + nblk;
     uint32_t* blk_max = blk_i + nblk;
     uint32_t* blk_cls = blk_max + nblk;
-    hipLaunchKernelGGL(msmk::k_sched1, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT,
+    hipLaunchKernelGGL(msmk::k_sched1, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT | (pl.cls_shift << 8),
                        nblk, blk_e, blk_i, blk_cls, blk_max);
     hipLaunchKernelGGL(msmk::k_sched2, dim3(1), dim3(1024), 0, s, nblk, blk_e, blk_i, blk_cls, (const uint32_t*)blk_max,
                        (uint32_t*)d.meta.p);
-    hipLaunchKernelGGL(msmk::k_sched3, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT,
+    hipLaunchKernelGGL(msmk::k_sched3, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT | (pl.cls_shift << 8),
                        nblk, (const uint32_t*)blk_e, (const uint32_t*)blk_i, (const uint32_t*)blk_cls, (uint32_t*)d.offsets.p,
                        (uint32_t*)d.woff.p, (uint32_t*)d.order.p, (uint32_t*)d.item_bucket.p, (uint32_t*)d.merge_list.p,
                        (uint32_t*)d.meta.p);

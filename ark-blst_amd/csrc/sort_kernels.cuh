@@ -310,6 +310,173 @@ __global__ void __launch_bounds__(256) k_fine_scatter(const uint32_t* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------- three-level sort (c >= 17)
+// With c >= 17 a window has up to 4096 coarse bins: a workgroup of the one-step coarse scatter keeps up to 16384 runs open at
+// once, far more than L2 can merge, so every 4-byte entry reaches HBM as a partial line (2.8 ms at 2^24 for 0.87 GB), and the
+// window groups re-read the scalars 4 to 13 times.  The coarse level is therefore split in two when c >= 17:
+//   level A   bins = (window, top 5 bucket bits): <= 512 bins for ALL windows together, so the scalars are read once per pass and a
+//             workgroup keeps <= 512 runs open.  Entries are 8 bytes here — (point index, sign | remaining bucket bits): index +
+//             sign + up to 16 remaining bits do not fit one word.
+//   level B   per <= 8192-entry segment of an A bin: counting sort in LDS by the next MID bits (<= 512 sub-bins), written out as
+//             the 4-byte entries and the (window, hi) bins the fine level expects — coarse[] and bin_base[] come out exactly as
+//             the one-step coarse pass leaves them.
+constexpr uint32_t A_BITS = 5, A_BINS = 1u << A_BITS;
+constexpr uint32_t MID_MAX = 512;
+
+template <bool SCATTER, int CB>
+__global__ void __launch_bounds__(1024) k_coarseA(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flags, SortGeom g,
+                                                  uint32_t* __restrict__ tilecnt, const uint32_t* __restrict__ tileoff,
+                                                  const uint32_t* __restrict__ binA_base, uint2* __restrict__ coarseA) {
+    __shared__ uint32_t cnt[512];
+    const uint32_t tile = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+    const uint32_t nbinsA = g.nwin * A_BINS;
+    for (uint32_t k = t; k < nbinsA; k += nt) cnt[k] = SCATTER ? binA_base[k] + tileoff[(size_t)tile * nbinsA + k] : 0u;
+    __syncthreads();
+    constexpr uint32_t REM = CB - 1 - A_BITS;   // bucket bits left below the A bin
+    const uint32_t p0 = tile * g.tile_pts, p1 = p0 + g.tile_pts < g.n ? p0 + g.tile_pts : g.n;
+    for (uint32_t i = p0 + t; i < p1; i += nt) {
+        if (inf_flags[i] != 0) continue;
+        uint32_t s[8];
+        load_scalar(s, scalars, i, g.fmt);
+        for_each_digit_static<CB>(s, 0, g.nwin, [&](uint32_t w, uint32_t b, bool neg) {
+            uint32_t pos = atomicAdd(&cnt[w * A_BINS + (b >> REM)], 1u);
+            if (SCATTER) coarseA[pos] = make_uint2(i, ((neg ? 1u : 0u) << 31) | (b & ((1u << REM) - 1u)));
+        });
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t k = t; k < nbinsA; k += nt) tilecnt[(size_t)tile * nbinsA + k] = cnt[k];
+    }
+}
+
+// level B, per segment of an A bin: histogram of the MID bits
+__global__ void __launch_bounds__(256) k_mid_count(const uint2* __restrict__ coarseA, const uint32_t* __restrict__ binA_base,
+                                                   const uint32_t* __restrict__ segA_base, uint32_t nbinsA, uint32_t lo_bits, uint32_t mid_bits,
+                                                   uint32_t* __restrict__ segcnt) {
+    __shared__ uint32_t cnt[MID_MAX];
+    __shared__ uint32_t sb[3];
+    uint32_t t = threadIdx.x, seg = blockIdx.x;
+    if (t == 0) {
+        uint32_t bin = 0, beg = 0, end = 0;
+        bool ok = seg_locate(seg, segA_base, binA_base, nbinsA, bin, beg, end);
+        sb[0] = ok ? beg : 1u; sb[1] = ok ? end : 0u; sb[2] = ok ? 1u : 0u;
+    }
+    cnt[t] = 0; cnt[t + 256] = 0;
+    __syncthreads();
+    if (!sb[2]) return;
+    const uint32_t beg = sb[0], end = sb[1], M = 1u << mid_bits;
+    for (uint32_t i = beg + t; i < end; i += 256) atomicAdd(&cnt[(coarseA[i].y >> lo_bits) & (M - 1u)], 1u);
+    __syncthreads();
+    for (uint32_t k = t; k < M; k += 256) segcnt[(size_t)seg * M + k] = cnt[k];
+}
+
+// level B, one workgroup per A bin: offsets of every (segment, sub-bin) run inside the A bin, and the bases of the final bins
+// (window, top 5 bits, MID bits) = the bins of the one-step coarse pass: bin_base[a * M + sub].
+__global__ void __launch_bounds__(512) k_mid_scan(const uint32_t* __restrict__ binA_base, const uint32_t* __restrict__ segA_base,
+                                                  uint32_t mid_bits, const uint32_t* __restrict__ segcnt, uint32_t* __restrict__ segoff,
+                                                  uint32_t* __restrict__ bin_base, uint32_t nbinsA) {
+    __shared__ uint32_t scan[MID_MAX];
+    const uint32_t a = blockIdx.x, t = threadIdx.x, M = 1u << mid_bits;
+    const uint32_t s0 = segA_base[a], s1 = segA_base[a + 1];
+    // lane = sub-bin (an A bin of 2^24 points has 64 segments: the loads of eight of them are kept in flight per lane)
+    uint32_t tot = 0;
+    if (t < M) {
+        uint32_t sg = s0;
+        for (; sg + 8 <= s1; sg += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = segcnt[(size_t)(sg + u) * M + t];
+#pragma unroll
+            for (int u = 0; u < 8; u++) tot += v[u];
+        }
+        for (; sg < s1; sg++) tot += segcnt[(size_t)sg * M + t];
+    }
+    scan[t] = t < M ? tot : 0;
+    __syncthreads();
+    for (uint32_t d = 1; d < MID_MAX; d <<= 1) {
+        uint32_t v = t >= d ? scan[t - d] : 0;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    if (t < M) {
+        uint32_t run = scan[t] - tot;   // start of sub-bin t inside the A bin; then exclusive over the segments
+        bin_base[(size_t)a * M + t] = binA_base[a] + run;
+        uint32_t sg = s0;
+        for (; sg + 8 <= s1; sg += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = segcnt[(size_t)(sg + u) * M + t];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                segoff[(size_t)(sg + u) * M + t] = run;
+                run += v[u];
+            }
+        }
+        for (; sg < s1; sg++) {
+            uint32_t v = segcnt[(size_t)sg * M + t];
+            segoff[(size_t)sg * M + t] = run;
+            run += v;
+        }
+    }
+    if (a == nbinsA - 1 && t == 0) bin_base[(size_t)nbinsA * M] = binA_base[nbinsA];
+}
+
+// level B scatter, LDS-staged like k_fine_scatter: 8-byte entries in, 4-byte entries out
+__global__ void __launch_bounds__(256) k_mid_scatter(const uint2* __restrict__ coarseA, const uint32_t* __restrict__ binA_base,
+                                                     const uint32_t* __restrict__ segA_base, uint32_t nbinsA, uint32_t lo_bits, uint32_t mid_bits,
+                                                     const uint32_t* __restrict__ segcnt, const uint32_t* __restrict__ segoff,
+                                                     uint32_t* __restrict__ coarse) {
+    __shared__ uint32_t stage[FINE_SEG];
+    __shared__ uint32_t lstart[MID_MAX + 1], cur[MID_MAX], goff[MID_MAX];
+    __shared__ uint32_t sb[4];
+    const uint32_t t = threadIdx.x, seg = blockIdx.x;
+    if (t == 0) {
+        uint32_t bin = 0, beg = 0, end = 0;
+        bool ok = seg_locate(seg, segA_base, binA_base, nbinsA, bin, beg, end);
+        sb[0] = beg; sb[1] = end; sb[2] = ok ? 1u : 0u; sb[3] = ok ? binA_base[bin] : 0u;
+    }
+    __syncthreads();
+    if (!sb[2]) return;
+    const uint32_t beg = sb[0], end = sb[1], binA_beg = sb[3], M = 1u << mid_bits;
+    uint32_t mine[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const uint32_t k = t + 256 * r;
+        mine[r] = k < M ? segcnt[(size_t)seg * M + k] : 0u;
+        goff[k] = k < M ? binA_beg + segoff[(size_t)seg * M + k] : 0u;
+        cur[k] = mine[r];
+    }
+    __syncthreads();
+    for (uint32_t d = 1; d < MID_MAX; d <<= 1) {   // inclusive scan of the 512 counts, two per lane
+        uint32_t v0 = t >= d ? cur[t - d] : 0, v1 = cur[t + 256 - d];
+        __syncthreads();
+        cur[t] += v0; cur[t + 256] += v1;
+        __syncthreads();
+    }
+    const uint32_t e0 = cur[t] - mine[0], e1 = cur[t + 256] - mine[1];
+    __syncthreads();
+    lstart[t] = e0; lstart[t + 256] = e1;
+    cur[t] = e0; cur[t + 256] = e1;
+    if (t == 255) lstart[MID_MAX] = e1 + mine[1];
+    __syncthreads();
+    const uint32_t lo_mask = (1u << lo_bits) - 1u;
+    for (uint32_t i = beg + t; i < end; i += 256) {
+        uint2 e = coarseA[i];
+        uint32_t pos = atomicAdd(&cur[(e.y >> lo_bits) & (M - 1u)], 1u);
+        stage[pos] = (e.x << (lo_bits + 1)) | ((e.y >> 31) << lo_bits) | (e.y & lo_mask);
+    }
+    __syncthreads();
+    const uint32_t len = end - beg;
+    for (uint32_t j = t; j < len; j += 256) {
+        uint32_t k = 0;
+#pragma unroll
+        for (uint32_t step = MID_MAX / 2; step >= 1; step >>= 1)
+            if (lstart[k + step] <= j) k += step;
+        coarse[goff[k] + (j - lstart[k])] = stage[j];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- scan / schedule
 // Three small launches turn the histogram into (a) entry offsets for the scatter, (b) WORK ITEMS and (c) a
 // length-sorted processing order for them:
@@ -325,7 +492,10 @@ constexpr int SCHED_CLASSES = 65;
 __device__ __forceinline__ uint32_t items_of(uint32_t cnt, uint32_t logT) {
     return cnt == 0 ? 1u : (cnt + (1u << logT) - 1u) >> logT;
 }
-__device__ __forceinline__ uint32_t class_of(uint32_t len, uint32_t logT) { return (len << 6) >> logT; }  // 0..64
+// length class 0..64 of an item: len >> cls_shift, clamped.  The class width follows the TYPICAL item (twice the mean bucket load
+// spans the 64 classes), not T: when T is raised for a long kernel the ordinary buckets must still be sorted to a few entries,
+// or the lanes of a wave walk items of visibly different lengths (measured +8 % on the accumulate kernel at 2^24).
+__device__ __forceinline__ uint32_t class_of(uint32_t len, uint32_t cls_shift) { uint32_t c = len >> cls_shift; return c < 64 ? c : 64; }
 
 __global__ void __launch_bounds__(1024) k_sched1(const uint32_t* __restrict__ hist, uint32_t m, uint32_t per_blk, uint32_t logT,
                                                  uint32_t nblk, uint32_t* __restrict__ blk_e, uint32_t* __restrict__ blk_i,
@@ -338,6 +508,8 @@ __global__ void __launch_bounds__(1024) k_sched1(const uint32_t* __restrict__ hi
     __syncthreads();
     uint32_t per_t = per_blk >> 10;
     uint32_t lo = blk * per_blk + t * per_t, hi = lo + per_t < m ? lo + per_t : m;
+    const uint32_t cls_shift = logT >> 8;   // the launch packs (class shift << 8) | log2 T
+    logT &= 0xffu;
     uint32_t sum_e = 0, sum_i = 0, mx = 1, T = 1u << logT;
     for (uint32_t k = lo; k < hi; k++) {
         uint32_t h = hist[k], it = items_of(h, logT);
@@ -345,7 +517,7 @@ __global__ void __launch_bounds__(1024) k_sched1(const uint32_t* __restrict__ hi
         sum_i += it;
         mx = it > mx ? it : mx;
         if (it > 1) atomicAdd(&cls[64], it - 1);
-        atomicAdd(&cls[class_of(h - (it - 1) * T, logT)], 1u);
+        atomicAdd(&cls[class_of(h - (it - 1) * T, cls_shift)], 1u);
     }
     atomicAdd(&se, sum_e);
     atomicAdd(&si, sum_i);
@@ -428,6 +600,8 @@ __global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hi
     if (t < SCHED_CLASSES) cur[t] = blk_cls[t * nblk + blk];
     uint32_t per_t = per_blk >> 10;
     uint32_t lo = blk * per_blk + t * per_t, hi = lo + per_t < m ? lo + per_t : m;
+    const uint32_t cls_shift = logT >> 8;
+    logT &= 0xffu;
     uint32_t sum_e = 0, sum_i = 0, T = 1u << logT;
     for (uint32_t k = lo; k < hi; k++) {
         uint32_t h = hist[k];
@@ -461,7 +635,7 @@ __global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hi
             }
         }
         uint32_t last = run_i + it - 1;
-        uint32_t pos = atomicAdd(&cur[class_of(h - (it - 1) * T, logT)], 1u);
+        uint32_t pos = atomicAdd(&cur[class_of(h - (it - 1) * T, cls_shift)], 1u);
         order[pos] = last;
         item_bucket[last] = k;
         run_e += h;
