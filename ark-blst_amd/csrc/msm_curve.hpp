@@ -19,7 +19,7 @@ template <> struct HostCurve<msmk::G2C> {
     using J = hostec::G2;
     static constexpr int IDX = 1;
     // lane pairs for the reduce (throughput), eight lanes per logical lane for the combine (latency)
-    static CurveCost cost() { return CurveCost{msmk::PairG2::LOG_LL, msmk::OctG2::LOG_LL, 1024, 2300.0, 33.0, 28.0, 14.0, 150.0, 0, 0.0}; }
+    static CurveCost cost() { return CurveCost{msmk::PairG2::LOG_LL, msmk::OctG2::LOG_LL, 1024, 2300.0, 36.0, 28.0, 14.0, 150.0, 0, 0.0}; }
 };
 template <class C> constexpr size_t aff_bytes() { return (size_t)msmk::Geo<C>::RAW_AFF * 4; }
 template <class C> constexpr size_t jac_bytes() { return (size_t)msmk::Geo<C>::RAW_JAC * 4; }

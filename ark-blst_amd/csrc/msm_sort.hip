@@ -63,12 +63,15 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         const double T = (double)(1u << p.logT);
         int merge_levels = 0;
         for (double x = per_bucket; x > T; x *= 0.5) merge_levels++;
-        const double item_len = std::min(T, std::max(mean, std::min(per_bucket, T)));   // entries a lane walks serially
+        // entries the longest ordinary lane walks serially: bucket loads are Poisson distributed, the kernel ends with the tail
+        const double tail = mean + 3.0 * std::sqrt(mean);
+        const double item_len = std::min(T, std::max(tail, std::min(per_bucket, T)));
         const double rounds = (double)((p.nchunks + cc.max_chunks - 1) / cc.max_chunks);
         int levels = 0;
         for (uint32_t m = p.chunks_per_win; m > 1; m = (m + (1u << cc.comb_log_ll) - 1) >> cc.comb_log_ll) levels++;
         const double reduce_us = p.serial_reduce ? std::ceil((double)p.nchunks / 131072.0) * 134.0 * cc.serial_step_us
-                                                 : rounds * (2.0 * (1u << p.logL) + 2.0 * log_ll + p.logL + 1.0) * cc.step_us;
+                                                 : rounds * (2.0 * (1u << p.logL) + 2.0 * log_ll + p.logL + 1.0) *
+                                                       (p.nchunks <= 1024 ? std::min(cc.step_us, cc.comb_step_us * 1.05) : cc.step_us);   // lone waves step faster
         // combine: one latency chain per level; the first level of a long pair list runs in several rounds of 2048 waves
         const double comb_chain = (2.0 * cc.comb_log_ll + 1.0) * cc.comb_step_us;
         const double comb_us = std::max(1, levels) * (comb_chain + 8.0) +
