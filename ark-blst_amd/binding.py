@@ -51,6 +51,7 @@ def load_library(test_hooks: bool = False):
             getattr(L, f"mi_msm_{g}_device").argtypes = [vp, vp, sz, u, vp]
             getattr(L, f"mi_{g}_sum").argtypes = [vp, sz, vp]
             getattr(L, f"mi_msm_{g}_batch").argtypes = [vp, C.POINTER(C.c_char_p), sz, sz, u, vp]
+            getattr(L, f"mi_msm_{g}_batch_device").argtypes = [vp, C.POINTER(vp), sz, sz, u, vp]
             getattr(L, f"mi_{g}_normalize_batch").argtypes = [vp, vp, sz, vp]
         for g in ("g1", "g2"):
             getattr(L, f"mi_{g}_deserialize_batch").argtypes = [vp, vp, sz, i, i, vp, vp]
@@ -154,6 +155,15 @@ class Context:
         out = C.create_string_buffer(size * max(k, 1))
         arr = (C.c_char_p * max(k, 1))(*[bytes(v) for v in scalar_vectors])
         self._check(getattr(self._L, f"mi_msm_{group}_batch")(self._h, arr, k, n, scalar_fmt, out), f"mi_msm_{group}_batch")
+        return [out.raw[size * j:size * (j + 1)] for j in range(k)]
+
+    def msm_batch_device(self, group: str, d_scalar_ptrs, n: int, scalar_fmt: int = SCALAR_CANONICAL):
+        """msm_batch with the scalar vectors already in device memory (a list of device pointers)."""
+        k = len(d_scalar_ptrs)
+        size = G1_JAC if group == "g1" else G2_JAC
+        out = C.create_string_buffer(size * max(k, 1))
+        arr = (C.c_void_p * max(k, 1))(*[C.c_void_p(p) for p in d_scalar_ptrs])
+        self._check(getattr(self._L, f"mi_msm_{group}_batch_device")(self._h, arr, k, n, scalar_fmt, out), f"mi_msm_{group}_batch_device")
         return [out.raw[size * j:size * (j + 1)] for j in range(k)]
 
     def msm_device(self, group: str, d_scalars_ptr: int, n: int, scalar_fmt: int = SCALAR_CANONICAL) -> bytes:

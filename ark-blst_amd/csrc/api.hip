@@ -119,10 +119,16 @@ int mi_msm_g2_device(mi_ctx* ctx, const void* d_scalars, size_t n, unsigned scal
 }
 
 int mi_msm_g1_batch(mi_ctx* ctx, const uint8_t* const* scalars, size_t k, size_t n, unsigned scalar_fmt, mi_g1* out) {
-    return g1_msm_batch(ctx, scalars, k, n, scalar_fmt, out);
+    return g1_msm_batch(ctx, scalars, false, k, n, scalar_fmt, out);
 }
 int mi_msm_g2_batch(mi_ctx* ctx, const uint8_t* const* scalars, size_t k, size_t n, unsigned scalar_fmt, mi_g2* out) {
-    return g2_msm_batch(ctx, scalars, k, n, scalar_fmt, out);
+    return g2_msm_batch(ctx, scalars, false, k, n, scalar_fmt, out);
+}
+int mi_msm_g1_batch_device(mi_ctx* ctx, const void* const* d_scalars, size_t k, size_t n, unsigned scalar_fmt, mi_g1* out) {
+    return g1_msm_batch(ctx, reinterpret_cast<const uint8_t* const*>(d_scalars), true, k, n, scalar_fmt, out);
+}
+int mi_msm_g2_batch_device(mi_ctx* ctx, const void* const* d_scalars, size_t k, size_t n, unsigned scalar_fmt, mi_g2* out) {
+    return g2_msm_batch(ctx, reinterpret_cast<const uint8_t* const*>(d_scalars), true, k, n, scalar_fmt, out);
 }
 
 int mi_g1_normalize_batch(mi_ctx* ctx, const mi_g1* in, size_t n, mi_g1_affine* out) { return g1_normalize(ctx, in, n, out); }

@@ -385,7 +385,7 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
 
 // k MSMs over the resident base set, two in flight (one per lane): the calling thread and one helper pull jobs
 template <class C, class Out>
-int msm_batch_impl(mi_ctx* ctx, const uint8_t* const* scalars, size_t k, size_t n, unsigned fmt, Out* out) {
+int msm_batch_impl(mi_ctx* ctx, const uint8_t* const* scalars, bool scalars_on_device, size_t k, size_t n, unsigned fmt, Out* out) {
     if (!ctx || (k && (!scalars || !out))) return fail(ctx, MI_E_INVALID, "invalid argument");
     for (size_t j = 0; j < k; j++)
         if (n && !scalars[j]) return fail(ctx, MI_E_INVALID, "null scalar vector");
@@ -398,7 +398,7 @@ int msm_batch_impl(mi_ctx* ctx, const uint8_t* const* scalars, size_t k, size_t 
             for (;;) {
                 size_t j = next.fetch_add(1);
                 if (j >= k || first_err.load() != MI_OK) break;
-                int rc = msm_impl<C>(ctx, nullptr, scalars[j], false, n, fmt, &out[j]);   // never throws (guarded)
+                int rc = msm_impl<C>(ctx, nullptr, scalars[j], scalars_on_device, n, fmt, &out[j]);   // never throws (guarded)
                 int ok = MI_OK;
                 if (rc != MI_OK && first_err.compare_exchange_strong(ok, rc)) {
                     std::lock_guard<std::mutex> lk(msg_mu);

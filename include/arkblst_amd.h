@@ -127,6 +127,10 @@ int mi_msm_g2_device(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scal
  * call msm once per polynomial and re-upload the bases each time, src/gpu.rs:149).  Stops at the first error. */
 int mi_msm_g1_batch(mi_ctx *ctx, const uint8_t *const *scalars, size_t k, size_t n, unsigned scalar_fmt, mi_g1 *out);
 int mi_msm_g2_batch(mi_ctx *ctx, const uint8_t *const *scalars, size_t k, size_t n, unsigned scalar_fmt, mi_g2 *out);
+/* The same with the k scalar vectors already in device memory (an array of k device pointers, each n x 32 B; synchronise their
+ * producer first, as for mi_msm_g1_device): nothing but the window sums crosses PCIe. */
+int mi_msm_g1_batch_device(mi_ctx *ctx, const void *const *d_scalars, size_t k, size_t n, unsigned scalar_fmt, mi_g1 *out);
+int mi_msm_g2_batch_device(mi_ctx *ctx, const void *const *d_scalars, size_t k, size_t n, unsigned scalar_fmt, mi_g2 *out);
 
 /* Jacobian -> affine for n points with one field inversion (product tree on the GPU).  Replaces
  * CurveGroup::normalize_batch = blstrs::G{1,2}Projective::batch_normalize (src/g1.rs:537-543, src/g2.rs:517-523), the step

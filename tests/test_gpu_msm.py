@@ -504,6 +504,13 @@ def test_msm_batch_over_resident_bases(ctx, co, pkg, group):
     assert co.to_affine(group, one[0]) == co.to_affine(group, got[0])
     mont = ctx.msm_batch(group, [co.fr_to_mont(v) for v in vecs[:2]], n, pkg.SCALAR_MONTGOMERY)
     assert [co.to_affine(group, x) for x in mont] == [co.to_affine(group, x) for x in got[:2]]
+    # the same vectors from device memory
+    import torch
+
+    dv = [torch.frombuffer(bytearray(v), dtype=torch.uint8).cuda() for v in vecs]
+    torch.cuda.synchronize()
+    dev = ctx.msm_batch_device(group, [t.data_ptr() for t in dv], n, pkg.SCALAR_CANONICAL)
+    assert [co.to_affine(group, x) for x in dev] == [co.to_affine(group, x) for x in got]
 
 
 def test_bench_json_contract():
