@@ -44,6 +44,8 @@ int mi_msm_init(mi_ctx** out, const int* device_ids, int n_devices) {
             for (DevState* d : {&ctx->devs[k], &ctx->devs_b[k]}) {
                 d->dev = id;
                 d->res = ctx->residents[k].data();
+                int cus = 0;
+                if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, id) == hipSuccess && cus > 0) d->simds = 4u * (uint32_t)cus;
                 HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
                 for (auto& e : d->ev) HIP_TRY(hipEventCreate(&e));
             }

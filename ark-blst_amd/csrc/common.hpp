@@ -93,6 +93,7 @@ struct Resident {
 // under the other's accumulate kernel.  The resident bases are shared.
 struct DevState {
     int dev = 0;
+    uint32_t simds = 1024;   // 4 per compute unit (256 CUs on MI355X)
     hipStream_t stream = nullptr;
     hipEvent_t ev[12] = {};
     Resident* res = nullptr;   // -> mi_ctx::residents[device][2]

@@ -1,5 +1,6 @@
 // Batched Miller loop + final exponentiation (BASELINE config #5): host driver of pairing_kernels.cuh.
 // Replaces <Bls12 as Pairing>::multi_miller_loop / final_exponentiation (/root/reference/src/pairing.rs:49-80).
+#include <cmath>
 #include "internal.hpp"
 #include "pairing_kernels.cuh"
 
@@ -72,10 +73,15 @@ HT::E12 device_miller(mi_ctx* ctx, DevState& d, const mi_g1_affine* p, const mi_
     HIP_TRY(hipEventRecord(d.ev[1], s));
     bool single_lane = false;
     size_t batch_cap = (size_t)1 << 17;
-    // pairs per accumulator.  Measured at 2^16 pairs (tools/scan_pairing_share.py): 1 / 2 / 4 / 8 pairs -> 8.0 / 6.8 / 5.7 / 5.4 ms —
-    // the saved squarings outweigh the idle SIMDs (819 waves at 8); a twelve-lane variant of the kernel (one Fp component per
-    // lane, twice the waves of half the length) was slower at every setting (6.2 ms at 8) and was not kept.
-    uint32_t share = (uint32_t)std::min<size_t>(8, std::max<size_t>(1, n >> 13));
+    // Pairs per accumulator m: f <- f^2 l_1 ... l_m per step, so a larger m saves squarings (one squaring costs about two line
+    // multiplications), but the accumulate kernel is a grid of lone waves (ten accumulators each, 254 VGPRs): its time is the time
+    // of ONE wave as long as every wave has a SIMD to itself, and 1.84x that once a second wave shares the SIMD.  m is the minimum of
+    //   (1 + 0.53 m) * g(ceil(waves(m) / SIMD slots)),  g(1) = 1, g(2) = 1.84, g(r) = 0.92 r,  m <= 8
+    // Measured (tools/scan_pairing_share.py, accumulate kernel, ms): 2^16 pairs m = 4 / 6 / 7 / 8 / 16 -> 5.7 / 7.5 / 4.75 / 5.3 / 9.2
+    // (937 waves at 7, 1093 at 6); 2^17: 7 / 8 / 13 / 16 -> 8.8 / 9.6 / 14.0 / 16.9; 2^15: 2 / 3 / 4 / 5 -> 3.6 / 4.4 / 3.0 / 3.6;
+    // 2^14: 1 / 2 / 4 -> 2.4 / 1.8 / 2.8.  1009 waves (m = 13 at 2^17) already behave as doubled up: slots = 15/16 of the SIMDs.
+    // A twelve-lane variant of the kernel (one Fp component per lane) was slower at every setting.
+    uint32_t share = 0;
 #if defined(MI_TEST_HOOKS)
     single_lane = ctx->test_pairing_single_lane;
     if (ctx->test_pairing_batch) batch_cap = ctx->test_pairing_batch;
@@ -83,6 +89,17 @@ HT::E12 device_miller(mi_ctx* ctx, DevState& d, const mi_g1_affine* p, const mi_
 #else
     (void)ctx;
 #endif
+    if (!share) {
+        const size_t batch_pairs = std::min<size_t>(n, batch_cap);
+        const double slots = d.simds * (15.0 / 16.0);
+        double best = 0;
+        for (uint32_t m = 1; m <= 8; m++) {
+            const double waves = std::ceil(std::ceil((double)batch_pairs / m) / msmk::MILLER_GROUPS);
+            const double r = std::max(1.0, std::ceil(waves / slots));
+            const double cost = (1.0 + 0.53 * m) * (r == 1.0 ? 1.0 : 0.92 * r);
+            if (!share || cost < best) { best = cost; share = m; }
+        }
+    }
     size_t nvals = 0;   // Fp12 values the Miller kernels leave in lvl[0]
     bool split_timed = false;
     if (single_lane) {
@@ -94,17 +111,17 @@ HT::E12 device_miller(mi_ctx* ctx, DevState& d, const mi_g1_affine* p, const mi_
     } else {
         // line coefficients of a batch of pairs (26 KB per pair), then six lanes per accumulator fold them into f
         const size_t batch = std::min<size_t>(n, batch_cap);
-        while (share > 1 && batch % share) share >>= 1;   // accumulators must not straddle line batches
-        dlines.ensure(batch * msmk::MILLER_LINES * 3 * 32 * 4);
+        const uint32_t blk = share * msmk::MILLER_GROUPS;   // pairs per accumulate wave = one block of the line buffer
+        dlines.ensure((batch + blk - 1) / blk * blk * msmk::MILLER_LINES * 3 * 32 * 4);
         for (size_t lo = 0; lo < n; lo += batch) {
             uint32_t mm = (uint32_t)std::min(batch, n - lo);
             uint32_t groups = (mm + share - 1) / share;
             hipLaunchKernelGGL(msmk::k_miller_lines2, dim3((2 * mm + 63) / 64), dim3(64), 0, s,
                                (const uint32_t*)dp.p + lo * msmk::Geo<msmk::G1C>::RAW_AFF, (const uint32_t*)dq.p + lo * msmk::Geo<msmk::G2C>::RAW_AFF,
-                               mm, (uint32_t*)dlines.p);
+                               mm, blk, (uint32_t*)dlines.p);
             if (lo == 0) HIP_TRY(hipEventRecord(d.ev[4], s));   // first batch: the two kernels timed separately (profile)
             hipLaunchKernelGGL(msmk::k_miller_accumulate, dim3((groups + msmk::MILLER_GROUPS - 1) / msmk::MILLER_GROUPS), dim3(64), 0, s,
-                               (const uint32_t*)dlines.p, mm, share, (uint32_t*)lvl[0].p + nvals * msmk::FP12_WORDS);
+                               (const uint32_t*)dlines.p, mm, share, blk, (uint32_t*)lvl[0].p + nvals * msmk::FP12_WORDS);
             if (lo == 0) HIP_TRY(hipEventRecord(d.ev[5], s));
             nvals += groups;
         }

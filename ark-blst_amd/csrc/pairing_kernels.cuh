@@ -150,8 +150,17 @@ __device__ __forceinline__ void coop_line_add(ec::Proj<CoopF2>& T, const uint32_
     ec::proj_add<CoopF2>(T, q);
 }
 
+// Line buffer layout: [block of `blk` pairs][line][pair in block][3 Fp2 slots of 32 words].  blk = the pairs one wave of
+// k_miller_accumulate folds (ten accumulators of m pairs), so a wave's 68 reads walk ONE contiguous region (1.8 MB at m = 7)
+// instead of 68 regions n * 384 B apart: with [line][pair] over all pairs the 3.4 GB of 2^17 pairs fell off the TLB reach and
+// every line cost twice what it costs at 2^16 pairs.
+__device__ __forceinline__ size_t line_base_words(uint32_t pair, uint32_t blk) {   // line 0 of `pair`; line l is l * blk * 96 words on
+    const uint32_t b = pair / blk, i = pair - b * blk;
+    return ((size_t)b * MILLER_LINES * blk + i) * 96;
+}
+
 __global__ void __launch_bounds__(64, 2) k_miller_lines2(const uint32_t* __restrict__ g1_raw, const uint32_t* __restrict__ g2_raw, uint32_t n,
-                                                         uint32_t* __restrict__ lines) {
+                                                         uint32_t blk, uint32_t* __restrict__ lines) {
     __shared__ uint32_t cst[LINES_LDS_WORDS];
     const uint32_t lane = threadIdx.x, h = lane & 1u;
     const uint32_t pair = (blockIdx.x * 64 + lane) >> 1;
@@ -181,14 +190,16 @@ __global__ void __launch_bounds__(64, 2) k_miller_lines2(const uint32_t* __restr
     }
     __syncthreads();
     LineSink out{nullptr, valid, anyp == 0 || anyq == 0, h};
+    uint32_t* const line0 = lines + line_base_words(i, blk) + 16 * h;
+    const size_t line_stride = (size_t)blk * 96;
     int line = 0;
 #pragma unroll 1
     for (int b = 62; b >= 0; b--) {
-        out.o = lines + ((size_t)line * n + pair) * 3 * 32 + 16 * h;
+        out.o = line0 + line * line_stride;
         coop_line_dbl(T, lds_p, out);
         line++;
         if ((fp28c::Z_ABS >> b) & 1) {
-            out.o = lines + ((size_t)line * n + pair) * 3 * 32 + 16 * h;
+            out.o = line0 + line * line_stride;
             coop_line_add(T, lds_q, lds_p, out);
             line++;
         }
@@ -233,7 +244,7 @@ __device__ __forceinline__ void fp2_acc_term(uint64_t (&c0)[2 * fp28::NL], uint6
 
 // `m` consecutive pairs share one accumulator: f <- f^2 * l_1 * ... * l_m per step (the multi-Miller-loop trick: one squaring
 // for m pairs, as blst's miller_loop_n does); out[g] = product of the Miller values of pairs [g m, g m + m).
-__global__ void __launch_bounds__(64, 2) k_miller_accumulate(const uint32_t* __restrict__ lines, uint32_t n, uint32_t m,
+__global__ void __launch_bounds__(64, 2) k_miller_accumulate(const uint32_t* __restrict__ lines, uint32_t n, uint32_t m, uint32_t blk,
                                                              uint32_t* __restrict__ out) {
     __shared__ uint32_t fs[(MILLER_GROUPS + 1) * 6 * LDS_COEFF_WORDS];   // + one dummy group for the idle lanes
     const uint32_t lane = threadIdx.x;
@@ -258,7 +269,7 @@ __global__ void __launch_bounds__(64, 2) k_miller_accumulate(const uint32_t* __r
 #pragma unroll 1
         for (uint32_t q = 0; q < m; q++) {
             const bool live = first + q < n;
-            const uint32_t* lp = lines + ((size_t)line * n + (live ? first + q : n - 1)) * 3 * 32;
+            const uint32_t* lp = lines + line_base_words(live ? first + q : n - 1, blk) + (size_t)line * blk * 96;
             uint64_t c0[2 * fp28::NL], c1[2 * fp28::NL];
 #pragma unroll
             for (int t = 0; t < 2 * fp28::NL; t++) { c0[t] = 0; c1[t] = 0; }

@@ -125,12 +125,14 @@ def test_line_buffer_batches(ctx, tctx, co):
     """more pairs than one line-buffer batch (2^17 in production; forced to 100 through the test build's hook)"""
     g1 = co.gen_bases("g1", 77, 257, 2)
     g2 = co.gen_bases("g2", 78, 257, 2)
-    tctx.test_set_pairing(batch=100)
-    try:
-        got = tctx.multi_pairing(g1, g2)
-    finally:
-        tctx.test_set_pairing()
-    assert got == ctx.multi_pairing(g1, g2) and len(got) == 576
+    want = ctx.multi_pairing(g1, g2)
+    for batch, share in ((100, 0), (100, 7), (64, 3)):   # batches that are not a multiple of the accumulator width either
+        tctx.test_set_pairing(batch=batch, share=share)
+        try:
+            got = tctx.multi_pairing(g1, g2)
+        finally:
+            tctx.test_set_pairing()
+        assert got == want and len(got) == 576, (batch, share)
 
 
 def test_single_lane_first_version_agrees(ctx, tctx, co):
@@ -145,10 +147,11 @@ def test_single_lane_first_version_agrees(ctx, tctx, co):
     assert got == ctx.multi_pairing(g1, g2)
 
 
-@pytest.mark.parametrize("share", [2, 3, 8])
+@pytest.mark.parametrize("share", [2, 3, 5, 7, 8])
 def test_shared_squaring_accumulators(tctx, co, share):
-    """m pairs per accumulator (one Fp12 squaring per Miller step for all of them; production picks m = n / 2^14, capped
-    at 8): forced through the test hook on sizes that do and do not divide by m, with infinity pairs, against the C oracle"""
+    """m pairs per accumulator (one Fp12 squaring per Miller step for all of them; production picks the m <= 8 that leaves
+    one accumulate wave per SIMD: 7 at 2^16 pairs): forced through the test hook on sizes that do and do not divide by m, with
+    infinity pairs, against the C oracle.  The line buffer is laid out in blocks of 10 m pairs: 997 pairs leave a ragged block."""
     for n in (1, share, share + 1, 997):
         g1 = bytearray(co.gen_bases("g1", SEED_P + 11, n, 8))
         g2 = bytearray(co.gen_bases("g2", SEED_Q + 11, n, 8))

@@ -13,7 +13,7 @@ g1 = co.gen_bases("g1", 21, n, 16)
 g2 = co.gen_bases("g2", 22, n, 16)
 with pkg.Context([0], test_hooks=True) as ctx:
     ref = None
-    for m in (0, 1, 2, 4, 8):
+    for m in (0,) + tuple(int(x) for x in (sys.argv[2].split(',') if len(sys.argv) > 2 else '1,2,4,8'.split(','))):
         ctx.test_set_pairing(share=m)
         ctx.multi_pairing(g1[:96 * 256], g2[:192 * 256])
         best = None
