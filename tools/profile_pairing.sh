@@ -2,7 +2,7 @@
 # rocprofv3 evidence for the pairing row (BASELINE config #5): kernel stats and PMC passes of tools/bench_pairing.py 16.
 # Run on the GPU box via gpurun:  tools/profile_pairing.sh <tag>;  then  python tools/summarize_profile.py gpurun_out/prof_<tag> <tag> pairing 16
 set -e
-TAG=${1:-r02c_pairing_2p16}
+TAG=${1:-r02e_pairing_2p16}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
