@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Time-boxed randomized parity soak on one MI355X: MSM (G1/G2) and multi-pairing through the C ABI against the C
 oracles, over random sizes, window sizes (7..22), scalar formats/distributions, repeated / opposite / infinity bases, resident
-plain and precomputed-table base sets, and (single-threaded runs, through the test build's hook) calls split into several passes.
+plain and precomputed-table base sets, and (single-threaded runs, through the test build's hooks) calls split into several passes and
+pairings with forced pairs-per-accumulator / line-buffer batch sizes.
 Prints a progress line every ~20 s and a final JSON summary; exits non-zero on the first mismatch.
     python tools/soak.py [seconds=300] [seed=1] [threads=1]
 With threads > 1 the same loop runs from several host threads on ONE context (two lanes + exclusive entry points); the batch
@@ -87,7 +88,12 @@ def loop(ctx, rnd, tid):
             for k in range(n):
                 if rnd.random() < 0.03: g1[96 * k:96 * k + 96] = bytes(96)
                 if rnd.random() < 0.03: g2[192 * k:192 * k + 192] = bytes(192)
-            got = ctx.multi_pairing(bytes(g1), bytes(g2))
+            forced = nthreads == 1 and rnd.random() < 0.5   # pairs per accumulator / line-buffer batch as large inputs get them
+            if forced: ctx.test_set_pairing(share=rnd.randrange(1, 9), batch=rnd.choice([0, 0, 100, 777]))
+            try:
+                got = ctx.multi_pairing(bytes(g1), bytes(g2))
+            finally:
+                if forced: ctx.test_set_pairing()
             want = co.multi_pairing(bytes(g1), bytes(g2), ncpu)
             if got != want:
                 print("PAIRING MISMATCH", seed, n); failed.append(1); return
