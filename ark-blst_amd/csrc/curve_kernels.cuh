@@ -43,15 +43,17 @@ __device__ __forceinline__ void load_point(typename C::F::E& x, typename C::F::E
 // left the kernel time unchanged (2.38 vs 2.38 ms), the SIMDs are issue-bound either way.
 // A lane that meets an exceptional pair (same x) leaves the hot loop and finishes on the complete formulas.
 // Output: partial[i] (projective), i = natural item id.
+// Workgroups of ONE wave: a CU refills a wave slot the moment a wave retires instead of waiting for the four slots a 256-thread
+// workgroup needs (same-box A/B at 2^20 points: 2.30 vs 2.33 ms; nothing at 2^24, nothing for G2).
 template <class C>
-__global__ void __launch_bounds__(256, C::OCC) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(64, C::OCC) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                             const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ woff,
                                                             const uint32_t* __restrict__ order, const uint32_t* __restrict__ item_bucket,
                                                             uint32_t nitems, uint32_t logT, uint32_t* __restrict__ partial) {
     using F = typename C::F;
     using FA = typename C::FA;
     using E = typename F::E;
-    uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    uint32_t j = blockIdx.x * 64 + threadIdx.x;
     if (j >= nitems) return;
     uint32_t i = order[j];          // items are processed longest class first; partial[] keeps natural item order
     uint32_t b = item_bucket[i];
@@ -99,13 +101,13 @@ __global__ void __launch_bounds__(256, C::OCC) k_accumulate(const uint32_t* __re
 static __device__ __noinline__ void coop_add_inplace(ec::Proj<CoopF2>& a, const ec::Proj<CoopF2>& b) { ec::proj_add<CoopF2>(a, b); }
 
 template <class C>   // C = G2C (a template so that only the G2 translation unit instantiates it)
-__global__ void __launch_bounds__(256, 2) k_accumulate_g2_coop(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(64, 2) k_accumulate_g2_coop(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                                const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ woff,
                                                                const uint32_t* __restrict__ order, const uint32_t* __restrict__ item_bucket,
                                                                uint32_t nitems, uint32_t logT, uint32_t* __restrict__ partial) {
     using FA = CoopF2A;
     const uint32_t h = threadIdx.x & 1u;
-    uint32_t j = (blockIdx.x * 256 + threadIdx.x) >> 1;
+    uint32_t j = (blockIdx.x * 64 + threadIdx.x) >> 1;
     if (j >= nitems) return;        // pairs never straddle the bound (even block size)
     uint32_t i = order[j];
     uint32_t b = item_bucket[i];

@@ -112,10 +112,10 @@ template <class C>
 void launch_accumulate(hipStream_t s, const uint32_t* bases, const uint32_t* sorted, const uint32_t* offsets, const uint32_t* woff,
                        const uint32_t* order, const uint32_t* item_bucket, uint32_t nitems, uint32_t logT, uint32_t* partial) {
     if constexpr (std::is_same<C, msmk::G2C>::value) {
-        hipLaunchKernelGGL(msmk::k_accumulate_g2_coop<C>, dim3((2 * nitems + 255) / 256), dim3(256), 0, s, bases, sorted, offsets, woff, order,
+        hipLaunchKernelGGL(msmk::k_accumulate_g2_coop<C>, dim3((2 * nitems + 63) / 64), dim3(64), 0, s, bases, sorted, offsets, woff, order,
                            item_bucket, nitems, logT, partial);
     } else {
-        hipLaunchKernelGGL(msmk::k_accumulate<C>, dim3((nitems + 255) / 256), dim3(256), 0, s, bases, sorted, offsets, woff, order, item_bucket,
+        hipLaunchKernelGGL(msmk::k_accumulate<C>, dim3((nitems + 63) / 64), dim3(64), 0, s, bases, sorted, offsets, woff, order, item_bucket,
                            nitems, logT, partial);
     }
 }
