@@ -60,9 +60,17 @@ __global__ void __launch_bounds__(64, C::OCC) k_accumulate(const uint32_t* __res
     uint32_t k = i - woff[b];
     uint32_t e = offsets[b] + (k << logT), bend = offsets[b + 1];
     uint32_t end = e + (1u << logT) < bend ? e + (1u << logT) : bend;
+    // the first entry only initialises the running sum: peeled off the loop, which then has no "still empty" branch
     ec::Xyzz<FA> acc;
-    acc.x = F::zero(); acc.y = F::zero(); acc.zz = F::zero(); acc.zzz = F::zero();
-    bool inf = true;
+    const bool inf = e >= end;
+    {
+        uint32_t ent = inf ? 0u : sorted[e];
+        E x, y;
+        load_point<C>(x, y, bases, ent);
+        y = F::select((ent >> 31) != 0, y, FA::template neg_l<4>(y));
+        acc.x = x; acc.y = FA::norm(y); acc.zz = F::one(); acc.zzz = F::one();   // acc.y must be subtractable: N-form
+        if (!inf) e++;
+    }
     uint32_t nent = e < end ? sorted[e] : 0u;
     while (e < end) {
         uint32_t ent = nent;
@@ -72,12 +80,7 @@ __global__ void __launch_bounds__(64, C::OCC) k_accumulate(const uint32_t* __res
             nent = sorted[e + 1];
         }
         y = F::select((ent >> 31) != 0, y, FA::template neg_l<4>(y));
-        if (inf) {
-            acc.x = x; acc.y = FA::norm(y); acc.zz = F::one(); acc.zzz = F::one();   // acc.y must be subtractable: N-form
-            inf = false;
-        } else if (ec::xyzz_madd<FA>(acc, x, y)) {
-            break;  // exceptional pair at entry e: acc untouched
-        }
+        if (ec::xyzz_madd<FA>(acc, x, y)) break;  // exceptional pair at entry e: acc untouched
         e++;
     }
     ec::Proj<F> out = ec::proj_inf<F>();
@@ -96,9 +99,34 @@ __global__ void __launch_bounds__(64, C::OCC) k_accumulate(const uint32_t* __res
 
 // G2 accumulate with TWO lanes per work item (CoopF2A: the even lane holds c0 and the odd lane c1 of every Fp2 value; a product
 // exchanges the partner's components by DPP and is one fused reduction per lane).  Same schedule, same entries and the same
-// formulas as k_accumulate<G2C>; the accumulator is 4 x 14 registers per lane instead of 8 x 14, so the hot loop runs without
-// scratch.  Cold path (exceptional pairs): complete additions on the same lane pair through ONE out-of-line body.
+// formulas as k_accumulate<G2C>; the accumulator is 4 x 14 registers per lane instead of 8 x 14.  The hot loop runs without
+// scratch since round 3 (product-scanning multiplier, first entry peeled, tail out of line: 35 spilled registers -> 0, which
+// tests/test_cabi.py::test_hot_kernels_do_not_spill reads off the shipped code object).  Cold path (exceptional pairs):
+// complete additions on the same lane pair through ONE out-of-line body.
 static __device__ __noinline__ void coop_add_inplace(ec::Proj<CoopF2>& a, const ec::Proj<CoopF2>& b) { ec::proj_add<CoopF2>(a, b); }
+
+// Everything after the hot loop of k_accumulate_g2_coop as ONE out-of-line body: XYZZ -> projective, the cold path (complete
+// additions for the entries from an exceptional pair on; never taken on random inputs) and the store.  Out of line so that none
+// of its values (a second point, the projective sum, the shared-call operands) is live inside the hot loop: with the tail
+// inlined the loop spilled 35 registers (2.8 GB of scratch writes per launch at 2^20 points, profiles/r02c_g2_2p20_pmc_summary.json).
+static __device__ __noinline__ void g2_coop_finish(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, uint32_t e,
+                                                   uint32_t end, bool inf, const ec::Xyzz<CoopF2>& acc, uint32_t* __restrict__ o) {
+    const uint32_t h = threadIdx.x & 1u;
+    ec::Proj<CoopF2> out = ec::proj_inf<CoopF2>();
+    if (!inf) out = ec::xyzz_to_proj<CoopF2>(acc);
+    while (e < end) {
+        uint32_t ent = sorted[e];
+        Fp x, y;
+        const uint32_t* p = bases + (size_t)(ent & 0x7fffffffu) * G2_PT_WORDS + 16 * h;
+        load_fp16(x, p);
+        load_fp16(y, p + 32);
+        y = fp28::fp_select((ent >> 31) != 0, y, fp28::fp_neg<4>(y));
+        ec::Proj<CoopF2> q = ec::proj_from_affine<CoopF2>(x, y);
+        coop_add_inplace(out, q);
+        e++;
+    }
+    store_fp16(o, out.x); store_fp16(o + 32, out.y); store_fp16(o + 64, out.z);   // x | y | z, each (c0, c1) in 16-word slots
+}
 
 template <class C>   // C = G2C (a template so that only the G2 translation unit instantiates it)
 __global__ void __launch_bounds__(64, 2) k_accumulate_g2_coop(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
@@ -119,9 +147,18 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_g2_coop(const uint32_t* __
         load_fp16(x, p);
         load_fp16(y, p + 32);
     };
+    // the first entry only initialises the running sum: peeled off the loop (inside it the lane-dependent constant of
+    // FA::one() was hoisted into 14 loop-invariant registers, which the loop then spilled)
     ec::Xyzz<FA> acc;
-    acc.x = FA::zero(); acc.y = FA::zero(); acc.zz = FA::zero(); acc.zzz = FA::zero();
-    bool inf = true;
+    const bool inf = e >= end;
+    {
+        uint32_t ent = inf ? 0u : sorted[e];
+        Fp x, y;
+        load_comp(x, y, ent);
+        y = fp28::fp_select((ent >> 31) != 0, y, fp28::fp_neg<4>(y));
+        acc.x = x; acc.y = y; acc.zz = FA::one(); acc.zzz = FA::one();
+        if (!inf) e++;
+    }
     uint32_t nent = e < end ? sorted[e] : 0u;
     while (e < end) {
         uint32_t ent = nent;
@@ -131,27 +168,10 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_g2_coop(const uint32_t* __
             nent = sorted[e + 1];
         }
         y = fp28::fp_select((ent >> 31) != 0, y, fp28::fp_neg<4>(y));
-        if (inf) {
-            acc.x = x; acc.y = y; acc.zz = FA::one(); acc.zzz = FA::one();
-            inf = false;
-        } else if (ec::xyzz_madd<FA>(acc, x, y)) {
-            break;  // exceptional pair at entry e (pair-wide decision): acc untouched
-        }
+        if (ec::xyzz_madd<FA>(acc, x, y)) break;  // exceptional pair at entry e (pair-wide decision): acc untouched
         e++;
     }
-    ec::Proj<CoopF2> out = ec::proj_inf<CoopF2>();
-    if (!inf) out = ec::xyzz_to_proj<CoopF2>(reinterpret_cast<const ec::Xyzz<CoopF2>&>(acc));
-    while (e < end) {  // cold path (never taken on random inputs): complete additions
-        uint32_t ent = sorted[e];
-        Fp x, y;
-        load_comp(x, y, ent);
-        y = fp28::fp_select((ent >> 31) != 0, y, fp28::fp_neg<4>(y));
-        ec::Proj<CoopF2> q = ec::proj_from_affine<CoopF2>(x, y);
-        coop_add_inplace(out, q);
-        e++;
-    }
-    uint32_t* o = partial + (size_t)i * G2_BK_WORDS + 16 * h;   // x | y | z, each (c0, c1) in 16-word slots
-    store_fp16(o, out.x); store_fp16(o + 32, out.y); store_fp16(o + 64, out.z);
+    g2_coop_finish(bases, sorted, e, end, inf, reinterpret_cast<const ec::Xyzz<CoopF2>&>(acc), partial + (size_t)i * G2_BK_WORDS + 16 * h);
 }
 
 // One binary-tree level of the per-bucket merge of split buckets: partial[i] += partial[i + d] for the items whose

@@ -64,9 +64,10 @@ struct FpOps {
 // instruction cache, and the compiler schedules across multiplication boundaries.  Everything that is not the hot
 // loop keeps the shared call (code size: a complete addition is 12 multiplications).
 struct FpOpsInline : FpOps {
-    static FP_HD E mul(const E& a, const E& b) { return fp28::fp_mul(a, b); }
-    static FP_HD E sqr(const E& a) { return fp28::fp_sqr(a); }
-    static FP_HD E mul2add(const E& a, const E& b, const E& c, const E& d) { return fp28::fp_mul2add(a, b, c, d); }
+    // operand-scanning form of the multiplier (fp28.cuh): 2 % faster than product scanning in this one loop
+    static FP_HD E mul(const E& a, const E& b) { return fp28::fp_mul_os(a, b); }
+    static FP_HD E sqr(const E& a) { return fp28::fp_sqr_os(a); }
+    static FP_HD E mul2add(const E& a, const E& b, const E& c, const E& d) { return fp28::fp_mul2add_os(a, b, c, d); }
     // truly lazy linear operations (no carry pass); limb bounds proved in tools/bounds_check.py check_madd_lazy()
     static FP_HD E add_l(const E& a, const E& b) { return fp28::fp_add_lazy(a, b); }
     template <int K>
@@ -75,6 +76,13 @@ struct FpOpsInline : FpOps {
     static FP_HD E neg_l(const E& a) { return fp28::fp_sub_lazy<K>(fp28::fp_zero(), a); }
     static FP_HD E sub8_wide(const E& a, const E& b) { return fp28::fp_sub8_lazy_wide(a, b); }
     static FP_HD E norm(const E& a) { return fp28::fp_norm(a); }
+};
+
+// The same with the product-scanning multiplier: the serial bucket reduction (k_reduce_serial)
+struct FpOpsInlinePS : FpOpsInline {
+    static FP_HD E mul(const E& a, const E& b) { return fp28::fp_mul(a, b); }
+    static FP_HD E sqr(const E& a) { return fp28::fp_sqr(a); }
+    static FP_HD E mul2add(const E& a, const E& b, const E& c, const E& d) { return fp28::fp_mul2add(a, b, c, d); }
 };
 
 // ------------------------------------------------------------------------------------------------

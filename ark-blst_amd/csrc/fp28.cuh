@@ -17,6 +17,7 @@
 //   Montgomery multiplication accepts any a, b with a*b < 2^392 * p (i.e. a, b < ~50p) and returns < 2p.
 #pragma once
 #include <cstdint>
+#include <type_traits>
 #include "fp28_consts.h"
 
 #if defined(__HIPCC__)
@@ -142,6 +143,27 @@ FP_HD Fp fp_select(bool take_b, const Fp& a, const Fp& b) {
     return r;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Montgomery multiplication, two forms with the same multiply-adds and the same column sums (bit-identical results):
+//
+//   product scanning (FIPS; fp_mul, fp_sqr, fp_mul2add, fp_mul4add — the default): the columns of the product are produced one
+//     after the other in ONE 64-bit accumulator, the reduction's m_i follows from column i the moment it is complete and the carry
+//     into the next column is a shift of the accumulator itself.  2 live registers of column state instead of 56: the G2
+//     accumulate loop spilled 35 registers with the wide form (2.8 GB of scratch writes per launch at 2^20 points), it runs
+//     without scratch and 5 % faster with this one; the lane-pair and lone-wave kernels are unchanged or slightly faster.
+//   operand scanning (fp_mul_os, fp_sqr_os, fp_mul2add_os): 28 64-bit columns live, every product row and every reduction row
+//     a run of independent multiply-adds.  Kept for the G1 accumulate hot loop only, where it measures 2 % faster (same-box A/B,
+//     2^20 points: 2.34 vs 2.39 ms) — that loop has the registers, and the compiler interleaves the rows of neighbouring
+//     multiplications.
+//
+// Measured and not kept (round 3, profiles/r03_ab_multiplier.txt): the product-scanning chain written with inline-assembly
+// v_mad_u64_u32 whose addend IS the accumulator.  From plain C++ the compiler re-associates every column into (fresh chain
+// from zero) + (carry of the previous column) and spends a v_lshl_add_u64 per column on the last addition (235 per mixed
+// addition); the assembly form removes those, but the hazard recogniser then puts an s_nop behind every inline-assembly
+// instruction whose result is consumed next (it must assume a dst_sel forwarding hazard): 3378 s_nop per mixed addition, the
+// same 2.33 ms for the two-wave accumulate kernel and 4-30 % SLOWER lone-wave kernels (reduce, combine, G2 reduce).
+// ------------------------------------------------------------------------------------------------
+
 // Montgomery reduction of 28 64-bit columns (each < 2^63) holding a product < 2^392 * p.  Returns exact limbs, < 2p.
 FP_HD Fp fp_mont_reduce(uint64_t (&c)[2 * NL]) {
 #pragma unroll
@@ -165,8 +187,49 @@ FP_HD Fp fp_mont_reduce(uint64_t (&c)[2 * NL]) {
     return r;
 }
 
+template <int I, int N, class Fn>
+FP_HD void fp_static_for(Fn&& f) {   // f(integral_constant<int, I>) for I .. N-1: every index below is a compile-time constant
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        fp_static_for<I + 1, N>(f);
+    }
+}
+// col(K, acc) adds every product term of column K (K = 0 .. 26) into acc; terms + 14 reduction terms + carry stay below 2^63.
+template <class ColFn>
+FP_HD Fp fp_fips(ColFn col) {
+    uint32_t m[NL];
+    uint64_t acc = 0;
+    Fp r;
+    fp_static_for<0, 2 * NL>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < 2 * NL - 1) col(ic, acc);
+        constexpr int j0 = i < NL ? 0 : i - NL + 1, j1 = i < NL ? i : NL;   // reduction terms m_j P_{i-j}, j in [j0, j1)
+#pragma unroll
+        for (int j = j0; j < j1; j++) acc += (uint64_t)m[j] * P[i - j];
+        if constexpr (i < NL) {
+            m[i] = ((uint32_t)acc * PINV) & MASK;
+            acc += (uint64_t)m[i] * P[0];   // the low 28 bits are zero now
+        } else {
+            r.l[i - NL] = (uint32_t)acc & MASK;
+        }
+        acc >>= W;
+    });
+    r.l[NL - 1] |= (uint32_t)acc << W;  // value < 2p < 2^382: nothing is carried out of limb 13
+    return r;
+}
+// the terms a_i b_j, i + j = K, of one product
+template <int K>
+FP_HD void fp_col(uint64_t& acc, const Fp& a, const Fp& b) {
+    constexpr int i0 = K < NL ? 0 : K - NL + 1, i1 = K < NL ? K + 1 : NL;
+#pragma unroll
+    for (int i = i0; i < i1; i++) acc += (uint64_t)a.l[i] * b.l[K - i];
+}
+
 // r = a*b / 2^392 mod p.  a, b in N-form (limbs < 2^29.5 are still safe), a*b < 2^392 p.  Result N-form, < 2p.
 FP_HD Fp fp_mul(const Fp& a, const Fp& b) {
+    return fp_fips([&](auto kc, uint64_t& acc) { fp_col<decltype(kc)::value>(acc, a, b); });
+}
+FP_HD Fp fp_mul_os(const Fp& a, const Fp& b) {
     uint64_t c[2 * NL];
 #pragma unroll
     for (int k = 0; k < 2 * NL; k++) c[k] = 0;
@@ -181,6 +244,13 @@ FP_HD Fp fp_mul(const Fp& a, const Fp& b) {
 // r = (a*b + c*d) / 2^392 mod p with ONE Montgomery reduction (the two products share the 64-bit columns:
 // 28 + 14 terms of < 2^56 stay below 2^62).  Needs a*b + c*d < 2^392 p.  Saves a 210-MAD reduction per use.
 FP_HD Fp fp_mul2add(const Fp& a, const Fp& b, const Fp& c2, const Fp& d) {
+    return fp_fips([&](auto kc, uint64_t& acc) {
+        constexpr int k = decltype(kc)::value;
+        fp_col<k>(acc, a, b);
+        fp_col<k>(acc, c2, d);
+    });
+}
+FP_HD Fp fp_mul2add_os(const Fp& a, const Fp& b, const Fp& c2, const Fp& d) {
     uint64_t c[2 * NL];
 #pragma unroll
     for (int k = 0; k < 2 * NL; k++) c[k] = 0;
@@ -199,45 +269,49 @@ FP_HD Fp fp_mul2add(const Fp& a, const Fp& b, const Fp& c2, const Fp& d) {
 
 // r = (a*b + c*d + e*f + g*h) / 2^392 mod p, one reduction (Fp2 fused multiply-add): 56 + 14 terms < 2^62.2.
 FP_HD Fp fp_mul4add(const Fp& a, const Fp& b, const Fp& c2, const Fp& d, const Fp& e, const Fp& f, const Fp& g, const Fp& h) {
-    uint64_t c[2 * NL];
-#pragma unroll
-    for (int k = 0; k < 2 * NL; k++) c[k] = 0;
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-#pragma unroll
-        for (int j = 0; j < NL; j++) {
-            c[i + j] += (uint64_t)a.l[i] * b.l[j];
-            c[i + j] += (uint64_t)c2.l[i] * d.l[j];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-#pragma unroll
-        for (int j = 0; j < NL; j++) {
-            c[i + j] += (uint64_t)e.l[i] * f.l[j];
-            c[i + j] += (uint64_t)g.l[i] * h.l[j];
-        }
-    }
-    return fp_mont_reduce(c);
+    return fp_fips([&](auto kc, uint64_t& acc) {
+        constexpr int k = decltype(kc)::value;
+        fp_col<k>(acc, a, b);
+        fp_col<k>(acc, c2, d);
+        fp_col<k>(acc, e, f);
+        fp_col<k>(acc, g, h);
+    });
 }
 
-// The shared multiplier instance.  On the device this is a REAL function (by-value args travel in v0..v27, the
+// The shared multiplier instance.  The out-of-line bodies keep the operand-scanning form: register pressure is no concern
+// inside a function of its own, and with product-scanning bodies behind these by-value signatures the test-only single-lane
+// Miller kernel (4 KB of scratch per lane, ~10^3 calls) stopped agreeing with the production path on the GPU while the same
+// source agrees with the oracle on the host (tests/host/pairing_host_check.cpp) — not root-caused, so the bodies that six
+// soak seeds have exercised stay as they were.
+// On the device this is a REAL function (by-value args travel in v0..v27, the
 // result in v0..v13): one ~4.5 KB body per kernel instead of one per use keeps bucket kernels inside the
 // 64 KB instruction cache (see ec.cuh).  On the host it is plain inline code.
 #if defined(__HIP_DEVICE_COMPILE__)
-static __device__ __noinline__ Fp fp_mul_call(Fp a, Fp b) { return fp_mul(a, b); }
+static __device__ __noinline__ Fp fp_mul_call(Fp a, Fp b) { return fp_mul_os(a, b); }
 #else
-FP_HD_NOINLINE Fp fp_mul_call(const Fp& a, const Fp& b) { return fp_mul(a, b); }
+FP_HD_NOINLINE Fp fp_mul_call(const Fp& a, const Fp& b) { return fp_mul_os(a, b); }
 #endif
 
 // r = a^2 / 2^392 mod p (105 products instead of 196)
 FP_HD Fp fp_sqr(const Fp& a) {
-    uint64_t c[2 * NL];
-#pragma unroll
-    for (int k = 0; k < 2 * NL; k++) c[k] = 0;
     uint32_t a2[NL];
 #pragma unroll
     for (int k = 0; k < NL; k++) a2[k] = a.l[k] << 1;
+    return fp_fips([&](auto kc, uint64_t& acc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int i0 = k < NL ? 0 : k - NL + 1;   // pairs i < j = k - i, j < NL; the square a_{k/2}^2 for even k
+#pragma unroll
+        for (int i = i0; 2 * i < k; i++) acc += (uint64_t)a.l[i] * a2[k - i];
+        if constexpr (k % 2 == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+    });
+}
+FP_HD Fp fp_sqr_os(const Fp& a) {
+    uint32_t a2[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) a2[k] = a.l[k] << 1;
+    uint64_t c[2 * NL];
+#pragma unroll
+    for (int k = 0; k < 2 * NL; k++) c[k] = 0;
 #pragma unroll
     for (int i = 0; i < NL; i++) {
         c[2 * i] += (uint64_t)a.l[i] * a.l[i];
@@ -249,16 +323,16 @@ FP_HD Fp fp_sqr(const Fp& a) {
 
 // shared fused two-product instance (Fp2 arithmetic outside the hot loop)
 #if defined(__HIP_DEVICE_COMPILE__)
-static __device__ __noinline__ Fp fp_mul2add_call(Fp a, Fp b, Fp c, Fp d) { return fp_mul2add(a, b, c, d); }
+static __device__ __noinline__ Fp fp_mul2add_call(Fp a, Fp b, Fp c, Fp d) { return fp_mul2add_os(a, b, c, d); }
 #else
-FP_HD_NOINLINE Fp fp_mul2add_call(const Fp& a, const Fp& b, const Fp& c, const Fp& d) { return fp_mul2add(a, b, c, d); }
+FP_HD_NOINLINE Fp fp_mul2add_call(const Fp& a, const Fp& b, const Fp& c, const Fp& d) { return fp_mul2add_os(a, b, c, d); }
 #endif
 
 // shared squaring instance (see fp_mul_call)
 #if defined(__HIP_DEVICE_COMPILE__)
-static __device__ __noinline__ Fp fp_sqr_call(Fp a) { return fp_sqr(a); }
+static __device__ __noinline__ Fp fp_sqr_call(Fp a) { return fp_sqr_os(a); }
 #else
-FP_HD_NOINLINE Fp fp_sqr_call(const Fp& a) { return fp_sqr(a); }
+FP_HD_NOINLINE Fp fp_sqr_call(const Fp& a) { return fp_sqr_os(a); }
 #endif
 
 // Exact carry propagation of an N-form value that fits 392 bits: limbs -> [0, 2^28), l[13] holds the rest.

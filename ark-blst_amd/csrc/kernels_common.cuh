@@ -95,7 +95,7 @@ template <> struct ElemIO<ec::Fp2> {
 struct G1C {                         // /root/reference/src/g1.rs: G1Affine / G1Projective over Fp
     using F = ec::FpOps;             // shared-call multiplier: everything outside the hot loop
     using FA = ec::FpOpsInline;      // accumulate hot loop
-    using FR = ec::FpOpsInline;      // the single addition site of the reduce loop
+    using FR = ec::FpOpsInlinePS;    // the single addition site of the serial reduce loop: product-scanning multiplier (2.99 vs 3.13 ms at 2^24)
     static constexpr int OCC = 2;    // waves per SIMD the accumulate kernel is built for
 };
 struct G2C {                         // /root/reference/src/g2.rs: G2Affine / G2Projective over Fp2

@@ -324,8 +324,10 @@ __global__ void __launch_bounds__(64, 2) k_miller_accumulate(const uint32_t* __r
 }
 
 // One level of the multiplication tree, six lanes per output: out[g] = prod in[g*K .. g*K+K).  Same scheme as
-// k_miller_accumulate: the running product's coefficients in LDS, the factor's coefficients read from HBM.
-__global__ void __launch_bounds__(64, 2) k_fp12_prod(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+// k_miller_accumulate: the running product's coefficients in LDS, the factor's coefficients read from HBM.  Built for one wave per
+// SIMD: a level has at most a few hundred waves (468 for the 9363 Miller values of 2^16 pairs), and capped at 256 registers the
+// kernel spilled 29 of them.
+__global__ void __launch_bounds__(64, 1) k_fp12_prod(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
     __shared__ uint32_t fs[(MILLER_GROUPS + 1) * 6 * LDS_COEFF_WORDS];
     const uint32_t lane = threadIdx.x;
     const uint32_t grp = lane / 6, k = lane - grp * 6;

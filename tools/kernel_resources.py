@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Per-kernel register / scratch / LDS figures of the SHIPPED library, read from the gfx950 code objects inside it.
+
+    python tools/kernel_resources.py [path/to/lib.so] [--json]
+
+The .so carries one clang offload bundle per translation unit in its .hip_fatbin section; each bundle holds one gfx950 ELF
+whose NT_AMDGPU_METADATA note lists, per kernel, .vgpr_count / .agpr_count / .vgpr_spill_count / .sgpr_spill_count /
+.private_segment_fixed_size (scratch bytes per lane) / .group_segment_fixed_size (LDS bytes per workgroup).  This is what
+`llvm-readelf --notes` prints; tests/test_cabi.py fails the CPU suite when a hot kernel reports spills, so that DESIGN.md
+cannot drift from the binary.
+"""
+from __future__ import annotations
+
+import json
+import os
+import re
+import struct
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _fatbin(lib: str, tmp: str) -> bytes:
+    out = os.path.join(tmp, "fat.bin")
+    subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", f".hip_fatbin={out}", lib, os.path.join(tmp, "copy.so")])
+    with open(out, "rb") as f:
+        return f.read()
+
+
+def code_objects(lib: str, tmp: str) -> list[str]:
+    """Write every gfx950 ELF of the library into tmp; returns their paths."""
+    data = _fatbin(lib, tmp)
+    paths = []
+    for m in re.finditer(re.escape(MAGIC), data):
+        base = m.start()
+        (nent,) = struct.unpack_from("<Q", data, base + len(MAGIC))
+        pos = base + len(MAGIC) + 8
+        for _ in range(nent):
+            off, size, tlen = struct.unpack_from("<QQQ", data, pos)
+            triple = data[pos + 24:pos + 24 + tlen].decode()
+            pos += 24 + tlen
+            if "gfx950" in triple and size:
+                p = os.path.join(tmp, f"co{len(paths)}.elf")
+                with open(p, "wb") as f:
+                    f.write(data[base + off:base + off + size])
+                paths.append(p)
+    return paths
+
+
+_KEYS = (".vgpr_count", ".agpr_count", ".sgpr_count", ".vgpr_spill_count", ".sgpr_spill_count", ".private_segment_fixed_size",
+         ".group_segment_fixed_size", ".max_flat_workgroup_size")
+
+
+def kernels_of(elf: str) -> dict[str, dict[str, int]]:
+    txt = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", elf], capture_output=True, text=True, check=True).stdout
+    out: dict[str, dict[str, int]] = {}
+    cur: dict[str, int] | None = None
+    for line in txt.splitlines():
+        s = line.strip()
+        if s.startswith("- .agpr_count") or s.startswith("- .args"):
+            cur = {}
+        if cur is None:
+            continue
+        m = re.match(r"-?\s*(\.[a-z_]+):\s+(\S+)", s)
+        if not m:
+            continue
+        k, v = m.group(1), m.group(2)
+        if k in _KEYS:
+            cur[k[1:]] = int(v)
+        elif k == ".name":
+            out[v.strip("'\"")] = cur
+    return out
+
+
+def demangle(names: list[str]) -> dict[str, str]:
+    r = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True, check=True)
+    return dict(zip(names, r.stdout.splitlines()))
+
+
+def resources(lib: str | None = None) -> dict[str, dict[str, int]]:
+    lib = lib or os.path.join(ROOT, "ark-blst_amd", "lib", "libarkblst_amd.so")
+    res: dict[str, dict[str, int]] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for elf in code_objects(lib, tmp):
+            ks = kernels_of(elf)
+            names = demangle(list(ks))
+            for raw, v in ks.items():
+                res[names[raw]] = v
+    return res
+
+
+# kernels whose inner loops must run without register spills: substrings of the demangled name
+HOT = ("msmk::k_accumulate", "msmk::k_reduce_", "msmk::k_combine", "msmk::k_miller_", "msmk::k_fp12_prod")
+
+
+def is_hot(name: str) -> bool:
+    return any(h in name for h in HOT)
+
+
+def main() -> None:
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    res = resources(args[0] if args else None)
+    if "--json" in sys.argv:
+        print(json.dumps(res, indent=1, sort_keys=True))
+        return
+    print(f"{'kernel':100s} vgpr agpr  spill scratch    lds")
+    for name in sorted(res):
+        v = res[name]
+        hot = "*" if is_hot(name) else " "
+        print(f"{hot}{name[:99]:99s} {v.get('vgpr_count', 0):4d} {v.get('agpr_count', 0):4d} {v.get('vgpr_spill_count', 0):6d} "
+              f"{v.get('private_segment_fixed_size', 0):7d} {v.get('group_segment_fixed_size', 0):6d}")
+
+
+if __name__ == "__main__":
+    main()
