@@ -14,7 +14,9 @@ from .binding import (  # noqa: F401
     MsmError,
     SCALAR_CANONICAL,
     SCALAR_MONTGOMERY,
+    MAX_WINDOWS,
     final_exponentiation,
+    fold_windows,
     test_plan,
     g1_sum,
     g2_sum,

@@ -8,6 +8,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SCALAR_CANONICAL, SCALAR_MONTGOMERY = 0, 1
 G1_AFF, G1_JAC, G2_AFF, G2_JAC = 96, 144, 192, 288
 FP12 = 576
+MAX_WINDOWS = 37   # MI_MAX_WINDOWS
+
+
+class WindowInfo(C.Structure):
+    _fields_ = [("window_bits", C.c_uint32), ("num_windows", C.c_uint32)]
 
 
 class MsmError(RuntimeError):
@@ -21,6 +26,11 @@ class Profile(C.Structure):
                                           "reduce_ms", "combine_ms", "d2h_ms", "host_fold_ms", "total_ms")] + [
         ("window_bits", C.c_uint32), ("num_windows", C.c_uint32), ("n", C.c_uint64), ("accumulate_adds", C.c_uint64),
         ("work_items", C.c_uint32), ("max_items_per_bucket", C.c_uint32)]
+
+
+class PairingProfile(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("h2d_ms", "lines_ms", "accumulate_ms", "miller_ms", "tree_ms", "host_ms", "total_ms")] + [
+        ("n", C.c_uint64), ("pairs_per_accumulator", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 def lib_path(test_hooks: bool = False) -> str:
@@ -50,6 +60,8 @@ def load_library(test_hooks: bool = False):
             getattr(L, f"mi_msm_{g}").argtypes = [vp, vp, vp, sz, u, vp]
             getattr(L, f"mi_msm_{g}_device").argtypes = [vp, vp, sz, u, vp]
             getattr(L, f"mi_{g}_sum").argtypes = [vp, sz, vp]
+            getattr(L, f"mi_msm_{g}_device_windows").argtypes = [vp, vp, sz, u, vp, C.POINTER(WindowInfo)]
+            getattr(L, f"mi_{g}_fold_windows").argtypes = [vp, sz, sz, C.POINTER(WindowInfo), vp]
             getattr(L, f"mi_msm_{g}_batch").argtypes = [vp, C.POINTER(C.c_char_p), sz, sz, u, vp]
             getattr(L, f"mi_msm_{g}_batch_device").argtypes = [vp, C.POINTER(vp), sz, sz, u, vp]
             getattr(L, f"mi_{g}_normalize_batch").argtypes = [vp, vp, sz, vp]
@@ -61,6 +73,7 @@ def load_library(test_hooks: bool = False):
         L.mi_final_exponentiation.argtypes = [vp, vp]
         L.mi_msm_set_window_bits.argtypes = [vp, u]
         L.mi_msm_last_profile.argtypes = [vp, C.POINTER(Profile)]
+        L.mi_pairing_last_profile.argtypes = [vp, C.POINTER(PairingProfile)]
         L.mi_msm_last_error.argtypes = [vp]
         L.mi_msm_last_error.restype = C.c_char_p
         L.mi_msm_strerror.argtypes = [i]
@@ -71,6 +84,7 @@ def load_library(test_hooks: bool = False):
             L.mi_test_set_max_part.argtypes = [vp, sz]
             L.mi_test_fail_allocs.argtypes = [i]
             L.mi_test_fail_allocs.restype = None
+            L.mi_test_set_no_peer.argtypes = [vp, i]
             L.mi_test_plan.argtypes = [sz, u, i, i, sz, C.POINTER(C.c_uint32)]
         _LIBS[test_hooks] = L
     return _LIBS[test_hooks]
@@ -172,6 +186,14 @@ class Context:
                     f"mi_msm_{group}_device")
         return out.raw
 
+    def msm_device_windows(self, group: str, d_scalars_ptr: int, n: int, scalar_fmt: int, d_out_ptr: int):
+        """The pipeline of msm_device up to the per-window sums, left in the caller's DEVICE buffer (room for MAX_WINDOWS points):
+        the exchange step of a one-process-per-GPU deployment starts from device memory.  Returns (window_bits, num_windows)."""
+        info = WindowInfo()
+        self._check(getattr(self._L, f"mi_msm_{group}_device_windows")(self._h, C.c_void_p(d_scalars_ptr), n, scalar_fmt,
+                                                                        C.c_void_p(d_out_ptr), C.byref(info)), f"mi_msm_{group}_device_windows")
+        return int(info.window_bits), int(info.num_windows)
+
     def normalize_batch(self, group: str, jac: bytes) -> bytes:
         """CurveGroup::normalize_batch: packed Jacobian points -> packed affine points (infinity -> zeros)."""
         jb, ab = (G1_JAC, G1_AFF) if group == "g1" else (G2_JAC, G2_AFF)
@@ -225,6 +247,11 @@ class Context:
         self._check(self._L.mi_msm_last_profile(self._h, C.byref(p)), "mi_msm_last_profile")
         return {f: getattr(p, f) for f, _ in Profile._fields_}
 
+    def pairing_profile(self) -> dict:
+        p = PairingProfile()
+        self._check(self._L.mi_pairing_last_profile(self._h, C.byref(p)), "mi_pairing_last_profile")
+        return {f: getattr(p, f) for f, _ in PairingProfile._fields_ if f != "reserved"}
+
     # ---- test build only (Context(..., test_hooks=True))
     def test_fp_op(self, op: int, a: bytes, b: bytes) -> bytes:
         n = len(a) // 48
@@ -240,6 +267,9 @@ class Context:
 
     def test_fail_allocs(self, count: int):
         self._L.mi_test_fail_allocs(count)
+
+    def test_set_no_peer(self, no_peer: bool):
+        self._check(self._L.mi_test_set_no_peer(self._h, int(no_peer)), "mi_test_set_no_peer")
 
 
 def test_plan(n: int, forced_c: int = 0, group: str = "g1", shared: bool = False, stride: int = 0) -> dict:
@@ -274,6 +304,20 @@ def _sum(group: str, partials) -> bytes:
     rc = getattr(L, f"mi_{group}_sum")(blob, len(blob) // size, out)
     if rc != 0:
         raise MsmError(rc, f"mi_{group}_sum")
+    return out.raw
+
+
+def fold_windows(group: str, windows, n_ranks: int, rank_stride: int, window_bits: int, num_windows: int) -> bytes:
+    """Host fold of gathered per-window sums (mi_g{1,2}_fold_windows): windows[r * rank_stride + w], ranks added in index order,
+    Horner over the windows.  `windows`: bytes-like of n_ranks * rank_stride Jacobian points."""
+    size = G1_JAC if group == "g1" else G2_JAC
+    p, keep = _buf(windows)
+    assert memoryview(windows).nbytes >= n_ranks * rank_stride * size or n_ranks * num_windows == 0
+    info = WindowInfo(window_bits, num_windows)
+    out = C.create_string_buffer(size)
+    rc = getattr(load_library(), f"mi_{group}_fold_windows")(p, n_ranks, rank_stride, C.byref(info), out)
+    if rc != 0:
+        raise MsmError(rc, f"mi_{group}_fold_windows")
     return out.raw
 
 

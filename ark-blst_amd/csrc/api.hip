@@ -19,6 +19,29 @@ bool cpu_ok() {
     return true;
 #endif
 }
+
+// Host fold of gathered window sums: out = sum_w 2^(c w) sum_r windows[r * rank_stride + w] (Horner over the windows; the
+// doubling chain is the one thing the GPU cannot do in time).  Deterministic: ranks are added in index order.
+template <class J, class Raw>
+int fold_windows(const Raw* windows, size_t n_ranks, size_t rank_stride, const mi_window_info* info, Raw* out) {
+    if (!out || !info || (n_ranks && info->num_windows && !windows)) return MI_E_INVALID;
+    if (info->num_windows > MI_MAX_WINDOWS || rank_stride < info->num_windows ||
+        (info->num_windows && (info->window_bits < 1 || info->window_bits > 32)))
+        return MI_E_INVALID;
+    if (!cpu_ok()) return MI_E_UNSUPPORTED;
+    static_assert(sizeof(J) == sizeof(Raw), "host Jacobian type must be the reference's layout");
+    J r = J::inf();
+    for (int w = (int)info->num_windows - 1; w >= 0; w--) {
+        r = r.dbl_n(info->window_bits);
+        for (size_t k = 0; k < n_ranks; k++) {
+            J p;
+            memcpy(&p, &windows[k * rank_stride + (size_t)w], sizeof p);
+            r = r.add(p);
+        }
+    }
+    memcpy(out, &r, sizeof r);
+    return MI_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -54,14 +77,20 @@ int mi_msm_init(mi_ctx** out, const int* device_ids, int n_devices) {
             // one persistent host thread per device and lane (nothing is spawned per call); peer access so that a device can read
             // its shard of a scalar vector that lives on another device of the context (xGMI)
             for (int l = 0; l < NLANES; l++) ctx->workers[l].reset(new DeviceWorkers((size_t)n_devices));
+            // peer_ok[a][b]: device a may dereference memory of device b.  Recorded, not assumed: without peer access the shard of
+            // a device-resident scalar vector is staged by a peer copy instead (msm_impl), never read through a faulting pointer
+            ctx->peer_ok.assign((size_t)n_devices * n_devices, 0);
             for (int a = 0; a < n_devices; a++)
                 for (int b = 0; b < n_devices; b++) {
                     int da = ctx->devs[a].dev, db = ctx->devs[b].dev, can = 0;
-                    if (da == db) continue;
+                    if (da == db) { ctx->peer_ok[(size_t)a * n_devices + b] = 1; continue; }
                     if (hipDeviceCanAccessPeer(&can, da, db) == hipSuccess && can) {
                         (void)hipSetDevice(da);
                         hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+                        if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) ctx->peer_ok[(size_t)a * n_devices + b] = 1;
                         if (e != hipSuccess) (void)hipGetLastError();   // already enabled (by torch, or a second context): fine
+                    } else {
+                        (void)hipGetLastError();
                     }
                 }
         }
@@ -77,6 +106,7 @@ int mi_msm_init(mi_ctx** out, const int* device_ids, int n_devices) {
 
 void mi_msm_destroy(mi_ctx* ctx) {
     if (!ctx) return;
+    ctx->batch_workers.reset();
     for (int l = 0; l < NLANES; l++) ctx->workers[l].reset();
     for (std::vector<DevState>* lane : {&ctx->devs, &ctx->devs_b})
         for (auto& d : *lane) {
@@ -118,6 +148,19 @@ int mi_msm_g1_device(mi_ctx* ctx, const void* d_scalars, size_t n, unsigned scal
 }
 int mi_msm_g2_device(mi_ctx* ctx, const void* d_scalars, size_t n, unsigned scalar_fmt, mi_g2* out) {
     return g2_msm(ctx, nullptr, static_cast<const uint8_t*>(d_scalars), true, n, scalar_fmt, out);
+}
+
+int mi_msm_g1_device_windows(mi_ctx* ctx, const void* d_scalars, size_t n, unsigned scalar_fmt, void* d_out_windows, mi_window_info* info) {
+    return g1_msm_windows(ctx, static_cast<const uint8_t*>(d_scalars), n, scalar_fmt, d_out_windows, info);
+}
+int mi_msm_g2_device_windows(mi_ctx* ctx, const void* d_scalars, size_t n, unsigned scalar_fmt, void* d_out_windows, mi_window_info* info) {
+    return g2_msm_windows(ctx, static_cast<const uint8_t*>(d_scalars), n, scalar_fmt, d_out_windows, info);
+}
+int mi_g1_fold_windows(const mi_g1* windows, size_t n_ranks, size_t rank_stride, const mi_window_info* info, mi_g1* out) {
+    return fold_windows<hostec::G1>(windows, n_ranks, rank_stride, info, out);
+}
+int mi_g2_fold_windows(const mi_g2* windows, size_t n_ranks, size_t rank_stride, const mi_window_info* info, mi_g2* out) {
+    return fold_windows<hostec::G2>(windows, n_ranks, rank_stride, info, out);
 }
 
 int mi_msm_g1_batch(mi_ctx* ctx, const uint8_t* const* scalars, size_t k, size_t n, unsigned scalar_fmt, mi_g1* out) {
@@ -199,6 +242,13 @@ int mi_msm_last_profile(const mi_ctx* ctx, mi_profile* out) {
     return MI_OK;
 }
 
+int mi_pairing_last_profile(const mi_ctx* ctx, mi_pairing_profile* out) {
+    if (!ctx || !out) return MI_E_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->info_mu);
+    *out = ctx->pprof;
+    return MI_OK;
+}
+
 // text of the calling thread's most recent failure (thread-local: valid until the same thread fails again)
 const char* mi_msm_last_error(const mi_ctx* ctx) {
     (void)ctx;
@@ -235,6 +285,12 @@ int mi_test_set_max_part(mi_ctx* ctx, size_t points) {
     return MI_OK;
 }
 void mi_test_fail_allocs(int count) { g_fail_allocs.store(count); }
+int mi_test_set_no_peer(mi_ctx* ctx, int no_peer) {
+    if (!ctx) return MI_E_INVALID;
+    LaneLock lk(ctx, true);
+    ctx->test_no_peer = no_peer != 0;
+    return MI_OK;
+}
 int mi_test_plan(size_t n, unsigned forced_c, int group, int shared, size_t stride, uint32_t* out) {
     if (!out || n == 0) return MI_E_INVALID;
     Plan p = make_plan(n, forced_c, group == 0 ? g1_cost() : g2_cost(), shared != 0, stride);

@@ -31,6 +31,7 @@ namespace mi {
 struct HipFail {
     std::string msg;
     bool oom = false;
+    bool invalid = false;   // the caller's argument is at fault (MI_E_INVALID), not the runtime
 };
 #define HIP_TRY(expr)                                                                                     \
     do {                                                                                                  \
@@ -76,6 +77,12 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+    }
+    // ensure(), but an allocation more than twice the need (and > 64 MiB larger) is given back first: a plain set_bases after
+    // set_bases_precomputed must not keep the W x table allocation for the life of the context
+    void ensure_fit(size_t bytes) {
+        if (cap > 2 * bytes && cap - bytes > ((size_t)64 << 20)) release();
+        ensure(bytes);
     }
 };
 
@@ -188,17 +195,22 @@ struct mi_ctx {
     std::vector<mi::DevState> devs_b;                            // lane 1
     std::vector<std::array<mi::Resident, 2>> residents;          // per device
     std::unique_ptr<mi::DeviceWorkers> workers[mi::NLANES];      // multi-device contexts only: one thread per device and lane
+    std::unique_ptr<mi::DeviceWorkers> batch_workers;            // mi_msm_*_batch: two persistent job pullers, created on first use
+    std::mutex batch_mu;                                         // one batch call at a time drives them
+    std::vector<char> peer_ok;                                   // [a * ndev + b]: device slot a can read memory of device slot b
     std::mutex lane_mu;                                          // lane bookkeeping
     std::condition_variable lane_cv;
     bool lane_busy[mi::NLANES] = {false, false};
     mutable std::mutex info_mu;                                  // prof / err
     unsigned forced_c = 0;
     mi_profile prof{};
+    mi_pairing_profile pprof{};
     std::string err;
 #if defined(MI_TEST_HOOKS)
     unsigned test_pairing_share = 0, test_pairing_batch = 0;
     bool test_pairing_single_lane = false;
     size_t test_max_part = 0;   // points per pass of the pipeline (0 = the built-in limit)
+    bool test_no_peer = false;  // pretend no device can read another's memory (exercises the staging path on one GPU)
 #endif
 };
 
@@ -261,14 +273,29 @@ inline int fail(mi_ctx* ctx, int code, const std::string& msg) {
     return code;
 }
 
+// The single-device entry points run on the caller's thread and select the context's device there: the caller's current device
+// (torch's, say) is put back when the call returns.
+struct DeviceRestore {
+    int dev = -1;
+    DeviceRestore() {
+        if (hipGetDevice(&dev) != hipSuccess) { dev = -1; (void)hipGetLastError(); }
+    }
+    ~DeviceRestore() {
+        if (dev >= 0) (void)hipSetDevice(dev);
+    }
+    DeviceRestore(const DeviceRestore&) = delete;
+    DeviceRestore& operator=(const DeviceRestore&) = delete;
+};
+
 // Nothing may cross the C ABI as an exception (include/arkblst_amd.h): every entry point body runs inside guarded().
 template <class Fn>
 int guarded(mi_ctx* ctx, Fn fn) {
+    DeviceRestore restore;
     try {
         return fn();
     } catch (const HipFail& e) {
         bool oom = e.oom || e.msg.find("out of memory") != std::string::npos;
-        return fail(ctx, oom ? MI_E_NOMEM : MI_E_HIP, e.msg);
+        return fail(ctx, e.invalid ? MI_E_INVALID : oom ? MI_E_NOMEM : MI_E_HIP, e.msg);
     } catch (const std::bad_alloc&) {
         return fail(ctx, MI_E_NOMEM, "host allocation failed");
     } catch (const std::exception& e) {
@@ -288,7 +315,7 @@ void guarded_part(PartErr& e, Fn fn) noexcept {
     try {
         fn();
     } catch (const HipFail& f) {
-        e.code = (f.oom || f.msg.find("out of memory") != std::string::npos) ? MI_E_NOMEM : MI_E_HIP;
+        e.code = f.invalid ? MI_E_INVALID : (f.oom || f.msg.find("out of memory") != std::string::npos) ? MI_E_NOMEM : MI_E_HIP;
         e.msg = f.msg;
     } catch (const std::bad_alloc&) {
         e.code = MI_E_NOMEM;

@@ -40,6 +40,8 @@ int g1_set_bases(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute_c
 int g2_set_bases(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute_c);
 int g1_msm(mi_ctx* ctx, const void* bases, const uint8_t* scalars, bool scalars_on_device, size_t n, unsigned fmt, void* out);
 int g2_msm(mi_ctx* ctx, const void* bases, const uint8_t* scalars, bool scalars_on_device, size_t n, unsigned fmt, void* out);
+int g1_msm_windows(mi_ctx* ctx, const uint8_t* d_scalars, size_t n, unsigned fmt, void* d_out, mi_window_info* info);
+int g2_msm_windows(mi_ctx* ctx, const uint8_t* d_scalars, size_t n, unsigned fmt, void* d_out, mi_window_info* info);
 int g1_msm_batch(mi_ctx* ctx, const uint8_t* const* scalars, bool scalars_on_device, size_t k, size_t n, unsigned fmt, mi_g1* out);
 int g2_msm_batch(mi_ctx* ctx, const uint8_t* const* scalars, bool scalars_on_device, size_t k, size_t n, unsigned fmt, mi_g2* out);
 int g1_normalize(mi_ctx* ctx, const mi_g1* in, size_t n, mi_g1_affine* out);

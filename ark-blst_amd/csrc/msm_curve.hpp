@@ -35,6 +35,35 @@ inline size_t max_part(mi_ctx* ctx) {
     return MAX_PART_POINTS;
 }
 
+// Device of a caller-supplied device pointer.  A pointer this runtime does not know — plain host memory, or memory of a second HIP
+// runtime loaded into the process (load order) — is the caller's error (MI_E_INVALID), not an opaque fault later.
+inline int device_of_ptr(const void* p, const char* what) {
+    hipPointerAttribute_t a{};
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) (void)hipGetLastError();
+    if (e != hipSuccess || a.type == hipMemoryTypeUnregistered)
+        throw HipFail{std::string(what) + " is not device memory known to this HIP runtime (a host pointer, or memory allocated through a "
+                      "second HIP runtime in this process: see INTEGRATION.md, load order)", false, true};
+    return a.device;
+}
+// can device slot k of the context read memory that lives on device `owner` directly (same device, or peer access over xGMI)?
+inline bool can_read(const mi_ctx* ctx, size_t k, int owner) {
+    const size_t g = ctx->devs.size();
+    if (ctx->devs[k].dev == owner) return true;
+#if defined(MI_TEST_HOOKS)
+    if (ctx->test_no_peer) return false;
+#endif
+    for (size_t b = 0; b < g; b++)
+        if (ctx->devs[b].dev == owner) return ctx->peer_ok.size() == g * g && ctx->peer_ok[k * g + b] != 0;
+    return false;   // a device outside the context: staged through a peer copy
+}
+
+// what mi_msm_g{1,2}_device_windows leaves behind instead of a folded result
+struct WinOut {
+    uint32_t* d_out = nullptr;   // caller's device buffer: num_windows Jacobian points in the reference's form
+    mi_window_info info{};
+};
+
 // bases raw (host or device) -> device form in `dst`
 template <class C>
 void ingest(DevState& d, const void* bases, bool bases_on_device, size_t n, uint32_t* dst, uint8_t* flags) {
@@ -123,7 +152,7 @@ void launch_accumulate(hipStream_t s, const uint32_t* bases, const uint32_t* sor
 // The pipeline on one device.  d_bases: device-form points (tables of `stride` points when shared); d_scalars: n x 32 B on device.
 template <class C>
 typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint8_t* d_flags, const uint32_t* d_scalars,
-                                 size_t n, unsigned fmt, bool shared, unsigned table_c, size_t stride, int ev0) {
+                                 size_t n, unsigned fmt, bool shared, unsigned table_c, size_t stride, int ev0, WinOut* wo = nullptr) {
     using J = typename HostCurve<C>::J;
     using RS = typename msmk::CoopOf<C>::RS;   // lane scheme of the reduce kernel
     using CS = typename msmk::CoopOf<C>::CS;   // lane scheme of the combine levels
@@ -182,7 +211,13 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
         }
     }
     HIP_TRY(hipEventRecord(d.ev[ev0 + 6], s));
-    HIP_TRY(hipMemcpyAsync(d.h_pairs, jac_dev, (size_t)pl.bwin * jac_bytes<C>(), hipMemcpyDeviceToHost, s));
+    if (wo) {   // the window sums stay on the device (the caller exchanges them: mi_msm_g1_device_windows); no fold here
+        HIP_TRY(hipMemcpyAsync(wo->d_out, jac_dev, (size_t)pl.bwin * jac_bytes<C>(), hipMemcpyDeviceToDevice, s));
+        wo->info.window_bits = pl.c;
+        wo->info.num_windows = pl.bwin;
+    } else {
+        HIP_TRY(hipMemcpyAsync(d.h_pairs, jac_dev, (size_t)pl.bwin * jac_bytes<C>(), hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipEventRecord(d.ev[ev0 + 7], s));
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipGetLastError());
@@ -198,6 +233,7 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     d.prof.work_items = nitems;
     d.prof.max_items_per_bucket = max_items;
 
+    if (wo) return J::inf();
     auto t0 = std::chrono::steady_clock::now();
     J r = horner<J>(reinterpret_cast<const J*>(d.h_pairs), pl);
     d.prof.host_fold_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -207,7 +243,7 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
 // One device's share of an MSM call. bases: host raw pointer for this shard or nullptr (= resident, starting at resident index r0).
 template <class C>
 typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bases, size_t r0, const uint8_t* scalars, bool scalars_on_device,
-                                    size_t n, unsigned fmt) {
+                                    size_t n, unsigned fmt, int stage_from_dev = -1, WinOut* wo = nullptr) {
     using J = typename HostCurve<C>::J;
     HIP_TRY(hipSetDevice(d.dev));
     d.prof = mi_profile{};
@@ -218,12 +254,17 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
     Resident& res = d.res[HostCurve<C>::IDX];
     const bool shared = !bases && res.tables > 1;
     const size_t part_max = max_part(ctx);
+    if (wo && n > part_max) throw HipFail{"device_windows: n exceeds one pass of the pipeline (2^26 points per device)", false, true};
     for (size_t lo = 0; lo < n; lo += part_max) {   // one pass unless n exceeds the per-pass limit
         const size_t m = std::min(part_max, n - lo);
         HIP_TRY(hipEventRecord(d.ev[0], s));
         const uint32_t* d_scalars;
-        if (scalars_on_device) {
+        if (scalars_on_device && stage_from_dev < 0) {
             d_scalars = reinterpret_cast<const uint32_t*>(scalars + lo * 32);
+        } else if (scalars_on_device) {   // the vector lives on a device this one cannot read: peer copy of the shard
+            d.scalars.ensure(m * 32);
+            HIP_TRY(hipMemcpyPeerAsync(d.scalars.p, d.dev, scalars + lo * 32, stage_from_dev, m * 32, s));
+            d_scalars = reinterpret_cast<const uint32_t*>(d.scalars.p);
         } else {
             d.scalars.ensure(m * 32);
             HIP_TRY(hipMemcpyAsync(d.scalars.p, scalars + lo * 32, m * 32, hipMemcpyHostToDevice, s));
@@ -245,7 +286,7 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
             d_bases = reinterpret_cast<const uint32_t*>(res.buf.p) + (r0 + lo) * msmk::Geo<C>::PT_WORDS;
             d_flags = reinterpret_cast<const uint8_t*>(res.flags.p) + r0 + lo;
         }
-        J r = run_msm<C>(ctx, d, d_bases, d_flags, d_scalars, m, fmt, shared, res.table_c, res.n, 2);
+        J r = run_msm<C>(ctx, d, d_bases, d_flags, d_scalars, m, fmt, shared, res.table_c, res.n, 2, wo);
         total = lo == 0 ? r : total.add(r);
         d.prof.h2d_ms += ev_ms(d.ev[0], d.ev[1]);
         d.prof.ingest_ms += ev_ms(d.ev[1], d.ev[2]);
@@ -266,10 +307,12 @@ void build_resident(mi_ctx* ctx, DevState& d, Resident& res, const uint8_t* base
     unsigned c = 0, W = 1;
     if (precompute_c) {
         c = precompute_c == 1 ? make_plan(n, 0, HostCurve<C>::cost(), true, n).c : precompute_c;
+        // c == 0: no window size fits the entry encoding (n x windows > 2^30 entries, i.e. more than ~9e7 points per device)
+        if (c < 7 || c > 22 || make_plan(n, c, HostCurve<C>::cost(), true, n).c == 0)
+            throw HipFail{"window_bits not usable for precomputed tables of this size", false, true};
         W = (256 + c - 1) / c;
-        if (c < 7 || c > 22 || make_plan(n, c, HostCurve<C>::cost(), true, n).c == 0) throw HipFail{"window_bits not usable for precomputed tables of this size"};
     }
-    res.buf.ensure(n * W * PTB);
+    res.buf.ensure_fit(n * W * PTB);
     res.flags.ensure(n);
     res.tables = 1;
     res.table_c = 0;
@@ -349,8 +392,10 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
             if (have == 0 && n) return fail(ctx, MI_E_NO_BASES, "no resident base set for this group");
             if (n > have) return fail(ctx, MI_E_INVALID, "n exceeds the resident base set");
         }
-        // device-resident scalars of a multi-device context: the shard of device k is read by device k (peer access over xGMI, or
-        // the caller placed each shard on its device: mi_msm_g{1,2}_device takes ONE pointer to n x 32 B visible to every device)
+        // device-resident scalars: the shard of device k is read by device k — directly when the vector lives there or peer access
+        // over xGMI exists (matrix recorded by mi_msm_init), through a peer copy of the shard otherwise
+        int owner = -1;
+        if (scalars_on_device && n) owner = device_of_ptr(scalars, "d_scalars");
         auto t0 = std::chrono::steady_clock::now();
         for_each_device(lane, g, [&](size_t k) {
             guarded_part(errs[k], [&] {
@@ -363,7 +408,8 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
                     lo = std::min(n, res.lo);
                     hi = std::min(n, res.lo + res.n);
                 }
-                part[k] = device_msm<C>(ctx, d, bases ? bases + lo * aff_bytes<C>() : nullptr, 0, scalars + lo * 32, scalars_on_device, hi - lo, fmt);
+                const int stage = scalars_on_device && hi > lo && !can_read(ctx, k, owner) ? owner : -1;
+                part[k] = device_msm<C>(ctx, d, bases ? bases + lo * aff_bytes<C>() : nullptr, 0, scalars + lo * 32, scalars_on_device, hi - lo, fmt, stage);
             });
         });
         for (size_t k = 0; k < g; k++)
@@ -383,7 +429,38 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
     });
 }
 
-// k MSMs over the resident base set, two in flight (one per lane): the calling thread and one helper pull jobs
+// The pipeline of mi_msm_g{1,2}_device up to the per-window sums, which stay in the caller's DEVICE buffer (no D2H, no host fold):
+// the exchange step of a one-process-per-GPU deployment starts from device memory (RCCL all-gather of the window sums, one D2H
+// of the gathered block, mi_g{1,2}_fold_windows on the host).  Single-device contexts, resident bases, one pass.
+template <class C>
+int msm_windows_impl(mi_ctx* ctx, const uint8_t* d_scalars, size_t n, unsigned fmt, void* d_out, mi_window_info* info) {
+    if (!ctx || !d_out || !info || (n && !d_scalars) || fmt > 1) return fail(ctx, MI_E_INVALID, "invalid argument");
+    if (ctx->devs.size() != 1) return fail(ctx, MI_E_INVALID, "device_windows needs a single-device context (one context per rank)");
+    LaneLock lane(ctx, false);
+    std::vector<DevState>& devs = lane.devs();
+    return guarded(ctx, [&]() -> int {
+        DevState& d = devs[0];
+        auto& res = d.res[HostCurve<C>::IDX];
+        if (res.n == 0 && n) return fail(ctx, MI_E_NO_BASES, "no resident base set for this group");
+        if (n > res.n) return fail(ctx, MI_E_INVALID, "n exceeds the resident base set");
+        info->window_bits = 0;
+        info->num_windows = 0;
+        if (n == 0) return MI_OK;
+        (void)device_of_ptr(d_scalars, "d_scalars");
+        (void)device_of_ptr(d_out, "d_out_windows");
+        auto t0 = std::chrono::steady_clock::now();
+        WinOut wo;
+        wo.d_out = static_cast<uint32_t*>(d_out);
+        (void)device_msm<C>(ctx, d, nullptr, 0, d_scalars, true, n, fmt, -1, &wo);
+        *info = wo.info;
+        mi_profile pr = d.prof;
+        pr.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        set_prof(ctx, pr);
+        return MI_OK;
+    });
+}
+
+// k MSMs over the resident base set, two in flight (one per lane): two persistent job pullers share the k jobs
 template <class C, class Out>
 int msm_batch_impl(mi_ctx* ctx, const uint8_t* const* scalars, bool scalars_on_device, size_t k, size_t n, unsigned fmt, Out* out) {
     if (!ctx || (k && (!scalars || !out))) return fail(ctx, MI_E_INVALID, "invalid argument");
@@ -406,10 +483,11 @@ int msm_batch_impl(mi_ctx* ctx, const uint8_t* const* scalars, bool scalars_on_d
                 }
             }
         };
-        if (k > 1) {
-            std::thread helper(worker);   // a failure to start it (std::system_error) is caught by guarded()
-            worker();
-            helper.join();
+        if (k > 1) {   // two persistent job pullers (one per lane), created on the first batch call: nothing is spawned per call
+            std::lock_guard<std::mutex> lk(ctx->batch_mu);
+            if (!ctx->batch_workers) ctx->batch_workers.reset(new DeviceWorkers(NLANES));
+            std::function<void(size_t)> f = [&](size_t) { worker(); };
+            ctx->batch_workers->run(f);
         } else {
             worker();
         }

@@ -7,6 +7,9 @@ int g1_set_bases(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute_c
 int g1_msm(mi_ctx* ctx, const void* bases, const uint8_t* scalars, bool scalars_on_device, size_t n, unsigned fmt, void* out) {
     return msm_impl<msmk::G1C>(ctx, bases, scalars, scalars_on_device, n, fmt, out);
 }
+int g1_msm_windows(mi_ctx* ctx, const uint8_t* d_scalars, size_t n, unsigned fmt, void* d_out, mi_window_info* info) {
+    return msm_windows_impl<msmk::G1C>(ctx, d_scalars, n, fmt, d_out, info);
+}
 int g1_msm_batch(mi_ctx* ctx, const uint8_t* const* scalars, bool scalars_on_device, size_t k, size_t n, unsigned fmt, mi_g1* out) {
     return msm_batch_impl<msmk::G1C>(ctx, scalars, scalars_on_device, k, n, fmt, out);
 }

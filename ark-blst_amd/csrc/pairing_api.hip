@@ -54,7 +54,7 @@ void fp12_to_raw(mi_fp12* out, const HT::E12& a) { memcpy(out, &a, sizeof a); }
 
 
 // Miller loops of one shard on one device, multiplied down to <= 4 values on the GPU and to one on the host
-HT::E12 device_miller(mi_ctx* ctx, DevState& d, const mi_g1_affine* p, const mi_g2_affine* q, size_t n) {
+HT::E12 device_miller(mi_ctx* ctx, DevState& d, const mi_g1_affine* p, const mi_g2_affine* q, size_t n, mi_pairing_profile& pp) {
     HIP_TRY(hipSetDevice(d.dev));
     hipStream_t s = d.stream;
     DevBuf &dp = d.pr_p, &dq = d.pr_q, &raw = d.pr_raw, &dlines = d.pr_lines;   // kept across calls (no per-call hipMalloc)
@@ -144,15 +144,15 @@ HT::E12 device_miller(mi_ctx* ctx, DevState& d, const mi_g1_affine* p, const mi_
     HIP_TRY(hipGetLastError());
     const mi_fp12* top = static_cast<const mi_fp12*>(d.h_pairs);
     for (size_t k = 0; k < m; k++) acc = HT::mul12(acc, fp12_from_raw(&top[k]));
-    d.prof = mi_profile{};
-    d.prof.n = n;
-    d.prof.h2d_ms = ev_ms(d.ev[0], d.ev[1]);
-    d.prof.accumulate_ms = ev_ms(d.ev[1], d.ev[2]);   // Miller loops (line kernel + accumulate kernel, all batches)
-    d.prof.reduce_ms = ev_ms(d.ev[2], d.ev[3]);       // multiplication tree
-    if (split_timed) {                                // first line batch (the whole call up to 2^17 pairs): the two kernels apart
-        d.prof.digits_ms = ev_ms(d.ev[1], d.ev[4]);   // k_miller_lines2
-        d.prof.scatter_ms = ev_ms(d.ev[4], d.ev[5]);  // k_miller_accumulate
-        d.prof.work_items = share;                    // pairs per accumulator
+    pp = mi_pairing_profile{};
+    pp.n = n;
+    pp.h2d_ms = ev_ms(d.ev[0], d.ev[1]);
+    pp.miller_ms = ev_ms(d.ev[1], d.ev[2]);       // Miller loops (line kernel + accumulate kernel, all batches)
+    pp.tree_ms = ev_ms(d.ev[2], d.ev[3]);         // multiplication tree
+    if (split_timed) {                            // first line batch (the whole call up to 2^17 pairs): the two kernels apart
+        pp.lines_ms = ev_ms(d.ev[1], d.ev[4]);
+        pp.accumulate_ms = ev_ms(d.ev[4], d.ev[5]);
+        pp.pairs_per_accumulator = share;
     }
     return acc;
 }
@@ -168,13 +168,14 @@ int miller(mi_ctx* ctx, const mi_g1_affine* p, const mi_g2_affine* q, size_t n, 
         if (n < 2 * g) g = 1;   // a handful of pairs: one device
         std::vector<HT::E12> part(g, HT::one12());
         std::vector<PartErr> errs(g);
+        std::vector<mi_pairing_profile> pps(g);
         auto t0 = std::chrono::steady_clock::now();
         auto work = [&](size_t k) {
             if (k >= g) return;
             guarded_part(errs[k], [&] {
                 size_t lo, hi;
                 shard_range(n, g, k, lo, hi);
-                if (hi > lo) part[k] = device_miller(ctx, ctx->devs[k], p + lo, q + lo, hi - lo);
+                if (hi > lo) part[k] = device_miller(ctx, ctx->devs[k], p + lo, q + lo, hi - lo, pps[k]);
             });
         };
         if (g == 1) work(0);
@@ -186,11 +187,14 @@ int miller(mi_ctx* ctx, const mi_g1_affine* p, const mi_g2_affine* q, size_t n, 
         auto t1 = std::chrono::steady_clock::now();
         if (final_exp) f = HT::final_exp(f);
         fp12_to_raw(out, f);
-        mi_profile pr = ctx->devs[0].prof;
+        mi_pairing_profile pr = pps[0];
         pr.n = n;
-        pr.host_fold_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+        pr.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
         pr.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        set_prof(ctx, pr);
+        {
+            std::lock_guard<std::mutex> lk2(ctx->info_mu);
+            ctx->pprof = pr;
+        }
         return MI_OK;
     });
 }

@@ -95,6 +95,36 @@ def _traffic(g: str, log_n, precomputed: bool):
     return None, None
 
 
+def _pairing_traffic():
+    """HBM bytes of the two Miller kernels (largest launch of each = the 2^16-pair call) from the newest committed PMC summary."""
+    try:
+        files = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if "pairing" in f and f.endswith("_pmc_summary.json")), reverse=True)
+        for f in files:
+            ks = json.load(open(os.path.join(ROOT, "profiles", f))).get("kernels", {})
+            t = [v["hbm_bytes_largest_launch_corrected"] for k, v in ks.items()
+                 if ("k_miller_lines2" in k or "k_miller_accumulate" in k) and "hbm_bytes_largest_launch_corrected" in v]
+            if len(t) == 2:
+                return sum(t), "profiles/" + f
+    except Exception:
+        pass
+    return None, None
+
+
+def _expected_ms(g: str, log_n):
+    """single-GPU ms per call at this shard size from the newest committed size sweep (profiles/*_sweep_<g>_*.jsonl): what one
+    rank of a sharded run should take before any exchange cost"""
+    try:
+        files = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f"_sweep_{g}_" in f and f.endswith(".jsonl")), reverse=True)
+        for f in files:
+            for l in open(os.path.join(ROOT, "profiles", f)):
+                r = json.loads(l)
+                if r.get("log_n") == log_n and r.get("ok", True):
+                    return r["ms"], "profiles/" + f
+    except Exception:
+        pass
+    return None, None
+
+
 def _distort(scalars: bytes, n: int, dist: str) -> bytes:
     if dist == "uniform":
         return scalars
@@ -228,23 +258,25 @@ def _pairing_leg(pkg, co, ncpu, device) -> dict:
             gt = ctx.multi_pairing(P_all, Q_all)
             dt = time.perf_counter() - t1
             if dt < best:
-                best, pp = dt, ctx.profile()
-        m = 256
+                best, pp = dt, ctx.pairing_profile()
+        m = 4096   # CPU baseline sample: ~1 s on 16 host threads (the final exponentiation is then < 1 % of it)
         t1 = time.perf_counter()
         cpu_gt = co.multi_pairing(p1[:96 * m], q2[:192 * m], ncpu)
         cpu_s = time.perf_counter() - t1
         sample_ok = ctx.multi_pairing(p1[:96 * m], q2[:192 * m]) == cpu_gt
-    acc_ms, lines_ms = pp["scatter_ms"], pp["digits_ms"]
+    acc_ms, lines_ms, miller_ms = pp["accumulate_ms"], pp["lines_ms"], pp["miller_ms"]
     mads = PAIRING_FP_MULS_PER_PAIR * MADS_PER_FP_MUL
-    tmad = mads * n / (pp["accumulate_ms"] * 1e-3) / 1e12
-    gbs = 288.0 * n / (pp["accumulate_ms"] * 1e-3) / 1e9
+    tmad = mads * n / (miller_ms * 1e-3) / 1e12
+    gbs = 288.0 * n / (miller_ms * 1e-3) / 1e9
+    traffic, tsrc = _pairing_traffic()
     return {"metric": "pairs/s, batched Miller loop + final exponentiation (host buffers in, Gt out)", "value": n / best, "unit": "pairs/s",
-            "n_pairs": n, "ms": best * 1e3, "miller_kernels_ms": pp["accumulate_ms"], "k_miller_lines2_ms": lines_ms,
-            "k_miller_accumulate_ms": acc_ms, "pairs_per_accumulator": pp["work_items"], "fp12_tree_ms": pp["reduce_ms"], "h2d_ms": pp["h2d_ms"],
-            "host_tail_ms": pp["host_fold_ms"],
-            "product_cancels_to_one": gt == pr_oracle.fp12_to_bytes(pr_oracle.FP12_ONE), "bit_exact_256_pairs_vs_c_oracle": sample_ok,
+            "n_pairs": n, "ms": best * 1e3, "miller_kernels_ms": miller_ms, "k_miller_lines2_ms": lines_ms,
+            "k_miller_accumulate_ms": acc_ms, "pairs_per_accumulator": pp["pairs_per_accumulator"], "fp12_tree_ms": pp["tree_ms"], "h2d_ms": pp["h2d_ms"],
+            "host_tail_ms": pp["host_ms"],
+            "product_cancels_to_one": gt == pr_oracle.fp12_to_bytes(pr_oracle.FP12_ONE), f"bit_exact_{m}_pairs_vs_c_oracle": sample_ok,
+            "bit_exact": sample_ok,
             "roofline": {"bound": "hbm", "kernel": "k_miller_lines2 + k_miller_accumulate", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": 288 * n, "kernel_ms": pp["accumulate_ms"],
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": 288 * n, "kernel_ms": miller_ms,
                          "note": "288 B per pair in (96 B G1 + 192 B G2 affine); the 26 KB of line coefficients per pair written and "
                                  "re-read between the two kernels are counted as traffic, not as algorithmic bytes"},
             "valu_roofline": {"model_mads_per_pair": mads,
@@ -291,7 +323,7 @@ def _in_process_leg(pkg, co, torch, ncpu, slots: int, log_n: int, steps: int) ->
                 c1.msm_device("g1", d_sc.data_ptr(), per, pkg.SCALAR_CANONICAL)
         dt = (time.perf_counter() - t0) / steps
     out["serial_single_device_calls_ms"] = dt * 1e3
-    out.update({"device_slots": ids, "points": n,
+    out.update({"device_slots": ids, "points": n, "plumbing_only": len(set(ids)) < len(ids),
                 "note": "one mi_ctx over several device slots (mi_msm_init with a device list): contiguous shards, one persistent host "
                         "thread per slot, partial sums added in slot order; compared with the same shards as back-to-back "
                         "single-device calls"})
@@ -373,36 +405,62 @@ def main() -> None:
 
     jac_bytes = 144 if g == "g1" else 288
     cdev = "cuda" if on_gpu else "cpu"
-    gather = torch.empty(world * jac_bytes, dtype=torch.uint8, device=cdev) if world > 1 else None
-    mine_dev = torch.empty(jac_bytes, dtype=torch.uint8, device=cdev) if world > 1 else None
-    # staging buffers for the exchange: pinned on a GPU box (no pageable-copy synchronisation per step)
-    mine_host = torch.empty(jac_bytes, dtype=torch.uint8) if world > 1 else None
-    gather_host = torch.empty(world * jac_bytes, dtype=torch.uint8) if world > 1 else None
-    if world > 1 and on_gpu:
-        mine_host, gather_host = mine_host.pin_memory(), gather_host.pin_memory()
+    # ---- exchange step at N > 1: the library leaves this rank's per-window sums in DEVICE memory
+    # (mi_msm_g1_device_windows: no D2H, no host fold), RCCL all-gathers them over xGMI, ONE D2H copy of the gathered block,
+    # mi_g1_fold_windows adds the ranks per window in rank order and runs the Horner fold — identical result on every rank.
+    win_dev = torch.empty(pkg.MAX_WINDOWS * jac_bytes, dtype=torch.uint8, device="cuda") if world > 1 else None
+    xchg = {"info": None, "gather": None, "gather_host": None, "msm_s": 0.0, "wait_s": 0.0, "exchange_s": 0.0, "steps": 0}
+
+    def setup_exchange():
+        """one untimed call: learn the window geometry, make every rank agree on it, size the gather buffers"""
+        info = leg.ctx.msm_device_windows(g, leg.d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL, win_dev.data_ptr())
+        infos = [None] * world
+        dist.all_gather_object(infos, info)
+        if len(set(infos)) != 1:   # ragged shards chose different window sizes: pin the largest everywhere
+            leg.ctx.set_window_bits(max(i[0] for i in infos))
+            info = leg.ctx.msm_device_windows(g, leg.d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL, win_dev.data_ptr())
+            dist.all_gather_object(infos, info)
+            assert len(set(infos)) == 1, infos
+        xchg["info"] = info
+        nb = info[1] * jac_bytes
+        xchg["gather"] = torch.empty(world * nb, dtype=torch.uint8, device=cdev)
+        gh = torch.empty(world * nb, dtype=torch.uint8)
+        xchg["gather_host"] = gh.pin_memory() if on_gpu else gh
 
     def step() -> bytes:
-        part = leg.call()
         if world == 1:
-            return part
-        mine_host.numpy()[:] = memoryview(part)
-        mine_dev.copy_(mine_host, non_blocking=True)
-        dist.all_gather_into_tensor(gather, mine_dev)       # RCCL over xGMI: N x 144 B (latency-bound)
-        gather_host.copy_(gather, non_blocking=True)        # one D2H copy of the N partials
+            return leg.call()
+        t_a = time.perf_counter()
+        info = leg.ctx.msm_device_windows(g, leg.d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL, win_dev.data_ptr())
+        t_b = time.perf_counter()
+        dist.barrier()   # separates waiting for the slowest rank (wait_ms) from the exchange proper (exchange_ms)
+        t_w = time.perf_counter()
+        nb = info[1] * jac_bytes
         if on_gpu:
+            dist.all_gather_into_tensor(xchg["gather"], win_dev[:nb])      # RCCL over xGMI: N x W x 144 B, from device memory
+            xchg["gather_host"].copy_(xchg["gather"], non_blocking=True)    # the one D2H copy of the step
             torch.cuda.current_stream().synchronize()
-        allp = gather_host.numpy().tobytes()
-        # all-reduce under the curve group law: fold in rank order on every rank (identical result everywhere)
-        return (pkg.g1_sum if g == "g1" else pkg.g2_sum)([allp[k * jac_bytes:(k + 1) * jac_bytes] for k in range(world)])
+        else:                                                               # gloo rehearsal: host collective
+            dist.all_gather_into_tensor(xchg["gather_host"], win_dev[:nb].cpu())
+        out = pkg.fold_windows(g, xchg["gather_host"].numpy(), world, info[1], *info)
+        t_c = time.perf_counter()
+        xchg["msm_s"] += t_b - t_a
+        xchg["wait_s"] += t_w - t_b
+        xchg["exchange_s"] += t_c - t_w
+        xchg["steps"] += 1
+        return out
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        setup_exchange()
     for _ in range(args.warmup):
         step()
     prof_acc = []
+    xchg.update(msm_s=0.0, wait_s=0.0, exchange_s=0.0, steps=0)
     fence()
     t0 = time.perf_counter()
     result = b""
@@ -536,13 +594,40 @@ def main() -> None:
             "input_gen_s": gen_s,
         }
         out.update(_rooflines(g, headline_n, log_n, acc_ms, p0["num_windows"], args.precomputed))
+        if world > 1:
+            exp_ms, exp_src = _expected_ms(g, log_n) if log_n is not None else (None, None)
+            out["config"]["expected_ms_per_rank"] = exp_ms
+            out["config"]["expected_ms_source"] = exp_src
+            ks = max(1, xchg["steps"])
+            out["msm_ms"] = xchg["msm_s"] / ks * 1e3            # rank 0: the library call up to the window sums in device memory
+            out["wait_ms"] = xchg["wait_s"] / ks * 1e3          # rank 0: barrier until the slowest rank has its window sums (load imbalance)
+            out["exchange_ms"] = xchg["exchange_s"] / ks * 1e3  # rank 0: all-gather + one D2H + host fold (mi_g1_fold_windows)
+            out["exchange"] = {"backend": args.backend, "bytes_per_rank": xchg["info"][1] * jac_bytes, "windows": xchg["info"][1],
+                               "window_bits": xchg["info"][0],
+                               "path": "window sums in device memory -> all_gather_into_tensor -> one D2H of the gathered block -> mi_%s_fold_windows" % g}
         if cpu_baseline:
             out["cpu_baseline"] = cpu_baseline
         if secondary:
             out["secondary"] = secondary
-            for k in ("two_host_threads", "pairing_2p16", "call_shapes"):   # round-1 field names kept at the top level
-                if k in secondary:
-                    out[k] = secondary[k]
+        # compact recap LAST: a log tail always shows the north-star figures (the driver keeps the last 2000 characters)
+        def _brief(d):
+            b = {"value": d.get("value"), "ms_per_step": d.get("ms_per_step", d.get("ms")), "bit_exact": d.get("bit_exact")}
+            if "valu_roofline" in d:
+                b["valu_frac"] = round(d["valu_roofline"]["frac"], 3)
+            return b
+        summary = {f"{g}_2p{log_n}" if log_n is not None else f"{g}_{headline_n}": _brief(out)}
+        for k in ("g1_2p24", "g2_2p20", "pairing_2p16", "g1_2p20_precomputed_tables"):
+            if k in secondary and "error" not in secondary[k]:
+                summary[k] = _brief(secondary[k])
+        if "call_shapes" in secondary:
+            summary["call_shapes_ms"] = {k: round(v, 3) for k, v in secondary["call_shapes"].items() if isinstance(v, float)}
+        if world > 1:
+            summary["n_gpus"] = world
+            summary["exchange_ms"] = round(out["exchange_ms"], 4)
+            summary["wait_ms"] = round(out["wait_ms"], 4)
+        if cpu_baseline:
+            summary["cpu_points_per_s"] = cpu_baseline["value"]
+        out["summary"] = summary
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

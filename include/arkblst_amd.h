@@ -52,7 +52,8 @@ enum { MI_SCALAR_CANONICAL = 0, MI_SCALAR_MONTGOMERY = 1 };
 
 enum {
     MI_OK = 0,
-    MI_E_INVALID = -1,      /* bad argument (NULL pointer, unknown scalar_fmt, n too large for resident set) */
+    MI_E_INVALID = -1,      /* bad argument (NULL pointer, unknown scalar_fmt, n too large for resident set, a "device" pointer
+                               this HIP runtime does not know) */
     MI_E_NO_DEVICE = -2,    /* no usable HIP device / bad device id */
     MI_E_HIP = -3,          /* a HIP runtime call failed; mi_msm_last_error() has the text */
     MI_E_NOMEM = -4,        /* device or host allocation failed */
@@ -116,8 +117,9 @@ int mi_msm_g2(mi_ctx *ctx, const mi_g2_affine *bases, const uint8_t *scalars, si
 /* Same computation with the scalars ALREADY in device memory (hipMalloc'd or a torch CUDA tensor's data_ptr) and the bases
  * resident: nothing crosses PCIe except one Jacobian point per window.  The library reads d_scalars on its OWN stream: the
  * caller must have synchronised the stream that produced them (hipStreamSynchronize / torch.cuda.synchronize) before the
- * call.  With a multi-device context device k reads its shard [lo_k, hi_k) of the one vector (peer access over xGMI when the
- * vector lives on another device of the context). */
+ * call.  With a multi-device context device k reads its shard [lo_k, hi_k) of the one vector: directly when the vector lives on
+ * that device or peer access over xGMI exists, through a peer copy of the shard otherwise.  A pointer the runtime does not know
+ * (host memory; memory of a second HIP runtime in the process) is MI_E_INVALID. */
 int mi_msm_g1_device(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g1 *out);
 int mi_msm_g2_device(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g2 *out);
 
@@ -165,11 +167,46 @@ int mi_multi_miller_loop(mi_ctx *ctx, const mi_g1_affine *p, const mi_g2_affine 
 int mi_final_exponentiation(const mi_fp12 *f, mi_fp12 *out);
 /* both steps: out = prod_i e(p[i], q[i])  (ark_ec::pairing::Pairing::multi_pairing) */
 int mi_multi_pairing(mi_ctx *ctx, const mi_g1_affine *p, const mi_g2_affine *q, size_t n, mi_fp12 *out);
+/* Timing of the last pairing call on this context (milliseconds, HIP events on the library's stream; first device). */
+typedef struct {
+    double h2d_ms;          /* points host -> device */
+    double lines_ms;        /* k_miller_lines2 of the first line batch (the whole call up to 2^17 pairs) */
+    double accumulate_ms;   /* k_miller_accumulate of the first line batch */
+    double miller_ms;       /* all Miller kernels of the call (every batch) */
+    double tree_ms;         /* Fp12 multiplication tree on the GPU */
+    double host_ms;         /* last <= 4 products and, for mi_multi_pairing, the final exponentiation on the host */
+    double total_ms;        /* wall time of the call */
+    uint64_t n;             /* pairs */
+    uint32_t pairs_per_accumulator;   /* m: pairs that share one accumulator and its squarings */
+    uint32_t reserved;
+} mi_pairing_profile;
+int mi_pairing_last_profile(const mi_ctx *ctx, mi_pairing_profile *out);
 
 /* Deterministic fold of partial sums (one per GPU / rank), in index order: the "all-reduce under the curve
  * group law" that follows the RCCL all-gather in the multi-process harness.  Host only. */
 int mi_g1_sum(const mi_g1 *partials, size_t n, mi_g1 *out);
 int mi_g2_sum(const mi_g2 *partials, size_t n, mi_g2 *out);
+
+/* Exchange step of a one-process-per-GPU deployment (BASELINE config #3: the base set sharded over the GPUs of a node, partial
+ * sums combined by an RCCL collective over xGMI) starting from DEVICE memory.  mi_msm_g1_device_windows runs the pipeline of
+ * mi_msm_g1_device on this rank's shard but stops before the host tail: the num_windows per-window sums (Jacobian points in the
+ * reference's form, 144 B / 288 B each, window 0 first) are left in the caller's device buffer d_out_windows (room for
+ * MI_MAX_WINDOWS points, on the context's device) and nothing crosses PCIe.  The caller all-gathers the buffers of all ranks
+ * with its own communicator (ncclAllGather / torch.distributed.all_gather_into_tensor: point addition is not an ncclRedOp_t, so
+ * the all-reduce is all-gather + fold), copies the gathered block to the host ONCE and calls mi_g1_fold_windows, which adds the
+ * ranks' sums per window in rank order and runs the Horner fold over the windows: the result equals mi_msm_g1 over the
+ * concatenated shards.  All ranks must report the same mi_window_info — equal shard sizes do; otherwise fix the window size with
+ * mi_msm_set_window_bits on every rank.  Single-device contexts, resident bases, at most 2^26 points per call.  The reference has
+ * no counterpart (it uses Device::all()[0] only, src/gpu.rs:233-239).  Blocking: the buffer is complete when the call returns. */
+#define MI_MAX_WINDOWS 37   /* ceil(256 / 7) */
+typedef struct { uint32_t window_bits, num_windows; } mi_window_info;
+int mi_msm_g1_device_windows(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scalar_fmt, void *d_out_windows,
+                             mi_window_info *info);
+int mi_msm_g2_device_windows(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scalar_fmt, void *d_out_windows,
+                             mi_window_info *info);
+/* windows[r * rank_stride + w] = window sum w of rank r (rank_stride >= info->num_windows).  Host only. */
+int mi_g1_fold_windows(const mi_g1 *windows, size_t n_ranks, size_t rank_stride, const mi_window_info *info, mi_g1 *out);
+int mi_g2_fold_windows(const mi_g2 *windows, size_t n_ranks, size_t rank_stride, const mi_window_info *info, mi_g2 *out);
 
 /* Tuning / introspection. window_bits = 0 restores the built-in heuristic (cf. calc_window_size, src/gpu.rs:218-223). */
 int mi_msm_set_window_bits(mi_ctx *ctx, unsigned window_bits);

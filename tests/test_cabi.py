@@ -35,7 +35,8 @@ def test_product_library_has_no_test_hooks(pkg):
     prod = {s for s in _exported(pkg.lib_path()) if s.startswith("mi_")}
     assert prod == set(_declared_symbols()), prod ^ set(_declared_symbols())
     test = {s for s in _exported(pkg.lib_path(True)) if s.startswith("mi_")}
-    assert test - prod == {"mi_test_fp_op", "mi_test_set_pairing", "mi_test_set_max_part", "mi_test_fail_allocs", "mi_test_plan"}
+    assert test - prod == {"mi_test_fp_op", "mi_test_set_pairing", "mi_test_set_max_part", "mi_test_fail_allocs", "mi_test_plan",
+                           "mi_test_set_no_peer"}
 
 
 def test_hot_kernels_do_not_spill(pkg):
@@ -106,6 +107,41 @@ def test_host_fold_of_partials_matches_oracle(pkg, co, o):
         dbl = (pkg.g1_sum if group == "g1" else pkg.g2_sum)([p, p])
         assert co.to_affine(group, dbl) == o.affine_to_bytes(F, o.scalar_mul(F, gen, 14))
         assert len(got) == (144 if group == "g1" else 288) and aff
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_fold_windows_host(pkg, co, o, group):
+    """mi_g{1,2}_fold_windows (host only): the tail of the multi-process exchange — per-window sums of several ranks, added in
+    rank order per window, then Horner over the windows.  Expected value from the Python big-int oracle: the points are known
+    multiples k[r][w] G, so the fold is (sum_w 2^(c w) sum_r k[r][w]) G."""
+    import random
+
+    F, gen = (o.F1, o.G1_GEN) if group == "g1" else (o.F2, o.G2_GEN)
+    size = 144 if group == "g1" else 288
+    rnd = random.Random(77)
+    for ranks, nwin, c, stride in ((1, 1, 16, 1), (3, 5, 7, 5), (2, 13, 20, 37), (8, 16, 16, 16), (4, 37, 7, 37)):
+        k = [[rnd.randrange(0, 1 << 64) for _ in range(nwin)] for _ in range(ranks)]
+        k[0][0] = 0                                        # a window sum at infinity
+        if ranks > 1 and nwin > 1:
+            k[1][1] = o.R_ORDER - k[0][1]                  # two ranks cancel in one window
+        blob = bytearray(ranks * stride * size)
+        for r in range(ranks):
+            for w in range(nwin):
+                pt = o.scalar_mul(F, gen, k[r][w])
+                blob[(r * stride + w) * size:(r * stride + w + 1) * size] = o.jac_to_bytes(F, o.jac_from_aff(F, pt)) if pt is not o.INF else bytes(size)
+        got = pkg.fold_windows(group, bytes(blob), ranks, stride, c, nwin)
+        total = sum((1 << (c * w)) * sum(k[r][w] for r in range(ranks)) for w in range(nwin)) % o.R_ORDER
+        want = o.scalar_mul(F, gen, total)
+        assert co.to_affine(group, got) == (o.affine_to_bytes(F, want) if want is not o.INF else bytes(2 * size // 3)), (ranks, nwin, c)
+    # argument checks: more windows than MI_MAX_WINDOWS, a stride shorter than the window count
+    import ctypes as C2
+    from ark_blst_amd import binding as b
+
+    L = pkg.load_library()
+    out = C2.create_string_buffer(size)
+    assert getattr(L, f"mi_{group}_fold_windows")(bytes(size * 40), 1, 40, C2.byref(b.WindowInfo(16, 38)), out) == -1
+    assert getattr(L, f"mi_{group}_fold_windows")(bytes(size * 4), 1, 2, C2.byref(b.WindowInfo(16, 4)), out) == -1
+    assert getattr(L, f"mi_{group}_fold_windows")(None, 0, 0, C2.byref(b.WindowInfo(0, 0)), out) == 0 and out.raw == bytes(size)
 
 
 def test_reference_style_length_mismatch_error(pkg):

@@ -536,6 +536,29 @@ def test_bench_json_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port"
+    assert list(d)[-1] == "summary" and d["summary"]["g1_2p14"]["bit_exact"] is True   # the recap closes the line (log tails keep it)
+
+
+def test_bench_two_ranks_exchange_from_device_memory():
+    """The N > 1 path of bench.py end to end on ONE GPU (2 ranks share device 0, gloo collective): every rank leaves its window
+    sums in device memory (mi_msm_g1_device_windows), they are all-gathered and folded (mi_g1_fold_windows); the line carries
+    msm_ms / exchange_ms and the result is bit-exact against the closed form over both shards."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--total-log-n", "15", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--share-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["bit_exact"] is True and d["scaling"] == "strong" and d["config"]["total_points"] == 1 << 15
+    assert d["exchange_ms"] > 0 and d["msm_ms"] > 0 and d["exchange"]["windows"] == d["config"]["num_windows"]
+    assert d["summary"]["n_gpus"] == 2 and "expected_ms_per_rank" in d["config"]
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE sizes
@@ -743,3 +766,86 @@ def test_multi_device_context_device_resident_scalars(pkg, co):
         got_m = c3.msm_device("g1", d.data_ptr(), m, pkg.SCALAR_CANONICAL)
     assert _canon(co, "g1", got) == co.dlog_expected("g1", scalars, SEED_B + 250, n)
     assert _canon(co, "g1", got_m) == co.dlog_expected("g1", scalars[:32 * m], SEED_B + 250, m)
+
+
+def test_multi_device_context_without_peer_access_stages_the_shards(pkg, co):
+    """The 'no peer access' branch (a node or pair without it must not dereference another device's pointer): forced through the
+    test hook on one GPU, every slot but the owner's then copies its shard with hipMemcpyPeerAsync instead of reading in place."""
+    import torch
+
+    n = 9001
+    bases = co.gen_bases("g1", SEED_B + 251, n, 8)
+    scalars = co.gen_scalars(SEED_S + 251, n)
+    d = torch.frombuffer(bytearray(scalars), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    want = co.dlog_expected("g1", scalars, SEED_B + 251, n)
+    with pkg.Context([0, 0, 0], test_hooks=True) as c3:
+        c3.set_bases("g1", bases, n)
+        assert _canon(co, "g1", c3.msm_device("g1", d.data_ptr(), n, pkg.SCALAR_CANONICAL)) == want
+        c3.test_set_no_peer(True)
+        assert _canon(co, "g1", c3.msm_device("g1", d.data_ptr(), n, pkg.SCALAR_CANONICAL)) == want
+        m = 4000   # a prefix that leaves the last slot without work
+        assert _canon(co, "g1", c3.msm_device("g1", d.data_ptr(), m, pkg.SCALAR_CANONICAL)) == co.dlog_expected("g1", scalars[:32 * m], SEED_B + 251, m)
+
+
+def test_host_pointer_as_device_scalars_is_an_error_code(ctx, pkg, co):
+    """mi_msm_g1_device with memory the HIP runtime does not know (plain host memory here; memory of a second HIP runtime in the
+    process looks the same) is MI_E_INVALID with a message, not a GPU fault"""
+    import ctypes as C
+
+    n = 64
+    ctx.set_bases("g1", co.gen_bases("g1", 5, n, 1), n)
+    host = C.create_string_buffer(co.gen_scalars(6, n), 32 * n)
+    with pytest.raises(pkg.MsmError) as e:
+        ctx.msm_device("g1", C.addressof(host), n, pkg.SCALAR_CANONICAL)
+    assert e.value.code == -1 and "HIP runtime" in str(e.value)
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_device_windows_and_fold_equal_msm(pkg, co, group):
+    """mi_msm_g{1,2}_device_windows + mi_g{1,2}_fold_windows (the exchange step of the one-process-per-GPU deployment, BASELINE
+    config #3): three 'ranks' (contexts) each own a contiguous shard of the base set and leave their per-window sums in DEVICE
+    memory; the gathered windows folded on the host equal the MSM over the whole set (oracle) and mi_msm_device of each shard
+    equals the one-rank fold of its own windows.  Ragged shard sizes, so the window size is pinned on every rank."""
+    import torch
+
+    aff, size = (96, 144) if group == "g1" else (192, 288)
+    n = 20000 if group == "g1" else 6000
+    cuts = [0, n // 3, n // 3 + n // 4, n]
+    seed = 260 if group == "g1" else 261
+    bases = co.gen_bases(group, SEED_B + seed, n, 8)
+    scalars = co.gen_scalars(SEED_S + seed, n)
+    d = torch.frombuffer(bytearray(scalars), dtype=torch.uint8).cuda()
+    wins = [torch.zeros(pkg.MAX_WINDOWS * size, dtype=torch.uint8, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()
+    infos, gathered = [], b""
+    for r in range(3):
+        lo, hi = cuts[r], cuts[r + 1]
+        with pkg.Context([0]) as c:
+            c.set_window_bits(13)
+            c.set_bases(group, bases[aff * lo:aff * hi], hi - lo)
+            info = c.msm_device_windows(group, d.data_ptr() + 32 * lo, hi - lo, pkg.SCALAR_CANONICAL, wins[r].data_ptr())
+            infos.append(info)
+            w = wins[r].cpu().numpy().tobytes()
+            one = pkg.fold_windows(group, w, 1, pkg.MAX_WINDOWS, *info)
+            assert _canon(co, group, one) == _canon(co, group, c.msm_device(group, d.data_ptr() + 32 * lo, hi - lo, pkg.SCALAR_CANONICAL))
+            gathered += w[:info[1] * size]
+            # an empty call reports no windows
+            assert c.msm_device_windows(group, d.data_ptr(), 0, pkg.SCALAR_CANONICAL, wins[r].data_ptr()) == (0, 0)
+    assert infos[0] == infos[1] == infos[2] == (13, 20)
+    total = pkg.fold_windows(group, gathered, 3, infos[0][1], *infos[0])
+    assert _canon(co, group, total) == co.dlog_expected(group, scalars, SEED_B + seed, n)
+    # precomputed tables: every window feeds one bucket set, so there is ONE window sum and the fold is the sum over the ranks
+    if group == "g1":
+        with pkg.Context([0]) as c:
+            c.set_bases_precomputed(group, bases[:aff * 3000], 3000, 11)
+            info = c.msm_device_windows(group, d.data_ptr(), 3000, pkg.SCALAR_CANONICAL, wins[0].data_ptr())
+            assert info == (11, 1)
+            got = pkg.fold_windows(group, wins[0].cpu().numpy().tobytes(), 1, pkg.MAX_WINDOWS, *info)
+            assert _canon(co, group, got) == co.dlog_expected(group, scalars[:32 * 3000], SEED_B + seed, 3000)
+        # a multi-device context is refused (one context per rank)
+        with pkg.Context([0, 0]) as c2:
+            c2.set_bases(group, bases[:aff * 100], 100)
+            with pytest.raises(pkg.MsmError) as e:
+                c2.msm_device_windows(group, d.data_ptr(), 100, pkg.SCALAR_CANONICAL, wins[0].data_ptr())
+            assert e.value.code == -1
