@@ -60,8 +60,9 @@ def load_library(test_hooks: bool = False):
             getattr(L, f"mi_msm_{g}").argtypes = [vp, vp, vp, sz, u, vp]
             getattr(L, f"mi_msm_{g}_device").argtypes = [vp, vp, sz, u, vp]
             getattr(L, f"mi_{g}_sum").argtypes = [vp, sz, vp]
-            getattr(L, f"mi_msm_{g}_device_windows").argtypes = [vp, vp, sz, u, vp, C.POINTER(WindowInfo)]
-            getattr(L, f"mi_{g}_fold_windows").argtypes = [vp, sz, sz, C.POINTER(WindowInfo), vp]
+            if hasattr(L, f"mi_msm_{g}_device_windows"):   # absent from older builds that tools/ab_multi.sh swaps in for same-box A/Bs
+                getattr(L, f"mi_msm_{g}_device_windows").argtypes = [vp, vp, sz, u, vp, C.POINTER(WindowInfo)]
+                getattr(L, f"mi_{g}_fold_windows").argtypes = [vp, sz, sz, C.POINTER(WindowInfo), vp]
             getattr(L, f"mi_msm_{g}_batch").argtypes = [vp, C.POINTER(C.c_char_p), sz, sz, u, vp]
             getattr(L, f"mi_msm_{g}_batch_device").argtypes = [vp, C.POINTER(vp), sz, sz, u, vp]
             getattr(L, f"mi_{g}_normalize_batch").argtypes = [vp, vp, sz, vp]
@@ -73,7 +74,8 @@ def load_library(test_hooks: bool = False):
         L.mi_final_exponentiation.argtypes = [vp, vp]
         L.mi_msm_set_window_bits.argtypes = [vp, u]
         L.mi_msm_last_profile.argtypes = [vp, C.POINTER(Profile)]
-        L.mi_pairing_last_profile.argtypes = [vp, C.POINTER(PairingProfile)]
+        if hasattr(L, "mi_pairing_last_profile"):
+            L.mi_pairing_last_profile.argtypes = [vp, C.POINTER(PairingProfile)]
         L.mi_msm_last_error.argtypes = [vp]
         L.mi_msm_last_error.restype = C.c_char_p
         L.mi_msm_strerror.argtypes = [i]
@@ -274,7 +276,7 @@ class Context:
 
 def test_plan(n: int, forced_c: int = 0, group: str = "g1", shared: bool = False, stride: int = 0) -> dict:
     """The window-size plan of an n-point call (test build; host only, needs no device)."""
-    out = (C.c_uint32 * 12)()
+    out = (C.c_uint32 * 13)()
     rc = load_library(True).mi_test_plan(n, forced_c, 0 if group == "g1" else 1, int(shared), stride, out)
     if rc != 0:
         raise MsmError(rc, "mi_test_plan")
@@ -282,6 +284,7 @@ def test_plan(n: int, forced_c: int = 0, group: str = "g1", shared: bool = False
     d = {k: int(out[i]) for i, k in enumerate(keys)}
     d["nbuckets"] = (int(out[9]) << 32) | int(out[10])
     d["nchunks"] = int(out[11])
+    d["serial_L"] = int(out[12])
     return d
 
 

@@ -70,7 +70,9 @@ int mi_msm_init(mi_ctx** out, const int* device_ids, int n_devices) {
                 int cus = 0;
                 if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, id) == hipSuccess && cus > 0) d->simds = 4u * (uint32_t)cus;
                 HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+                HIP_TRY(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
                 for (auto& e : d->ev) HIP_TRY(hipEventCreate(&e));
+                for (auto& e : d->cev) HIP_TRY(hipEventCreate(&e));
             }
         }
         if (n_devices > 1) {
@@ -117,6 +119,9 @@ void mi_msm_destroy(mi_ctx* ctx) {
             if (d.h_meta) (void)hipHostFree(d.h_meta);
             for (auto& e : d.ev)
                 if (e) (void)hipEventDestroy(e);
+            for (auto& e : d.cev)
+                if (e) (void)hipEventDestroy(e);
+            if (d.copy_stream) (void)hipStreamDestroy(d.copy_stream);
             if (d.stream) (void)hipStreamDestroy(d.stream);
         }
     for (size_t k = 0; k < ctx->residents.size() && k < ctx->devs.size(); k++) {
@@ -296,7 +301,7 @@ int mi_test_plan(size_t n, unsigned forced_c, int group, int shared, size_t stri
     Plan p = make_plan(n, forced_c, group == 0 ? g1_cost() : g2_cost(), shared != 0, stride);
     out[0] = p.c; out[1] = p.nwin; out[2] = p.bwin; out[3] = p.logL; out[4] = p.chunk_log; out[5] = p.logT; out[6] = p.lo_bits;
     out[7] = p.serial_reduce ? 1u : 0u; out[8] = p.chunks_per_win; out[9] = (uint32_t)(p.nbuckets >> 32); out[10] = (uint32_t)p.nbuckets;
-    out[11] = (uint32_t)p.nchunks;
+    out[11] = (uint32_t)p.nchunks; out[12] = p.serial_reduce ? p.serial_L : 0u;
     return MI_OK;
 }
 #endif

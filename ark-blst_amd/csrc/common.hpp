@@ -56,7 +56,8 @@ struct Plan {
     uint32_t cls_shift;   // log2 of the width of a length class of the schedule (follows the typical item, not T)
     uint64_t nbuckets, nchunks;
     uint32_t chunk_log;   // log2 of the buckets one reduce wave (or, serial form, one reduce lane) covers
-    bool serial_reduce;   // throughput form: one lane per 64 buckets (k_reduce_serial)
+    bool serial_reduce;   // throughput form: one lane per serial_L buckets (k_reduce_serial)
+    uint32_t serial_L;    // buckets per lane of the serial form (<= 64, any value: chosen so that the lanes fill one round of wave slots)
 };
 
 struct DevBuf {
@@ -102,7 +103,9 @@ struct DevState {
     int dev = 0;
     uint32_t simds = 1024;   // 4 per compute unit (256 CUs on MI355X)
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // chunked H2D of host-slice calls, overlapped with the kernels that consume the chunks
     hipEvent_t ev[12] = {};
+    hipEvent_t cev[10] = {};             // copy stream: [0] first copy issued, [1..8] chunk landed, [9] last copy done
     Resident* res = nullptr;   // -> mi_ctx::residents[device][2]
     // scratch
     DevBuf raw, call_bases, call_flags, scalars, hist, offsets, woff, meta, sched, sorted, partial, order, item_bucket, pairs, pairs2;

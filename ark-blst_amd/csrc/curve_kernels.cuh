@@ -521,28 +521,33 @@ __global__ void __launch_bounds__(64, CS::MAX_OCC) k_reduce_coop(const uint32_t*
     if (ll == 0) CS::store(pairs + (size_t)(2 * chunk + 1) * BK, acc);
 }
 
-// Throughput form of the bucket reduction for millions of buckets (>= 2^21: 2^24 points at c = 20 have 6.8 M): ONE lane per 64
-// consecutive buckets, single-lane complete additions (5200 instructions per addition instead of 4 x 1864 on a quad), two
-// waves per SIMD.  Only the running sum lives in registers across a step: the weighted sum `acc` is parked in LDS (168 B per
+// Throughput form of the bucket reduction for millions of buckets (>= 2^21: 2^24 points at c = 20 have 6.8 M): ONE lane per L
+// consecutive buckets of a window, single-lane complete additions (5200 instructions per addition instead of 4 x 1864 on a quad),
+// two waves per SIMD.  Only the running sum lives in registers across a step: the weighted sum `acc` is parked in LDS (168 B per
 // lane) while run += B is computed and fetched for acc += run, so the one inlined addition site fits 256 VGPRs without
 // spilling (the round-1 kernel kept run, acc and a third point live: 512 VGPRs, one wave per SIMD, half the issue rate).
-// Lane g leaves the pair (64 S, T) of its 64 buckets in the layout k_reduce_coop uses: k_combine takes it from there.
+// L is ANY value <= 64 (round 3; it was fixed at 64): the plan picks the L whose lanes fill one round of wave slots — 53 at 2^24
+// points, 2010 waves of 114 steps instead of 1664 waves of 134.  Lane g = (window w, j) covers buckets [j L, min(j L + L, nb)) of
+// window w (the last lane of a window is ragged: its missing TOP buckets are infinity) and leaves the pair (L S, T) in the layout
+// k_reduce_coop uses — k_combine takes it from there; its element size K may be any number, it only has to be the same for all
+// pairs of a level.  L S comes from S by the double-and-add chain of L's bits (S parked in LDS once T has been written out).
 template <class C>
 __global__ void __launch_bounds__(64, 2) k_reduce_serial(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ woff,
-                                                        uint32_t nlanes, uint32_t* __restrict__ pairs) {
+                                                        uint32_t nlanes, uint32_t L, uint32_t nb, uint32_t lpw, uint32_t* __restrict__ pairs) {
     using F = typename C::F;
     using FR = typename C::FR;
     using E = typename F::E;
     using PJ = ec::Proj<F>;
     using PR = ec::Proj<FR>;
     constexpr int BK = Geo<C>::BK_WORDS, SLOT = Geo<C>::SLOT;
-    constexpr uint32_t L = 64;
-    __shared__ uint32_t park[64 * BK];   // acc of every lane, slot-interleaved: [coordinate][lane][SLOT words]
+    __shared__ uint32_t park[64 * BK];   // one point per lane, slot-interleaved: [coordinate][lane][SLOT words]; acc, later S
     const uint32_t lane = threadIdx.x;
     uint32_t g = blockIdx.x * 64 + lane;
     const bool live = g < nlanes;
     if (!live) g = nlanes - 1;             // idle lanes of the last wave repeat the last lane's work and store nothing
-    const uint32_t* wp = woff + (size_t)g * L;
+    const uint32_t w = g / lpw, j = g - w * lpw;
+    const uint32_t first = j * L, cnt = nb - first < L ? nb - first : L;   // this lane's buckets: first .. first + cnt - 1 of window w
+    const uint32_t* wp = woff + (size_t)w * nb + first;
     auto park_store = [&](const PJ& p) {
         ElemIO<E>::store(park + (0 * 64 + lane) * SLOT, p.x);
         ElemIO<E>::store(park + (1 * 64 + lane) * SLOT, p.y);
@@ -555,32 +560,53 @@ __global__ void __launch_bounds__(64, 2) k_reduce_serial(const uint32_t* __restr
         ElemIO<E>::load(p.z, park + (2 * 64 + lane) * SLOT);
         return p;
     };
+    int top = 0;                           // index of L's top bit
+    while ((L >> top) > 1u) top++;
+    uint32_t chain = 0;                    // steps of the double-and-add chain: one doubling per bit below the top one, one addition more per set bit
+    for (int b = top - 1; b >= 0; b--) chain += 1 + ((L >> b) & 1u);
+    const uint32_t nsteps = 2 * L + chain;
     PJ run = ec::proj_inf<F>();
     park_store(ec::proj_inf<F>());
-    uint32_t idx = wp[L - 1];
+    uint32_t idx = wp[L - 1 < cnt ? L - 1 : 0];   // bucket of step pair t = 0 is rel = L - 1 (beyond a ragged lane's buckets: infinity)
+    int bit = top - 1;                     // wave-uniform state of the chain
+    bool pend_add = false;
 #pragma unroll 1
-    for (uint32_t s = 0; s < 2 * L + 6; s++) {   // 2 L running-sum steps, then six doublings of run (64 S)
+    for (uint32_t s = 0; s < nsteps; s++) {
         PJ A, B;
-        const bool even = (s & 1u) == 0, dbl = s >= 2 * L;
-        if (dbl) {
-            A = run; B = run;
-        } else if (even) {
+        const bool phase1 = s < 2 * L, even = (s & 1u) == 0;
+        if (phase1 && even) {              // run += B_rel, rel = L - 1 - t
+            const uint32_t t = s >> 1, rel = L - 1 - t;
             A = run;
             B = load_bucket<C>(partial + (size_t)idx * BK);
-            const uint32_t t = s >> 1;
-            if (t + 1 < L) idx = wp[L - 2 - t];
-        } else {
+            // beyond a ragged lane's buckets: infinity = (0 : Y : 0) for ANY Y != 0 — clearing X and Z of whatever was loaded costs
+            // two selects against the inline constant 0 (a select against (0 : 1 : 0) parked the 14 limbs of one in registers)
+            B.x = F::select(rel < cnt, F::zero(), B.x);
+            B.z = F::select(rel < cnt, F::zero(), B.z);
+            if (t + 1 < L) idx = wp[rel - 1 < cnt ? rel - 1 : 0];
+        } else if (phase1) {               // acc += run
             A = park_load();
             B = run;
+        } else {
+            if (s == 2 * L) {              // T is complete: out it goes, the LDS slot now keeps S for the chain's additions
+                if (live) store_bucket<C>(pairs + (size_t)(2 * g + 1) * BK, park_load());
+                park_store(run);
+            }
+            A = run;
+            if (pend_add) {                // run = 2 run + S
+                B = park_load();
+                pend_add = false;
+            } else {                       // run = 2 run, then + S if this bit of L is set
+                B = run;
+                pend_add = ((L >> bit) & 1u) != 0;
+                bit--;
+            }
         }
         ec::proj_add<FR>(reinterpret_cast<PR&>(A), reinterpret_cast<const PR&>(B));
-        if (dbl || even) run = A;
-        else park_store(A);
+        if (phase1 && !even) park_store(A);
+        else run = A;
     }
-    if (live) {
-        store_bucket<C>(pairs + (size_t)(2 * g) * BK, run);
-        store_bucket<C>(pairs + (size_t)(2 * g + 1) * BK, park_load());
-    }
+    if (nsteps == 2 * L && live) store_bucket<C>(pairs + (size_t)(2 * g + 1) * BK, park_load());   // L = 1: no chain
+    if (live) store_bucket<C>(pairs + (size_t)(2 * g) * BK, run);
 }
 
 // One level of the per-window combine: a wave takes NLL consecutive pairs (S'_j, T_j) of one window (S'_j = K S_j already

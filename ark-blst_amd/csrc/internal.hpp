@@ -32,8 +32,11 @@ struct SortOut {
 };
 // scalars -> signed digits -> sorted (index | sign) entries, bucket offsets, work items, processing order.  Records
 // d.ev[ev0] .. d.ev[ev0 + 3] (start, coarse done, fine done, schedule done) and synchronises once to read the item counts.
+// host_scalars != nullptr: the scalars are still in host memory.  They are copied into d_scalars (device scratch of n x 32 B) in
+// chunks of whole point tiles on the lane's copy stream, and the count pass of a chunk starts when that chunk has landed
+// (the trait's actual call shape: host slices, /root/reference/src/g1.rs:604,623, uploaded per call at src/gpu.rs:149-150).
 void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, const uint8_t* d_flags, size_t n, unsigned fmt, bool shared_buckets,
-                       size_t stride, int ev0, SortOut& out);
+                       size_t stride, int ev0, SortOut& out, const uint8_t* host_scalars = nullptr);
 
 // ---- msm_g1.hip / msm_g2.hip
 int g1_set_bases(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute_c);

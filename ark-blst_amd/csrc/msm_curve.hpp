@@ -152,7 +152,8 @@ void launch_accumulate(hipStream_t s, const uint32_t* bases, const uint32_t* sor
 // The pipeline on one device.  d_bases: device-form points (tables of `stride` points when shared); d_scalars: n x 32 B on device.
 template <class C>
 typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint8_t* d_flags, const uint32_t* d_scalars,
-                                 size_t n, unsigned fmt, bool shared, unsigned table_c, size_t stride, int ev0, WinOut* wo = nullptr) {
+                                 size_t n, unsigned fmt, bool shared, unsigned table_c, size_t stride, int ev0, WinOut* wo = nullptr,
+                                 const uint8_t* host_scalars = nullptr) {
     using J = typename HostCurve<C>::J;
     using RS = typename msmk::CoopOf<C>::RS;   // lane scheme of the reduce kernel
     using CS = typename msmk::CoopOf<C>::CS;   // lane scheme of the combine levels
@@ -167,7 +168,7 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     d.ensure_host((size_t)pl.bwin * jac_bytes<C>());
 
     SortOut so;
-    sort_and_schedule(d, pl, d_scalars, d_flags, n, fmt, shared, stride, ev0, so);
+    sort_and_schedule(d, pl, d_scalars, d_flags, n, fmt, shared, stride, ev0, so, host_scalars);
 
     hipStream_t s = d.stream;
     const uint32_t nitems = so.nitems, max_items = so.max_items;
@@ -185,7 +186,7 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     if constexpr (std::is_same<C, msmk::G1C>::value) {   // the throughput form exists for G1 only (HostCurve<G2C>::cost() never asks for it)
         if (pl.serial_reduce) {
             hipLaunchKernelGGL(msmk::k_reduce_serial<C>, dim3((uint32_t)((pl.nchunks + 63) / 64)), dim3(64), 0, s, (const uint32_t*)d.partial.p,
-                               (const uint32_t*)d.woff.p, (uint32_t)pl.nchunks, (uint32_t*)d.pairs.p);
+                               (const uint32_t*)d.woff.p, (uint32_t)pl.nchunks, pl.serial_L, pl.nb, pl.chunks_per_win, (uint32_t*)d.pairs.p);
             reduced = true;
         }
     }
@@ -258,7 +259,10 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
     for (size_t lo = 0; lo < n; lo += part_max) {   // one pass unless n exceeds the per-pass limit
         const size_t m = std::min(part_max, n - lo);
         HIP_TRY(hipEventRecord(d.ev[0], s));
+        // Host slices (the trait's call shape) cross PCIe in chunks on the lane's copy stream, each consumed as it lands: bases first
+        // (k_ingest per chunk), then the scalars (count pass of the sort per chunk, inside sort_and_schedule).
         const uint32_t* d_scalars;
+        const uint8_t* host_scalars = nullptr;
         if (scalars_on_device && stage_from_dev < 0) {
             d_scalars = reinterpret_cast<const uint32_t*>(scalars + lo * 32);
         } else if (scalars_on_device) {   // the vector lives on a device this one cannot read: peer copy of the shard
@@ -267,18 +271,27 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
             d_scalars = reinterpret_cast<const uint32_t*>(d.scalars.p);
         } else {
             d.scalars.ensure(m * 32);
-            HIP_TRY(hipMemcpyAsync(d.scalars.p, scalars + lo * 32, m * 32, hipMemcpyHostToDevice, s));
             d_scalars = reinterpret_cast<const uint32_t*>(d.scalars.p);
+            host_scalars = scalars + lo * 32;
         }
         const uint32_t* d_bases;
         const uint8_t* d_flags;
         if (bases) {
             d.raw.ensure(m * aff_bytes<C>());
-            HIP_TRY(hipMemcpyAsync(d.raw.p, bases + lo * aff_bytes<C>(), m * aff_bytes<C>(), hipMemcpyHostToDevice, s));
-            HIP_TRY(hipEventRecord(d.ev[1], s));
             d.call_bases.ensure(m * msmk::Geo<C>::PT_WORDS * 4);
             d.call_flags.ensure(m);
-            ingest<C>(d, d.raw.p, true, m, (uint32_t*)d.call_bases.p, (uint8_t*)d.call_flags.p);
+            const size_t K = std::min<size_t>(8, std::max<size_t>(1, m >> 16));
+            for (size_t j = 0; j < K; j++) {
+                const size_t p0 = m * j / K, p1 = m * (j + 1) / K;
+                HIP_TRY(hipMemcpyAsync((char*)d.raw.p + p0 * aff_bytes<C>(), bases + (lo + p0) * aff_bytes<C>(), (p1 - p0) * aff_bytes<C>(),
+                                       hipMemcpyHostToDevice, d.copy_stream));
+                HIP_TRY(hipEventRecord(d.cev[1 + j], d.copy_stream));
+                HIP_TRY(hipStreamWaitEvent(s, d.cev[1 + j], 0));
+                if (p1 > p0)
+                    ingest<C>(d, (const char*)d.raw.p + p0 * aff_bytes<C>(), true, p1 - p0, (uint32_t*)d.call_bases.p + p0 * msmk::Geo<C>::PT_WORDS,
+                              (uint8_t*)d.call_flags.p + p0);
+            }
+            HIP_TRY(hipEventRecord(d.ev[1], s));
             d_bases = reinterpret_cast<const uint32_t*>(d.call_bases.p);
             d_flags = reinterpret_cast<const uint8_t*>(d.call_flags.p);
         } else {
@@ -286,10 +299,11 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
             d_bases = reinterpret_cast<const uint32_t*>(res.buf.p) + (r0 + lo) * msmk::Geo<C>::PT_WORDS;
             d_flags = reinterpret_cast<const uint8_t*>(res.flags.p) + r0 + lo;
         }
-        J r = run_msm<C>(ctx, d, d_bases, d_flags, d_scalars, m, fmt, shared, res.table_c, res.n, 2, wo);
+        J r = run_msm<C>(ctx, d, d_bases, d_flags, d_scalars, m, fmt, shared, res.table_c, res.n, 2, wo, host_scalars);
         total = lo == 0 ? r : total.add(r);
-        d.prof.h2d_ms += ev_ms(d.ev[0], d.ev[1]);
-        d.prof.ingest_ms += ev_ms(d.ev[1], d.ev[2]);
+        // h2d_ms: bases (their chunks interleave with k_ingest on the main stream) + scalars (copy stream, first to last chunk; the
+        // sort's count pass runs underneath, so digits_ms of a host-scalar call includes waiting for the chunks)
+        d.prof.h2d_ms += ev_ms(d.ev[0], d.ev[1]) + (host_scalars ? ev_ms(d.cev[0], d.cev[9]) : 0.0);
     }
     d.prof.n = n;
     d.prof.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

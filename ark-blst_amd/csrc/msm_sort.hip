@@ -40,8 +40,24 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         while (p.logL < 6 && p.logL + log_ll < c - 1 && (p.nbuckets >> (log_ll + p.logL)) > cc.max_chunks) p.logL++;
         p.chunk_log = log_ll + p.logL;
         p.serial_reduce = cc.serial_buckets != 0 && p.nbuckets >= cc.serial_buckets && c - 1 >= 6;
-        if (p.serial_reduce) { p.chunk_log = 6; p.logL = 6; }
         p.chunks_per_win = p.nb >> p.chunk_log;
+        double serial_steps = 0, serial_rounds = 0;
+        if (p.serial_reduce) {
+            // one lane per L consecutive buckets of a window, L <= 64 and NOT necessarily a power of two: the L that costs the fewest
+            // (rounds of wave slots) x (2 L running-sum steps + the double-and-add chain that turns S into L S).  2^24 points at c = 20:
+            // L = 53 fills 2010 of the 2048 slots with 114 steps, where L = 64 left 1664 waves walking 134 (3.0 -> 2.6 ms).
+            double best = 1e300;
+            for (uint32_t L = 8; L <= 64; L++) {
+                const uint64_t lanes = (uint64_t)((p.nb + L - 1) / L) * p.bwin;
+                const double rounds = std::ceil(std::ceil((double)lanes / 64.0) / (double)cc.max_chunks);
+                uint32_t bits = 0, ones = 0;
+                for (uint32_t v = L; v; v >>= 1) { bits++; ones += v & 1u; }
+                const double steps = 2.0 * L + (bits - 1) + (ones - 1);
+                if (rounds * steps < best) { best = rounds * steps; p.serial_L = L; serial_steps = steps; serial_rounds = rounds; }
+            }
+            p.chunk_log = 6; p.logL = 6;   // (unused by the serial form; kept within the coop form's range)
+            p.chunks_per_win = (p.nb + p.serial_L - 1) / p.serial_L;
+        }
         p.nchunks = (uint64_t)p.chunks_per_win * p.bwin;
         // The top window holds only 255 - c (nwin - 1) significant bits: its n entries share 2^top_bits buckets (on top of the
         // others' entries when all windows share one bucket set)
@@ -69,7 +85,7 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         const double rounds = (double)((p.nchunks + cc.max_chunks - 1) / cc.max_chunks);
         int levels = 0;
         for (uint32_t m = p.chunks_per_win; m > 1; m = (m + (1u << cc.comb_log_ll) - 1) >> cc.comb_log_ll) levels++;
-        const double reduce_us = p.serial_reduce ? std::ceil((double)p.nchunks / 131072.0) * 134.0 * cc.serial_step_us
+        const double reduce_us = p.serial_reduce ? serial_rounds * serial_steps * cc.serial_step_us
                                                  : rounds * (2.0 * (1u << p.logL) + 2.0 * log_ll + p.logL + 1.0) *
                                                        (p.nchunks <= 1024 ? std::min(cc.step_us, cc.comb_step_us * 1.05) : cc.step_us);   // lone waves step faster
         // combine: one latency chain per level; the first level of a long pair list runs in several rounds of 2048 waves
@@ -133,7 +149,7 @@ void launch_coarse_staged(uint32_t c, dim3 grid, hipStream_t s, const uint32_t* 
 }  // namespace
 
 void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, const uint8_t* d_flags, size_t n, unsigned fmt, bool shared_buckets,
-                       size_t stride, int ev0, SortOut& out) {
+                       size_t stride, int ev0, SortOut& out, const uint8_t* host_scalars) {
     const size_t entries_cap = (size_t)n * pl.nwin;
     d.hist.ensure(pl.nbuckets * 4);
     d.offsets.ensure((pl.nbuckets + 1) * 4);
@@ -145,6 +161,26 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
     hipStream_t s = d.stream;
     HIP_TRY(hipEventRecord(d.ev[ev0], s));
     // ---- two-level LDS-staged bucket sort (geometry in msmk::SortGeom)
+    // The count pass, per chunk of tiles: with host scalars chunk j is copied on the copy stream and counted as soon as it has
+    // landed, while chunk j + 1 is still crossing PCIe; device-resident scalars are one chunk.
+    auto feed_and_count = [&](msmk::SortGeom& gg, auto&& count_tiles) {
+        const uint32_t K = host_scalars ? std::min<uint32_t>(8, std::max<uint32_t>(1, std::min<uint32_t>(gg.tiles, (uint32_t)(n >> 16)))) : 1;
+        if (host_scalars) HIP_TRY(hipEventRecord(d.cev[0], d.copy_stream));
+        for (uint32_t j = 0; j < K; j++) {
+            const uint32_t t0 = (uint32_t)((uint64_t)gg.tiles * j / K), t1 = (uint32_t)((uint64_t)gg.tiles * (j + 1) / K);
+            if (host_scalars) {
+                const size_t p0 = (size_t)t0 * gg.tile_pts, p1 = std::min<size_t>(n, (size_t)t1 * gg.tile_pts);
+                HIP_TRY(hipMemcpyAsync((char*)const_cast<uint32_t*>(d_scalars) + p0 * 32, host_scalars + p0 * 32, (p1 - p0) * 32, hipMemcpyHostToDevice,
+                                       d.copy_stream));
+                HIP_TRY(hipEventRecord(d.cev[1 + j], d.copy_stream));
+                HIP_TRY(hipStreamWaitEvent(s, d.cev[1 + j], 0));
+            }
+            gg.tile0 = t0;
+            if (t1 > t0) count_tiles(t1 - t0);
+        }
+        gg.tile0 = 0;
+        if (host_scalars) HIP_TRY(hipEventRecord(d.cev[9], d.copy_stream));
+    };
     msmk::SortGeom g{};
     g.n = (uint32_t)n; g.fmt = fmt; g.c = pl.c; g.nwin = pl.nwin;
     g.shared = shared_buckets ? 1u : 0u;
@@ -186,8 +222,10 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
         d.bin_tot.ensure((size_t)nbinsA * 4);
         d.binA_base.ensure((size_t)(nbinsA + 1) * 4);
         d.coarseA.ensure(entries_cap * 8);
-        launch_coarseA<false>(pl.c, dim3(g.tiles), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p, (const uint32_t*)nullptr,
-                              (const uint32_t*)nullptr, (uint2*)nullptr);
+        feed_and_count(g, [&](uint32_t ntiles) {
+            launch_coarseA<false>(pl.c, dim3(ntiles), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p, (const uint32_t*)nullptr,
+                                  (const uint32_t*)nullptr, (uint2*)nullptr);
+        });
         hipLaunchKernelGGL(msmk::k_colscan, dim3((nbinsA + 255) / 256), dim3(256), 0, s, (const uint32_t*)d.tilecnt.p, nbinsA, g.tiles,
                            (uint32_t*)d.tileoff.p, (uint32_t*)d.bin_tot.p);
         hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.bin_tot.p, nbinsA, (uint32_t*)d.binA_base.p);
@@ -225,8 +263,10 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
     d.tilecnt.ensure((size_t)g.tiles * g.nbins * 4);
     d.tileoff.ensure((size_t)g.tiles * g.nbins * 4);
     d.bin_tot.ensure((size_t)g.nbins * 4);
-    launch_coarse<false>(pl.c, dim3(g.tiles, g.ngroups), dim3(coarse_block), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
-                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    feed_and_count(g, [&](uint32_t ntiles) {
+        launch_coarse<false>(pl.c, dim3(ntiles, g.ngroups), dim3(coarse_block), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
+                             (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    });
     hipLaunchKernelGGL(msmk::k_colscan, dim3((g.nbins + 255) / 256), dim3(256), 0, s, (const uint32_t*)d.tilecnt.p, g.nbins, g.tiles,
                        (uint32_t*)d.tileoff.p, (uint32_t*)d.bin_tot.p);
     hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.bin_tot.p, g.nbins, (uint32_t*)d.bin_base.p);

@@ -20,6 +20,7 @@ struct SortGeom {
     uint32_t n, fmt, c, nwin;
     uint32_t lo_bits, H;          // fine bits, coarse bins per window
     uint32_t tiles, tile_pts;     // point tiles (grid.x) and points per tile (multiple of 1024)
+    uint32_t tile0;               // first tile of this launch (count passes run per chunk of tiles while host scalars still arrive)
     uint32_t wgroup, ngroups;     // windows per group, groups (grid.y)
     uint32_t nbins;               // bucket windows * H
     uint32_t shared, stride;      // shared = 1: every digit window feeds ONE bucket set (precomputed 2^(c j) P tables of
@@ -33,7 +34,7 @@ __global__ void __launch_bounds__(1024) k_coarse(const uint32_t* __restrict__ sc
                                                  uint32_t* __restrict__ tilecnt, const uint32_t* __restrict__ tileoff,
                                                  const uint32_t* __restrict__ bin_base, uint32_t* __restrict__ coarse) {
     __shared__ uint32_t cnt[SORT_MAX_COUNTERS];
-    const uint32_t tile = blockIdx.x, grp = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
+    const uint32_t tile = blockIdx.x + g.tile0, grp = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
     uint32_t w0 = grp * g.wgroup, w1 = w0 + g.wgroup < g.nwin ? w0 + g.wgroup : g.nwin;
     const uint32_t bin0 = g.shared ? 0u : w0 * g.H;
     uint32_t ncnt = (g.shared ? 1u : (w1 - w0)) * g.H;
@@ -329,7 +330,7 @@ __global__ void __launch_bounds__(1024) k_coarseA(const uint32_t* __restrict__ s
                                                   uint32_t* __restrict__ tilecnt, const uint32_t* __restrict__ tileoff,
                                                   const uint32_t* __restrict__ binA_base, uint2* __restrict__ coarseA) {
     __shared__ uint32_t cnt[512];
-    const uint32_t tile = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+    const uint32_t tile = blockIdx.x + g.tile0, t = threadIdx.x, nt = blockDim.x;
     const uint32_t nbinsA = g.nwin * A_BINS;
     for (uint32_t k = t; k < nbinsA; k += nt) cnt[k] = SCATTER ? binA_base[k] + tileoff[(size_t)tile * nbinsA + k] : 0u;
     __syncthreads();

@@ -19,8 +19,8 @@ void mi_test_fail_allocs(int count);
 /* pretend that no device of the context can read another device's memory: device-resident scalars of a multi-device context are
  * then staged by peer copies (the path a node without full peer access takes) */
 int mi_test_set_no_peer(mi_ctx *ctx, int no_peer);
-/* the window-size plan of an n-point call (host only, no device): out[12] = c, windows, bucket sets, logL, chunk_log, logT, lo_bits,
- * serial reduce, chunks per window, buckets (hi, lo), chunks.  group 0 = G1, 1 = G2; c = 0 in out[0]: no usable plan */
+/* the window-size plan of an n-point call (host only, no device): out[13] = c, windows, bucket sets, logL, chunk_log, logT, lo_bits,
+ * serial reduce, chunks per window, buckets (hi, lo), chunks, buckets per lane of the serial reduce.  group 0 = G1, 1 = G2; c = 0 in out[0]: no usable plan */
 int mi_test_plan(size_t n, unsigned forced_c, int group, int shared, size_t stride, uint32_t *out);
 #ifdef __cplusplus
 }

@@ -64,9 +64,10 @@ enum {
 /* Per-call timing of the last MSM on this context, milliseconds, measured with HIP events on the
  * library's own stream (bench.py reads these for the roofline line). */
 typedef struct {
-    double h2d_ms;          /* host->device copies (0 for the device-resident entry points) */
-    double ingest_ms;       /* base conversion to the device field representation (0 when resident) */
-    double digits_ms;       /* signed-window digit extraction + histogram */
+    double h2d_ms;          /* host->device copies (0 for the device-resident entry points): host bases in chunks with their conversion
+                               to the device representation interleaved, host scalars in chunks on a copy stream */
+    double ingest_ms;       /* unused since the base conversion runs per chunk inside h2d_ms (0) */
+    double digits_ms;       /* signed-window digit extraction + histogram (host scalars: includes waiting for their chunks) */
     double scan_ms;         /* bucket offsets (prefix sum) */
     double scatter_ms;      /* bucket scatter (sort by bucket) */
     double accumulate_ms;   /* bucket accumulation (dominant kernel) + merge of split buckets */

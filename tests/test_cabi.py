@@ -179,14 +179,15 @@ def test_plan_geometry_invariants(pkg):
                     idx_bits = max(1, ((max(stride, n) * p["nwin"]) if shared else n) - 1).bit_length()
                     assert idx_bits + 1 + p["lo_bits"] <= 32 and p["lo_bits"] <= min(8, cc - 1)   # index | sign | fine bits in one word
                     assert (nb >> p["lo_bits"]) <= 16384                                      # coarse bins of a window fit the LDS counters
-                    assert p["chunk_log"] <= cc - 1 and p["chunks_per_win"] == nb >> p["chunk_log"]
                     assert p["nchunks"] == p["chunks_per_win"] * p["bwin"]
                     assert 5 <= p["logT"] <= 20
-                    if p["serial"]:
-                        assert group == "g1" and p["chunk_log"] == 6 and p["nbuckets"] >= 1 << 21
+                    if p["serial"]:   # one lane per serial_L buckets of a window (any L <= 64), ragged last lane
+                        assert group == "g1" and p["nbuckets"] >= 1 << 21 and 8 <= p["serial_L"] <= 64
+                        assert p["chunks_per_win"] == -(-nb // p["serial_L"])
                     else:
+                        assert p["chunk_log"] <= cc - 1 and p["chunks_per_win"] == nb >> p["chunk_log"] and p["serial_L"] == 0
                         assert p["chunk_log"] == p["logL"] + (4 if group == "g1" else 5) and p["logL"] <= 6
     # the sizes the benchmark configs use keep their measured choices
     assert pkg.test_plan(1 << 20)["c"] == 16 and pkg.test_plan(1 << 21)["c"] == 16 and pkg.test_plan(1 << 23)["c"] == 16
-    assert pkg.test_plan(1 << 24)["c"] == 20 and pkg.test_plan(1 << 24)["serial"] == 1
+    assert pkg.test_plan(1 << 24)["c"] == 20 and pkg.test_plan(1 << 24)["serial"] == 1 and pkg.test_plan(1 << 24)["serial_L"] == 53
     assert pkg.test_plan(1 << 20, 0, "g2")["c"] == 16

@@ -849,3 +849,31 @@ def test_device_windows_and_fold_equal_msm(pkg, co, group):
             with pytest.raises(pkg.MsmError) as e:
                 c2.msm_device_windows(group, d.data_ptr(), 100, pkg.SCALAR_CANONICAL, wins[0].data_ptr())
             assert e.value.code == -1
+
+
+@pytest.mark.parametrize("n", [(1 << 18) + 12345, (1 << 17) - 1, 65537])
+def test_host_slices_cross_pcie_in_chunks(ctx, co, pkg, n):
+    """The trait's call shape — host slices (/root/reference/src/g1.rs:604,623; uploaded per call at src/gpu.rs:149-150): above 2^16
+    points the bases and the scalars are copied in several chunks on a copy stream, each ingested / counted as it lands.  Odd sizes,
+    so the chunks are ragged; both scalar formats; host bases and resident bases."""
+    bases = co.gen_bases("g1", SEED_B + 270, n, 8)
+    scalars = co.gen_scalars(SEED_S + 270, n)
+    want = co.dlog_expected("g1", scalars, SEED_B + 270, n)
+    assert _canon(co, "g1", ctx.msm("g1", bases, scalars, n, pkg.SCALAR_CANONICAL)) == want
+    ctx.set_bases("g1", bases, n)
+    assert _canon(co, "g1", ctx.msm("g1", None, scalars, n, pkg.SCALAR_CANONICAL)) == want
+    mont = co.fr_to_mont(scalars)
+    assert _canon(co, "g1", ctx.msm("g1", None, mont, n, pkg.SCALAR_MONTGOMERY)) == want
+    m = n - 4097   # a prefix of the resident set
+    assert _canon(co, "g1", ctx.msm("g1", None, scalars[:32 * m], m, pkg.SCALAR_CANONICAL)) == co.dlog_expected("g1", scalars[:32 * m], SEED_B + 270, m)
+
+
+def test_host_slices_in_chunks_g2_and_large_window(pkg, co):
+    """the same for G2 and for a window size of the three-level sort (c = 18 forced), whose count pass is the other chunked kernel"""
+    n = (1 << 17) + 77
+    for group, c in (("g2", 0), ("g1", 18)):
+        bases = co.gen_bases(group, SEED_B + 271, n, 8)
+        scalars = co.gen_scalars(SEED_S + 271, n)
+        with pkg.Context([0]) as cx:
+            cx.set_window_bits(c)
+            assert _canon(co, group, cx.msm(group, bases, scalars, n, pkg.SCALAR_CANONICAL)) == co.dlog_expected(group, scalars, SEED_B + 271, n)
