@@ -171,7 +171,12 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_g2_coop(const uint32_t* __
         if (ec::xyzz_madd<FA>(acc, x, y)) break;  // exceptional pair at entry e (pair-wide decision): acc untouched
         e++;
     }
-    g2_coop_finish(bases, sorted, e, end, inf, reinterpret_cast<const ec::Xyzz<CoopF2>&>(acc), partial + (size_t)i * G2_BK_WORDS + 16 * h);
+    // the tail takes a COPY made after the loop: passing `acc` itself by reference makes the loop variable address-taken, and the
+    // compiler then keeps it in scratch and writes all 224 bytes back on every iteration (7.9 GB of scratch writes per launch at
+    // 2^20 points, profiles/r03_g2_2p20_* first take) although the code object reports no spill
+    ec::Xyzz<CoopF2> fin;
+    fin.x = acc.x; fin.y = acc.y; fin.zz = acc.zz; fin.zzz = acc.zzz;
+    g2_coop_finish(bases, sorted, e, end, inf, fin, partial + (size_t)i * G2_BK_WORDS + 16 * h);
 }
 
 // One binary-tree level of the per-bucket merge of split buckets: partial[i] += partial[i + d] for the items whose

@@ -96,7 +96,7 @@ HT::E12 device_miller(mi_ctx* ctx, DevState& d, const mi_g1_affine* p, const mi_
         for (uint32_t m = 1; m <= 8; m++) {
             const double waves = std::ceil(std::ceil((double)batch_pairs / m) / msmk::MILLER_GROUPS);
             const double r = std::max(1.0, std::ceil(waves / slots));
-            const double cost = (1.0 + 0.53 * m) * (r == 1.0 ? 1.0 : 0.92 * r);
+            const double cost = (1.0 + 0.53 * m) * r;   // the kernel is built for one wave per SIMD: a second round of waves waits for the first
             if (!share || cost < best) { best = cost; share = m; }
         }
     }

@@ -225,27 +225,67 @@ __device__ __forceinline__ void lds_store_fp2(uint32_t* p, const ec::Fp2& a) {
     store_fp16(p, a.c0);
     store_fp16(p + 16, a.c1);
 }
-// (c0, c1) += a * g * xi^[wrapped]   with a <= 4p (an exact coefficient or twice one), g exact (< 2p): four products
-// into the two column sets.  Bounds: xi a <= (12p, 8p) in N-form, 4p - g1 <= 4p: a term adds <= 56 p^2 to a component,
-// at most six terms per reduction (limit 2520 p^2); <= 168 column terms of < 2^56.01 plus the reduction's 2^59.9 stay
-// below 2^64.
-// GK = 4: g exact (< 2p); GK = 8: g <= 6p in N-form (a line's c0 as the line kernel leaves it): a term then adds
-// <= 12 * 6 + 8 * 8 = 136 p^2, three line terms per reduction.
-template <int GK = 4>
-__device__ __forceinline__ void fp2_acc_term(uint64_t (&c0)[2 * fp28::NL], uint64_t (&c1)[2 * fp28::NL], const ec::Fp2& a, bool wrapped,
-                                             const ec::Fp2& g) {
+// Karatsuba accumulation of Fp2 products (round 3).  A lane's coefficient h_k = sum_t xi^[wrapped] a_t g_t is collected in THREE
+// column sets  V0 += a0' g0,  V1 += a1' g1,  V2 += (a0' + a1')(g0 + g1)   (a' = a or xi a = (a0 - a1, a0 + a1))  — three products
+// per term instead of four — and recombined ONCE per coefficient:  c0 = V0 - V1 (+ bias),  c1 = V2 - V0 - V1.  The recombined
+// columns are signed (a column of V1 may exceed the same column of V0): the reduction below carries with arithmetic shifts.
+// c1 = a0' g1 + a1' g0 is non-negative as a number; c0 gets the bias p 2^388 (a multiple of p: P[j] << 24 added to column 13 + j),
+// which exceeds every V1 reached here (<= 144 p^2 ~ 2^387.9 p) and keeps the reduction's input below 373 p^2 of the 2520 p^2 it
+// may take, so every output is < 2p as before.  Operand bounds: a' <= (12p, 8p) in N-form, g <= 6p in N-form (a line's c0; exact
+// coefficients are < 2p), sums a0' + a1' and g0 + g1 normalised: <= 4 terms x 14 products of < 2^56.2 per column set, |column| < 2^62.
+// 168 registers of columns: the kernels below are built for ONE wave per SIMD (512 registers) — which costs nothing, a lone wave
+// of a 64-thread workgroup issues at the SIMD's full rate (tools/ubench_fp52.hip: 2484 vs 2447 cycles per multiplication).
+struct KaraCols {
+    uint64_t v0[2 * fp28::NL], v1[2 * fp28::NL], v2[2 * fp28::NL];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int t = 0; t < 2 * fp28::NL; t++) { v0[t] = 0; v1[t] = 0; v2[t] = 0; }
+    }
+};
+__device__ __forceinline__ void fp2_acc_term(KaraCols& c, const ec::Fp2& a, bool wrapped, const ec::Fp2& g) {
     Fp xa0 = fp28::fp_sub<8>(a.c0, a.c1), xa1 = fp28::fp_add(a.c0, a.c1);
     Fp a0 = fp28::fp_select(wrapped, a.c0, xa0), a1 = fp28::fp_select(wrapped, a.c1, xa1);
-    Fp ng1 = fp28::fp_neg<GK>(g.c1);
-    fp_acc(c0, a0, g.c0);
-    fp_acc(c0, a1, ng1);
-    fp_acc(c1, a0, g.c1);
-    fp_acc(c1, a1, g.c0);
+    fp_acc(c.v0, a0, g.c0);
+    fp_acc(c.v1, a1, g.c1);
+    fp_acc(c.v2, fp28::fp_add(a0, a1), fp28::fp_add(g.c0, g.c1));
+}
+// Montgomery reduction of SIGNED 64-bit columns (|column| < 2^62, value in [0, 2^392 p)): fp28::fp_mont_reduce with arithmetic carries
+__device__ __forceinline__ Fp fp_mont_reduce_signed(int64_t (&c)[2 * fp28::NL]) {
+    using namespace fp28;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        uint32_t m = ((uint32_t)c[i] * PINV) & MASK;
+#pragma unroll
+        for (int j = 0; j < NL; j++) c[i + j] += (int64_t)((uint64_t)m * P[j]);
+        c[i + 1] += c[i] >> W;   // exact: the low 28 bits are zero
+    }
+    Fp r;
+    int64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        int64_t v = c[NL + k] + carry;
+        r.l[k] = (uint32_t)v & MASK;
+        carry = v >> W;
+    }
+    r.l[NL - 1] |= (uint32_t)carry << W;
+    return r;
+}
+__device__ __forceinline__ ec::Fp2 fp2_kara_reduce(const KaraCols& c) {
+    int64_t c0[2 * fp28::NL], c1[2 * fp28::NL];
+#pragma unroll
+    for (int t = 0; t < 2 * fp28::NL; t++) {
+        const uint64_t w = c.v0[t] + c.v1[t];
+        c0[t] = (int64_t)(c.v0[t] - c.v1[t]);
+        c1[t] = (int64_t)(c.v2[t] - w);
+    }
+#pragma unroll
+    for (int j = 0; j < fp28::NL; j++) c0[fp28::NL - 1 + j] += (int64_t)((uint64_t)fp28::P[j] << 24);   // + p 2^388
+    return ec::Fp2{fp_mont_reduce_signed(c0), fp_mont_reduce_signed(c1)};
 }
 
 // `m` consecutive pairs share one accumulator: f <- f^2 * l_1 * ... * l_m per step (the multi-Miller-loop trick: one squaring
 // for m pairs, as blst's miller_loop_n does); out[g] = product of the Miller values of pairs [g m, g m + m).
-__global__ void __launch_bounds__(64, 2) k_miller_accumulate(const uint32_t* __restrict__ lines, uint32_t n, uint32_t m, uint32_t blk,
+__global__ void __launch_bounds__(64, 1) k_miller_accumulate(const uint32_t* __restrict__ lines, uint32_t n, uint32_t m, uint32_t blk,
                                                              uint32_t* __restrict__ out) {
     __shared__ uint32_t fs[(MILLER_GROUPS + 1) * 6 * LDS_COEFF_WORDS];   // + one dummy group for the idle lanes
     const uint32_t lane = threadIdx.x;
@@ -265,39 +305,55 @@ __global__ void __launch_bounds__(64, 2) k_miller_accumulate(const uint32_t* __r
         uint32_t j = (k + 6 - i) % 6;
         if (i <= j) sq_tab |= i << (3 * sq_cnt++);
     }
-    // h_k = sum over the three non-zero line coefficients at w^0, w^2, w^3
+    // h_k = sum over the three non-zero line coefficients at w^0, w^2, w^3.  The three coefficients of the NEXT pair's line are
+    // requested before the current pair's products are computed (84 more registers, which one wave per SIMD has): a lone wave has
+    // nobody to cover a load's latency, and with the loads inside a rolled term loop every term waited for its own.
+    auto line_ptr = [&](uint32_t q) {
+        const bool live = first + q < n;
+        return lines + line_base_words(live ? first + q : n - 1, blk) + (size_t)line * blk * 96;
+    };
     auto mul_line = [&]() {   // f <- f * (line `line` of pair first + q) for q < m; a pair beyond n multiplies by one
+        ec::Fp2 g0, g1, g2;
+        {
+            const uint32_t* lp = line_ptr(0);
+            ElemIO<ec::Fp2>::load(g0, lp); ElemIO<ec::Fp2>::load(g1, lp + 32); ElemIO<ec::Fp2>::load(g2, lp + 64);
+        }
 #pragma unroll 1
         for (uint32_t q = 0; q < m; q++) {
             const bool live = first + q < n;
-            const uint32_t* lp = lines + line_base_words(live ? first + q : n - 1, blk) + (size_t)line * blk * 96;
-            uint64_t c0[2 * fp28::NL], c1[2 * fp28::NL];
-#pragma unroll
-            for (int t = 0; t < 2 * fp28::NL; t++) { c0[t] = 0; c1[t] = 0; }
-#pragma unroll 1
-            for (int t = 0; t < 3; t++) {
-                int pos = t == 0 ? 0 : t + 1;                            // 0, 2, 3
-                int j = (int)k - pos;
+            ec::Fp2 n0 = g0, n1 = g1, n2 = g2;
+            if (q + 1 < m) {
+                const uint32_t* lp = line_ptr(q + 1);
+                ElemIO<ec::Fp2>::load(n0, lp); ElemIO<ec::Fp2>::load(n1, lp + 32); ElemIO<ec::Fp2>::load(n2, lp + 64);
+            }
+            KaraCols cols;
+            cols.clear();
+            {   // terms at w^0, w^2, w^3: f_j with j = k, k - 2, k - 3 (mod 6), times xi when the index wrapped
+                int j = (int)k;
+                fp2_acc_term(cols, lds_load_fp2(fg + j * LDS_COEFF_WORDS), false, g0);
+                j = (int)k - 2;
                 bool wrapped = j < 0;
                 if (wrapped) j += 6;
-                ec::Fp2 g;
-                ElemIO<ec::Fp2>::load(g, lp + 32 * t);
-                fp2_acc_term<8>(c0, c1, lds_load_fp2(fg + j * LDS_COEFF_WORDS), wrapped, g);
+                fp2_acc_term(cols, lds_load_fp2(fg + j * LDS_COEFF_WORDS), wrapped, g1);
+                j = (int)k - 3;
+                wrapped = j < 0;
+                if (wrapped) j += 6;
+                fp2_acc_term(cols, lds_load_fp2(fg + j * LDS_COEFF_WORDS), wrapped, g2);
             }
-            ec::Fp2 r{fp28::fp_mont_reduce(c0), fp28::fp_mont_reduce(c1)};
+            ec::Fp2 r = fp2_kara_reduce(cols);
             own = ec::Fp2Ops::select(live, own, r);
             __syncthreads();                                             // every lane has read the old f
             lds_store_fp2(fg + k * LDS_COEFF_WORDS, own);
             __syncthreads();
+            g0 = n0; g1 = n1; g2 = n2;
         }
         line++;
     };
 #pragma unroll 1
     for (int b = 62; b >= 0; b--) {
         {   // f <- f^2 : h_k = sum over unordered {i, j}, i + j = k (mod 6), of (2 - [i == j]) xi^[i + j >= 6] f_i f_j
-            uint64_t c0[2 * fp28::NL], c1[2 * fp28::NL];
-#pragma unroll
-            for (int t = 0; t < 2 * fp28::NL; t++) { c0[t] = 0; c1[t] = 0; }
+            KaraCols cols;
+            cols.clear();
 #pragma unroll 1
             for (uint32_t t = 0; t < 4; t++) {
                 uint32_t i = (sq_tab >> (3 * t)) & 7u;
@@ -307,10 +363,9 @@ __global__ void __launch_bounds__(64, 2) k_miller_accumulate(const uint32_t* __r
                 ec::Fp2 a2 = ec::Fp2Ops::add(a, a);
                 a = ec::Fp2Ops::select((int)i != j, a, a2);
                 a = ec::Fp2Ops::select(t >= sq_cnt, a, ec::Fp2Ops::zero());          // odd k has three terms only
-                fp2_acc_term(c0, c1, a, i + (uint32_t)j >= 6, lds_load_fp2(fg + j * LDS_COEFF_WORDS));
+                fp2_acc_term(cols, a, i + (uint32_t)j >= 6, lds_load_fp2(fg + j * LDS_COEFF_WORDS));
             }
-            own.c0 = fp28::fp_mont_reduce(c0);
-            own.c1 = fp28::fp_mont_reduce(c1);
+            own = fp2_kara_reduce(cols);
             __syncthreads();
             lds_store_fp2(fg + k * LDS_COEFF_WORDS, own);
             __syncthreads();
@@ -348,9 +403,8 @@ __global__ void __launch_bounds__(64, 1) k_fp12_prod(const uint32_t* __restrict_
         // again and discards the result
         const bool live = lo + e < hi;
         const uint32_t* gp = in + (size_t)(live ? lo + e : hi - 1) * FP12_WORDS;
-        uint64_t c0[2 * fp28::NL], c1[2 * fp28::NL];
-#pragma unroll
-        for (int t = 0; t < 2 * fp28::NL; t++) { c0[t] = 0; c1[t] = 0; }
+        KaraCols cols;
+        cols.clear();
 #pragma unroll 1
         for (int i = 0; i < 6; i++) {
             int j = (int)k - i;
@@ -358,9 +412,9 @@ __global__ void __launch_bounds__(64, 1) k_fp12_prod(const uint32_t* __restrict_
             if (wrapped) j += 6;
             ec::Fp2 gj;
             ElemIO<ec::Fp2>::load(gj, gp + slot((uint32_t)j));
-            fp2_acc_term(c0, c1, lds_load_fp2(fg + i * LDS_COEFF_WORDS), wrapped, gj);
+            fp2_acc_term(cols, lds_load_fp2(fg + i * LDS_COEFF_WORDS), wrapped, gj);
         }
-        ec::Fp2 r{fp28::fp_mont_reduce(c0), fp28::fp_mont_reduce(c1)};
+        ec::Fp2 r = fp2_kara_reduce(cols);
         own = ec::Fp2Ops::select(live, own, r);
         __syncthreads();
         lds_store_fp2(fg + k * LDS_COEFF_WORDS, own);

@@ -101,11 +101,60 @@ def is_hot(name: str) -> bool:
     return any(h in name for h in HOT)
 
 
+def scratch_in_hot_loops(lib: str | None = None) -> dict[str, int]:
+    """Scratch loads / stores INSIDE the arithmetic loops of the hot kernels, read off the disassembly of the shipped code objects.
+    A loop = the span of a backward branch; "arithmetic" = it holds at least 500 v_mad_u64_u32 (an inlined multiplier: the cold
+    loops call out-of-line bodies and pass their operands through scratch legitimately).  The code-object metadata cannot see
+    this: a loop variable whose address escapes is kept in scratch and written back every iteration with vgpr_spill_count = 0
+    (round 3: 7.9 GB of scratch writes per launch of the G2 accumulate kernel until the tail took a copy)."""
+    lib = lib or os.path.join(ROOT, "ark-blst_amd", "lib", "libarkblst_amd.so")
+    out: dict[str, int] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for elf in code_objects(lib, tmp):
+            txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", elf], capture_output=True, text=True, check=True).stdout
+            sym, base, ins = None, 0, []   # ins: (offset, mnemonic, branch target offset or None)
+            blocks = []
+            for line in txt.splitlines():
+                m = re.match(r"^([0-9a-f]{16}) <(.+)>:$", line)
+                if m:
+                    if sym is not None:
+                        blocks.append((sym, ins))
+                    sym, base, ins = m.group(2), int(m.group(1), 16), []
+                    continue
+                m = re.match(r"^\s+(\S+).*// ([0-9A-F]{12}):", line)
+                if m and sym is not None:
+                    tgt = None
+                    if m.group(1).startswith(("s_cbranch", "s_branch")):
+                        t = re.search(r"<[^>]*\+0x([0-9a-f]+)>", line)
+                        tgt = int(t.group(1), 16) if t else 0
+                    ins.append((int(m.group(2), 16) - base, m.group(1), tgt))
+            if sym is not None:
+                blocks.append((sym, ins))
+            names = demangle([b[0] for b in blocks])
+            for raw, ins in blocks:
+                name = names[raw]
+                if not is_hot(name):
+                    continue
+                bad = 0
+                for off, mn, tgt in ins:
+                    if tgt is None or tgt >= off:
+                        continue
+                    body = [i for i in ins if tgt <= i[0] <= off]
+                    if sum(1 for i in body if i[1] == "v_mad_u64_u32") >= 500:
+                        bad = max(bad, sum(1 for i in body if i[1].startswith("scratch_")))
+                out[name] = bad
+    return out
+
+
 def main() -> None:
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     res = resources(args[0] if args else None)
     if "--json" in sys.argv:
         print(json.dumps(res, indent=1, sort_keys=True))
+        return
+    if "--loops" in sys.argv:
+        for k, v in sorted(scratch_in_hot_loops(args[0] if args else None).items()):
+            print(f"{v:5d} scratch instructions inside arithmetic loops   {k[:110]}")
         return
     print(f"{'kernel':100s} vgpr agpr  spill scratch    lds")
     for name in sorted(res):

@@ -26,9 +26,13 @@ line = [l for l in open(f"{src}/bench_line_under_rocprof.json") if l.startswith(
 if line:
     open(f"profiles/{tag}_bench_line_under_rocprof.json", "w").write(line[-1])
 out = collections.defaultdict(dict)
-for name in ("fetch", "write", "sq"):
+for name in ("fetch", "write", "sq", "stall", "stall2"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(newest(f"{src}/{name}/**/*counter_collection.csv"))):
+    try:
+        path = newest(f"{src}/{name}/**/*counter_collection.csv")
+    except ValueError:
+        continue   # optional pass (stall counters) not collected for this workload
+    for r in csv.DictReader(open(path)):
         acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         for c, xs in v.items():
