@@ -85,7 +85,11 @@ struct CoopF2A : CoopF2 {
     static __device__ __forceinline__ E neg_l(const E& a) { return fp28::fp_neg<K>(a); }
     static __device__ __forceinline__ E sub8_wide(const E& a, const E& b) { return fp28::fp_sub<8>(a, b); }
     static __device__ __forceinline__ E norm(const E& a) { return a; }
-    static __device__ __forceinline__ bool is_zero_2p(const E& a) { return pair_and(fp28::fp_is_zero_2p(a)); }
+    static __device__ __forceinline__ bool is_zero_2p(const E& a) {   // a: a multiplier output (exact limbs)
+        const bool maybe = a.l[0] == 0 || a.l[0] == fp28::P[0];        // this lane's component could be 0 or p
+        if (!pair_and(maybe)) return false;                              // pair-wide and practically always the answer
+        return pair_and(fp28::fp_is_zero_2p(a));
+    }
     static __device__ __forceinline__ bool limbs_all_zero(const E& a) { return pair_and(ec::FpOps::limbs_all_zero(a)); }
 };
 

@@ -68,6 +68,7 @@ struct FpOpsInline : FpOps {
     static FP_HD E mul(const E& a, const E& b) { return fp28::fp_mul_os(a, b); }
     static FP_HD E sqr(const E& a) { return fp28::fp_sqr_os(a); }
     static FP_HD E mul2add(const E& a, const E& b, const E& c, const E& d) { return fp28::fp_mul2add_os(a, b, c, d); }
+    static FP_HD bool is_zero_2p(const E& a) { return fp28::fp_is_zero_2p_exact(a); }   // only ever asked of a multiplier output
     // truly lazy linear operations (no carry pass); limb bounds proved in tools/bounds_check.py check_madd_lazy()
     static FP_HD E add_l(const E& a, const E& b) { return fp28::fp_add_lazy(a, b); }
     template <int K>

@@ -191,6 +191,9 @@ def test_plan_geometry_invariants(pkg):
                     else:
                         assert p["chunk_log"] <= cc - 1 and p["chunks_per_win"] == nb >> p["chunk_log"] and p["serial_L"] == 0
                         assert p["chunk_log"] == p["logL"] + (4 if group == "g1" else 5) and p["logL"] <= 6
+    # no window size fits the entry encoding of precomputed tables beyond ~9e7 points per device (n x windows > 2^30 entries): the plan
+    # says so (c = 0) and mi_msm_g1_set_bases_precomputed turns that into MI_E_INVALID before it divides by c
+    assert pkg.test_plan(100_000_000, 0, "g1", True, 100_000_000)["c"] == 0
     # the sizes the benchmark configs use keep their measured choices
     assert pkg.test_plan(1 << 20)["c"] == 16 and pkg.test_plan(1 << 21)["c"] == 16 and pkg.test_plan(1 << 23)["c"] == 16
     assert pkg.test_plan(1 << 24)["c"] == 20 and pkg.test_plan(1 << 24)["serial"] == 1 and pkg.test_plan(1 << 24)["serial_L"] == 53

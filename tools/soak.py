@@ -11,6 +11,12 @@ case, which changes the resident base set, is then left out.
 import json, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+try:
+    import torch   # first: its bundled HIP runtime must be the one the process loads (load order)
+    if not torch.cuda.is_available():
+        torch = None
+except Exception:
+    torch = None
 import __graft_entry__ as ge
 from oracle import coracle as co, bls12_381 as o
 pkg = ge.load_package()
@@ -19,7 +25,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 nthreads = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 rnd = random.Random(seed)
 ncpu = min(16, len(os.sched_getaffinity(0)))
-POOL = {"g1": 60000, "g2": 20000}
+POOL = {"g1": 200000, "g2": 20000}   # G1 calls above 2^16 / 2^17 points cross PCIe in several chunks (host slices)
 pools = {g: co.gen_bases(g, 900 + seed + i, POOL[g], ncpu) for i, g in enumerate(("g1", "g2"))}
 AFF = {"g1": 96, "g2": 192}
 
@@ -64,7 +70,7 @@ def loop(ctx, rnd, tid):
                 if co.to_affine(g, got) != co.to_affine(g, co.msm(g, bases, canon, m, 0, ncpu)):
                     print("PRECOMPUTED MISMATCH", seed, g, n, m, kind); failed.append(1); return
                 stats["precomputed"] = stats.get("precomputed", 0) + 1; stats["points"] += m
-            ctx.set_bases(g, bases[:aff], 1)   # drop the tables
+            ctx.set_bases(g, bases[:aff], 1)   # drop the tables (the W x allocation is given back: DevBuf::ensure_fit)
         elif r < 0.06 and nthreads == 1:   # batch entry point over a resident base set (two MSMs in flight on the context's lanes)
             g = rnd.choice(["g1", "g1", "g2"])
             aff, lim = AFF[g], POOL[g]
@@ -79,6 +85,35 @@ def loop(ctx, rnd, tid):
                 if co.to_affine(g, x) != co.to_affine(g, co.msm(g, bases, v, n, 0, ncpu)):
                     print("BATCH MISMATCH", seed, g, n, k); failed.append(1); return
             stats["batch"] = stats.get("batch", 0) + 1; stats["points"] += n * k
+        elif r < 0.09 and nthreads == 1 and torch is not None:   # exchange entry points: window sums left in device memory, folded on the host
+            g = rnd.choice(["g1", "g1", "g2"])
+            aff, size = AFF[g], (144 if g == "g1" else 288)
+            n = rnd.randrange(1, POOL[g] // 2)
+            ranks = rnd.randrange(1, 4)
+            cuts = sorted([0, n] + [rnd.randrange(0, n + 1) for _ in range(ranks - 1)])
+            start = rnd.randrange(0, POOL[g] - n + 1)
+            bases = pools[g][aff * start:aff * (start + n)]
+            canon = b"".join(o.fr_to_canon_bytes(rnd.randrange(o.R_ORDER)) for _ in range(n))
+            d = torch.frombuffer(bytearray(canon), dtype=torch.uint8).cuda()
+            win = torch.zeros(pkg.MAX_WINDOWS * size, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            c = rnd.choice([9, 11, 13, 16])   # ragged shards: one window size for all of them
+            ctx.set_window_bits(c)
+            gathered, info = b"", None
+            try:
+                for k in range(ranks):
+                    lo, hi = cuts[k], cuts[k + 1]
+                    if hi == lo:
+                        continue
+                    ctx.set_bases(g, bases[aff * lo:aff * hi], hi - lo)
+                    info = ctx.msm_device_windows(g, d.data_ptr() + 32 * lo, hi - lo, pkg.SCALAR_CANONICAL, win.data_ptr())
+                    gathered += win.cpu().numpy().tobytes()[:info[1] * size]
+            finally:
+                ctx.set_window_bits(0)
+            got = pkg.fold_windows(g, gathered, len(gathered) // (info[1] * size), info[1], *info)
+            if co.to_affine(g, got) != co.to_affine(g, co.msm(g, bases, canon, n, 0, ncpu)):
+                print("WINDOWS MISMATCH", seed, g, n, ranks, c); failed.append(1); return
+            stats["windows"] = stats.get("windows", 0) + 1; stats["points"] += n
         elif r < 0.15:
             n = rnd.choice([1, 2, 9, 10, 11, 63, 64, 65, rnd.randrange(1, 3000)])
             i1 = [rnd.randrange(POOL["g1"]) for _ in range(n)]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Size sweep on one MI355X: ms per MSM call (resident bases, device scalars) for G1 / G2 at 2^lo..2^hi, with the plan's
 window size and phase times, and — with --scan-c — the same for every forced window size (to check the time model).
-    python tools/sweep_sizes.py g1 12 24 [--scan-c]"""
+    python tools/sweep_sizes.py g1 12 24 [--scan-c | --scan-c=LO,HI]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,7 +12,11 @@ pkg = ge.load_package()
 g = sys.argv[1] if len(sys.argv) > 1 else "g1"
 lo = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 hi = int(sys.argv[3]) if len(sys.argv) > 3 else 22
-scan = "--scan-c" in sys.argv
+scan = any(a.startswith("--scan-c") for a in sys.argv)   # --scan-c or --scan-c=LO,HI
+c_lo, c_hi = 8, 22
+for a in sys.argv:
+    if a.startswith("--scan-c="):
+        c_lo, c_hi = (int(x) for x in a.split("=")[1].split(","))
 nmax = 1 << hi
 bases = co.gen_bases(g, 77, nmax, 16)
 scalars = co.gen_scalars(78, nmax)
@@ -23,7 +27,7 @@ with pkg.Context([0]) as ctx:
     for ln in range(lo, hi + 1):
         n = 1 << ln
         want = co.dlog_expected(g, scalars[:32 * n], 77, n)
-        for c in ([0] + list(range(8, 23)) if scan else [0]):
+        for c in ([0] + list(range(c_lo, c_hi + 1)) if scan else [0]):
             try:
                 ctx.set_window_bits(c)
                 r = ctx.msm_device(g, d.data_ptr(), n, 0)
