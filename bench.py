@@ -40,6 +40,11 @@ MADS_PER_FP_MUL = 300                          # 12^2 + 12^2 +
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8 TB/s spec
 MAD_PEAK_T = 39.3                              # 1024 SIMD x 64 lanes x 2.4 GHz / 4 cycles (v_mad_u64_u32 theoretical issue rate)
 MAD_MEASURED_T = 33.4                          # tools/ubench_valu.hip on MI355X: what a pure MAD loop reaches (profiles/r01_ubench_valu.txt)
+# k_accumulate<G1C>: instructions of one mixed addition in the shipped code object (tools/kernel_resources.py + llvm-objdump) priced
+# with the measured per-instruction costs at two waves per SIMD (profiles/r03_ubench_carry.txt): 3542 v_mad_u64_u32 x 4.8 + 126 v_mul_lo x 4.4
+# + 234 v_lshrrev_b64 x 4.6 + 235 v_lshl_add_u64 x 5.05 + 257 v_and x 2.6 + ~330 others x 2.6
+G1_ADD_INSTRUCTION_COST_CYCLES = 21300.0
+SIMDS, CLOCK_HZ = 1024, 2.4e9
 PAIRING_FP_MULS_PER_PAIR = 63 * (31 + 39) + 5 * (41 + 39)   # line + sparse Fp12 product per step, squarings shared
 
 
@@ -154,6 +159,8 @@ def _rooflines(g: str, n: int, log_n, acc_ms: float, nwin: int, precomputed: boo
     traffic, src = _traffic(g, log_n, precomputed) if log_n is not None else (None, None)
     mads = nwin * FP_MULS_PER_ADD[g] * MADS_PER_FP_MUL       # window-aware: one mixed addition per point and window
     tmad = mads * n / (acc_ms * 1e-3) / 1e12
+    # cycles one SIMD spends per wave-wide mixed addition (64 additions), incl. the per-bucket set-up and the kernel's tail
+    cyc_per_wave_add = acc_ms * 1e-3 * CLOCK_HZ * SIMDS / (nwin * n / 64.0)
     return {
         "roofline": {"bound": "hbm", "kernel": "k_accumulate<G1C>" if g == "g1" else "k_accumulate_g2_coop<G2C>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": alg_bytes,
@@ -163,7 +170,12 @@ def _rooflines(g: str, n: int, log_n, acc_ms: float, nwin: int, precomputed: boo
         "valu_roofline": {"model_mads_per_point": mads, "model": f"{nwin} windows x {FP_MULS_PER_ADD[g]} Fp-mul x {MADS_PER_FP_MUL} MAD",
                           "achieved_Tmad_s": tmad, "peak_Tmad_s": MAD_PEAK_T, "frac": tmad / MAD_PEAK_T,
                           "measured_peak_Tmad_s": MAD_MEASURED_T, "frac_of_measured_peak": tmad / MAD_MEASURED_T,
-                          "note": "integer VALU (v_mad_u64_u32) is the real bound of this path; HBM frac is low by construction"},
+                          "cycles_per_wave_addition": cyc_per_wave_add,
+                          "instruction_cost_sum_cycles": G1_ADD_INSTRUCTION_COST_CYCLES if g == "g1" else None,
+                          "frac_of_instruction_cost_bound": (G1_ADD_INSTRUCTION_COST_CYCLES / cyc_per_wave_add) if g == "g1" else None,
+                          "note": "integer VALU (v_mad_u64_u32) is the real bound of this path; HBM frac is low by construction.  "
+                                  "frac prices the MODEL's 3000 multiply-adds per addition at 4 cycles; the kernel executes 4770 instructions "
+                                  "per addition (3542 multiply-adds at a measured 4.8 cycles) and runs at the sum of their measured costs"},
     }
 
 
