@@ -232,7 +232,7 @@ __device__ __forceinline__ void lds_store_fp2(uint32_t* p, const ec::Fp2& a) {
 // c1 = a0' g1 + a1' g0 is non-negative as a number; c0 gets the bias p 2^388 (a multiple of p: P[j] << 24 added to column 13 + j),
 // which exceeds every V1 reached here (<= 144 p^2 ~ 2^387.9 p) and keeps the reduction's input below 373 p^2 of the 2520 p^2 it
 // may take, so every output is < 2p as before.  Operand bounds: a' <= (12p, 8p) in N-form, g <= 6p in N-form (a line's c0; exact
-// coefficients are < 2p), sums a0' + a1' and g0 + g1 normalised: <= 4 terms x 14 products of < 2^56.2 per column set, |column| < 2^62.
+// coefficients are < 2p), sums a0' + a1' and g0 + g1 normalised: <= 6 terms x 14 products of < 2^56.01 per column set (see fp2_kara_reduce).
 // 168 registers of columns: the kernels below are built for ONE wave per SIMD (512 registers) — which costs nothing, a lone wave
 // of a 64-thread workgroup issues at the SIMD's full rate (tools/ubench_fp52.hip: 2484 vs 2447 cycles per multiplication).
 struct KaraCols {
@@ -270,17 +270,24 @@ __device__ __forceinline__ Fp fp_mont_reduce_signed(int64_t (&c)[2 * fp28::NL]) 
     r.l[NL - 1] |= (uint32_t)carry << W;
     return r;
 }
+// Column ranges (tests/test_host_model.py::test_karatsuba_column_and_bias_bounds restates them with big integers):
+//   c0 = V0 - V1 + bias is SIGNED per column, |column| <= max(V0, V1) column <= 6 terms x 14 products x 2^56.01 = 2^62.4, plus the bias
+//        (< 2^52) and the reduction's own 14 x 2^56: inside +-2^63;
+//   c1 = V2 - V0 - V1 is NON-NEGATIVE per column — the Karatsuba identity holds column by column: it is the sum of the cross
+//        products a0'_i g1_j + a1'_i g0_j — and may reach 6 x 14 x 2 x 2^56.01 = 2^63.4: it must be reduced as an UNSIGNED column set
+//        (the plain fp28::fp_mont_reduce, whose 2^64 bound it meets as the four-product form did).
 __device__ __forceinline__ ec::Fp2 fp2_kara_reduce(const KaraCols& c) {
-    int64_t c0[2 * fp28::NL], c1[2 * fp28::NL];
+    int64_t c0[2 * fp28::NL];
+    uint64_t c1[2 * fp28::NL];
 #pragma unroll
     for (int t = 0; t < 2 * fp28::NL; t++) {
         const uint64_t w = c.v0[t] + c.v1[t];
         c0[t] = (int64_t)(c.v0[t] - c.v1[t]);
-        c1[t] = (int64_t)(c.v2[t] - w);
+        c1[t] = c.v2[t] - w;
     }
 #pragma unroll
     for (int j = 0; j < fp28::NL; j++) c0[fp28::NL - 1 + j] += (int64_t)((uint64_t)fp28::P[j] << 24);   // + p 2^388
-    return ec::Fp2{fp_mont_reduce_signed(c0), fp_mont_reduce_signed(c1)};
+    return ec::Fp2{fp_mont_reduce_signed(c0), fp28::fp_mont_reduce(c1)};
 }
 
 // `m` consecutive pairs share one accumulator: f <- f^2 * l_1 * ... * l_m per step (the multi-Miller-loop trick: one squaring
