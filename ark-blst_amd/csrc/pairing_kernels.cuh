@@ -232,7 +232,7 @@ __device__ __forceinline__ void lds_store_fp2(uint32_t* p, const ec::Fp2& a) {
 // c1 = a0' g1 + a1' g0 is non-negative as a number; c0 gets the bias p 2^388 (a multiple of p: P[j] << 24 added to column 13 + j),
 // which exceeds every V1 reached here (<= 144 p^2 ~ 2^387.9 p) and keeps the reduction's input below 373 p^2 of the 2520 p^2 it
 // may take, so every output is < 2p as before.  Operand bounds: a' <= (12p, 8p) in N-form, g <= 6p in N-form (a line's c0; exact
-// coefficients are < 2p), sums a0' + a1' and g0 + g1 normalised: <= 6 terms x 14 products of < 2^56.01 per column set (see fp2_kara_reduce).
+// coefficients are < 2p), sums a0' + a1' and g0 + g1 normalised: <= 4 terms x 14 products of < 2^56.01 per column set (see fp2_kara_reduce).
 // 168 registers of columns: the kernels below are built for ONE wave per SIMD (512 registers) — which costs nothing, a lone wave
 // of a 64-thread workgroup issues at the SIMD's full rate (tools/ubench_fp52.hip: 2484 vs 2447 cycles per multiplication).
 struct KaraCols {
@@ -270,24 +270,35 @@ __device__ __forceinline__ Fp fp_mont_reduce_signed(int64_t (&c)[2 * fp28::NL]) 
     r.l[NL - 1] |= (uint32_t)carry << W;
     return r;
 }
-// Column ranges (tests/test_host_model.py::test_karatsuba_column_and_bias_bounds restates them with big integers):
-//   c0 = V0 - V1 + bias is SIGNED per column, |column| <= max(V0, V1) column <= 6 terms x 14 products x 2^56.01 = 2^62.4, plus the bias
-//        (< 2^52) and the reduction's own 14 x 2^56: inside +-2^63;
-//   c1 = V2 - V0 - V1 is NON-NEGATIVE per column — the Karatsuba identity holds column by column: it is the sum of the cross
-//        products a0'_i g1_j + a1'_i g0_j — and may reach 6 x 14 x 2 x 2^56.01 = 2^63.4: it must be reduced as an UNSIGNED column set
-//        (the plain fp28::fp_mont_reduce, whose 2^64 bound it meets as the four-product form did).
+// Column ranges (tests/test_host_model.py::test_karatsuba_column_and_bias_bounds restates them with big integers).  The sums
+// a0' + a1' and g0 + g1 are carry-normalised, so the Karatsuba identity holds for the VALUE, not column by column: both recombined
+// column sets are signed.  With at most FOUR terms per reduction: |c0 column| <= max(V0, V1) column <= 4 x 14 x 2^56.01 = 2^61.8,
+// |c1 column| <= V0 + V1 column <= 2^62.8, plus the bias (< 2^52) and the reduction's own 14 x 2^56: inside +-2^63.  (Six terms —
+// the Fp12 tree — would reach 2^63.4: k_fp12_prod keeps the four-product form with unsigned columns, fp2_acc_term4 below.)
 __device__ __forceinline__ ec::Fp2 fp2_kara_reduce(const KaraCols& c) {
-    int64_t c0[2 * fp28::NL];
-    uint64_t c1[2 * fp28::NL];
+    int64_t c0[2 * fp28::NL], c1[2 * fp28::NL];
 #pragma unroll
     for (int t = 0; t < 2 * fp28::NL; t++) {
         const uint64_t w = c.v0[t] + c.v1[t];
         c0[t] = (int64_t)(c.v0[t] - c.v1[t]);
-        c1[t] = c.v2[t] - w;
+        c1[t] = (int64_t)(c.v2[t] - w);
     }
 #pragma unroll
     for (int j = 0; j < fp28::NL; j++) c0[fp28::NL - 1 + j] += (int64_t)((uint64_t)fp28::P[j] << 24);   // + p 2^388
-    return ec::Fp2{fp_mont_reduce_signed(c0), fp28::fp_mont_reduce(c1)};
+    return ec::Fp2{fp_mont_reduce_signed(c0), fp_mont_reduce_signed(c1)};
+}
+// (c0, c1) += a * g * xi^[wrapped] as FOUR products into two unsigned column sets (the form of rounds 1-2; the Fp12 tree's six terms):
+// a <= 4p, g exact (< 2p): xi a <= (12p, 8p) in N-form, 4p - g1 <= 4p: a term adds <= 56 p^2 to a component, six terms per reduction
+// (limit 2520 p^2); <= 168 column terms of < 2^56.01 plus the reduction's 2^59.9 stay below 2^64.
+__device__ __forceinline__ void fp2_acc_term4(uint64_t (&c0)[2 * fp28::NL], uint64_t (&c1)[2 * fp28::NL], const ec::Fp2& a, bool wrapped,
+                                              const ec::Fp2& g) {
+    Fp xa0 = fp28::fp_sub<8>(a.c0, a.c1), xa1 = fp28::fp_add(a.c0, a.c1);
+    Fp a0 = fp28::fp_select(wrapped, a.c0, xa0), a1 = fp28::fp_select(wrapped, a.c1, xa1);
+    Fp ng1 = fp28::fp_neg<4>(g.c1);
+    fp_acc(c0, a0, g.c0);
+    fp_acc(c0, a1, ng1);
+    fp_acc(c1, a0, g.c1);
+    fp_acc(c1, a1, g.c0);
 }
 
 // `m` consecutive pairs share one accumulator: f <- f^2 * l_1 * ... * l_m per step (the multi-Miller-loop trick: one squaring
@@ -410,8 +421,9 @@ __global__ void __launch_bounds__(64, 1) k_fp12_prod(const uint32_t* __restrict_
         // again and discards the result
         const bool live = lo + e < hi;
         const uint32_t* gp = in + (size_t)(live ? lo + e : hi - 1) * FP12_WORDS;
-        KaraCols cols;
-        cols.clear();
+        uint64_t c0[2 * fp28::NL], c1[2 * fp28::NL];
+#pragma unroll
+        for (int t = 0; t < 2 * fp28::NL; t++) { c0[t] = 0; c1[t] = 0; }
 #pragma unroll 1
         for (int i = 0; i < 6; i++) {
             int j = (int)k - i;
@@ -419,9 +431,9 @@ __global__ void __launch_bounds__(64, 1) k_fp12_prod(const uint32_t* __restrict_
             if (wrapped) j += 6;
             ec::Fp2 gj;
             ElemIO<ec::Fp2>::load(gj, gp + slot((uint32_t)j));
-            fp2_acc_term(cols, lds_load_fp2(fg + i * LDS_COEFF_WORDS), wrapped, gj);
+            fp2_acc_term4(c0, c1, lds_load_fp2(fg + i * LDS_COEFF_WORDS), wrapped, gj);
         }
-        ec::Fp2 r = fp2_kara_reduce(cols);
+        ec::Fp2 r{fp28::fp_mont_reduce(c0), fp28::fp_mont_reduce(c1)};
         own = ec::Fp2Ops::select(live, own, r);
         __syncthreads();
         lds_store_fp2(fg + k * LDS_COEFF_WORDS, own);

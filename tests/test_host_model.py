@@ -106,10 +106,11 @@ def test_complete_addition_tree_and_doubling(h28, co, o):
 
 
 def test_karatsuba_column_and_bias_bounds():
-    """The pairing accumulate / Fp12-tree kernels collect Fp2 products as Karatsuba column sets (pairing_kernels.cuh: KaraCols,
-    fp2_kara_reduce).  Restated with big integers: the bias p 2^388 covers every V1 the three users can reach, the reduction input
-    stays below the 2^392 p the multiplier's contract allows with outputs < 2p, the signed c0 columns stay inside +-2^63 and the
-    unsigned c1 columns below 2^64 — for the worst operands the documented value bounds permit."""
+    """The pairing accumulate kernel collects Fp2 products as Karatsuba column sets (pairing_kernels.cuh: KaraCols, fp2_kara_reduce).
+    Restated with big integers: the bias p 2^388 covers every V1 its two users reach, the reduction input stays below the 2^392 p of
+    the multiplier's contract with outputs < 2p, and both recombined (signed) column sets stay inside +-2^63 for the worst operands
+    the documented value bounds permit — with at most four terms per reduction; six (the Fp12 tree) would not fit, which is why
+    k_fp12_prod keeps the four-product form with unsigned columns."""
     from oracle import bls12_381 as o
 
     p = o.P
@@ -118,8 +119,8 @@ def test_karatsuba_column_and_bias_bounds():
     limb = (1 << 28) + 64          # N-form limb bound (fp28.cuh: SPREAD_LO)
     prod = limb * limb             # one limb product
     # (terms, bound of a0', a1', g0, g1 in units of p): line multiplication (a line's c0 <= 6p), squaring (a <= 4p doubled
-    # coefficient, xi a <= (12p, 8p)), Fp12 tree product
-    users = {"line": (3, 10, 4, 6, 6), "square": (4, 12, 8, 2, 2), "tree": (6, 10, 4, 2, 2)}
+    # coefficient, xi a <= (12p, 8p))
+    users = {"line": (3, 10, 4, 6, 6), "square": (4, 12, 8, 2, 2)}
     for name, (terms, a0, a1, g0, g1) in users.items():
         v0, v1 = terms * a0 * g0 * p * p, terms * a1 * g1 * p * p
         cross = terms * (a0 * g1 + a1 * g0) * p * p
@@ -127,5 +128,6 @@ def test_karatsuba_column_and_bias_bounds():
         assert v0 + bias < R * p and cross < R * p, name          # the multiplier's contract: input < 2^392 p
         assert (v0 + bias) // R + p < 2 * p and cross // R + p < 2 * p, name   # outputs < 2p, as every consumer assumes
         col = terms * 14 * prod                                   # one column of one column set
-        assert col + (1 << 52) + 14 * prod < 1 << 63, name        # signed c0: |V0 - V1| + bias column + the reduction's 14 m_i p_j
-        assert 2 * col + 14 * prod + (1 << 36) < 1 << 64, name    # unsigned c1: cross products + reduction terms + carry
+        assert col + (1 << 52) + 14 * prod < 1 << 63, name        # |V0 - V1| + bias column + the reduction's 14 m_i p_j
+        assert 2 * col + 14 * prod + (1 << 36) < 1 << 63, name    # |V2 - (V0 + V1)| + reduction terms + carry
+    assert 2 * 6 * 14 * prod > 1 << 63                            # six terms: why the tree does not use this form
