@@ -9,10 +9,11 @@ namespace mi { std::atomic<int> g_fail_allocs{0}; }
 using namespace mi;
 
 namespace {
-// The host tail (Horner fold, partial-sum fold, final exponentiation) is compiled for BMI2 + ADX (Intel since Broadwell, AMD
-// since Zen): on anything older the entry points that run it return MI_E_UNSUPPORTED instead of faulting.
+// The host tail (Horner fold, partial-sum fold, final exponentiation: the functions of host_curve.hpp) is compiled for BMI2 + ADX
+// (Intel since Broadwell, AMD since Zen): on anything older the entry points that run it return MI_E_UNSUPPORTED instead of
+// faulting.  This function and everything else outside host_curve.hpp is baseline x86-64 code.
 bool cpu_ok() {
-#if defined(__x86_64__) && defined(__ADX__)
+#if defined(__x86_64__)
     static const bool ok = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx");
     return ok;
 #else

@@ -12,6 +12,19 @@
 #include <immintrin.h>
 #endif
 
+// BMI2 + ADX are enabled for the functions of THIS header only (clang's per-function target attribute), not for the translation
+// units that include it: everything outside — mi_msm_init and its cpu_ok() check, std::string / vector code, static initialisers —
+// is compiled for the baseline x86-64, so a CPU without the extensions gets MI_E_UNSUPPORTED from the check instead of a SIGILL
+// from some shlx / mulx the compiler placed in front of it (the -mbmi2 -madx flags of rounds 1-2 applied to all host code).
+#if defined(__clang__) && defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#define HOSTEC_MULX_ADX 1
+#pragma clang attribute push(__attribute__((target("bmi2,adx"))), apply_to = function)
+#define HOSTEC_FLATTEN __attribute__((flatten))   // the point formulas inline every field operation (callers outside this header cannot:
+                                                   // they are compiled without the extensions and call these as functions)
+#else
+#define HOSTEC_FLATTEN
+#endif
+
 namespace hostec {
 
 typedef unsigned __int128 u128;
@@ -75,10 +88,10 @@ struct Fp {
         return out;
     }
     // Montgomery multiplication, coarsely integrated operand scanning (CIOS), fully unrolled: one pass of a * b_i and one
-    // reduction round per word of b.  With BMI2 + ADX (the library is built with -mbmi2 -madx by clang; mi_msm_init refuses
+    // reduction round per word of b.  With BMI2 + ADX (enabled for this header's functions, see the top; mi_msm_init refuses
     // CPUs without them) each pass is six mulx feeding two independent carry chains (adcx / adox): 79 cycles on a 2.1 GHz
     // Xeon against 124 for the portable unsigned __int128 form below (kept for other compilers: gcc serialises the chains).
-#if defined(__clang__) && defined(__ADX__) && defined(__BMI2__)
+#if defined(HOSTEC_MULX_ADX)
     Fp operator*(const Fp& o) const {
         typedef unsigned long long u64;
         u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
@@ -163,12 +176,12 @@ struct Fp2 {
     bool operator==(const Fp2& o) const { return c0 == o.c0 && c1 == o.c1; }
     Fp2 operator+(const Fp2& o) const { return {c0 + o.c0, c1 + o.c1}; }
     Fp2 operator-(const Fp2& o) const { return {c0 - o.c0, c1 - o.c1}; }
-    Fp2 operator*(const Fp2& o) const {
+    HOSTEC_FLATTEN Fp2 operator*(const Fp2& o) const {
         Fp a = c0 * o.c0, b = c1 * o.c1;
         Fp m = (c0 + c1) * (o.c0 + o.c1);
         return {a - b, m - a - b};
     }
-    Fp2 sqr() const {
+    HOSTEC_FLATTEN Fp2 sqr() const {
         Fp s = c0 + c1, d = c0 - c1, m = c0 * c1;
         return {s * d, m + m};
     }
@@ -185,7 +198,7 @@ struct Jac {
     static Jac inf() { return {FE::zero(), FE::zero(), FE::zero()}; }
     bool is_inf() const { return z.is_zero(); }
 
-    Jac dbl() const {  // a = 0 short Weierstrass
+    HOSTEC_FLATTEN Jac dbl() const {  // a = 0 short Weierstrass
         if (is_inf() || y.is_zero()) return inf();
         FE xx = x.sqr(), yy = y.sqr(), yyyy = yy.sqr();
         FE s = ((x + yy).sqr() - xx - yyyy).dbl();
@@ -195,7 +208,7 @@ struct Jac {
         FE z3 = (y * z).dbl();
         return {x3, y3, z3};
     }
-    Jac add(const Jac& q) const {
+    HOSTEC_FLATTEN Jac add(const Jac& q) const {
         if (is_inf()) return q;
         if (q.is_inf()) return *this;
         FE z1z1 = z.sqr(), z2z2 = q.z.sqr();
@@ -221,3 +234,7 @@ using G2 = Jac<Fp2>;   // 288 B == blst_p2
 static_assert(sizeof(G1) == 144 && sizeof(G2) == 288, "layout must match blst_p1 / blst_p2");
 
 }  // namespace hostec
+
+#if defined(HOSTEC_MULX_ADX)
+#pragma clang attribute pop
+#endif

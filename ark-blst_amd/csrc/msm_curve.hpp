@@ -46,16 +46,15 @@ inline int device_of_ptr(const void* p, const char* what) {
                       "second HIP runtime in this process: see INTEGRATION.md, load order)", false, true};
     return a.device;
 }
-// can device slot k of the context read memory that lives on device `owner` directly (same device, or peer access over xGMI)?
+// Does device slot k of the context read its shard of a scalar vector that lives on device `owner` IN PLACE?  Only when it is the
+// same device.  A remote shard is copied once with hipMemcpyPeerAsync (DMA over xGMI, or through the host where two devices have no
+// peer access — the matrix recorded by mi_msm_init says which) instead of being read twice by the sort's count and scatter passes
+// through a peer mapping: half the link traffic, and no kernel ever dereferences a pointer its device may not be able to map.
 inline bool can_read(const mi_ctx* ctx, size_t k, int owner) {
-    const size_t g = ctx->devs.size();
-    if (ctx->devs[k].dev == owner) return true;
 #if defined(MI_TEST_HOOKS)
     if (ctx->test_no_peer) return false;
 #endif
-    for (size_t b = 0; b < g; b++)
-        if (ctx->devs[b].dev == owner) return ctx->peer_ok.size() == g * g && ctx->peer_ok[k * g + b] != 0;
-    return false;   // a device outside the context: staged through a peer copy
+    return ctx->devs[k].dev == owner;
 }
 
 // what mi_msm_g{1,2}_device_windows leaves behind instead of a folded result
@@ -406,8 +405,8 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
             if (have == 0 && n) return fail(ctx, MI_E_NO_BASES, "no resident base set for this group");
             if (n > have) return fail(ctx, MI_E_INVALID, "n exceeds the resident base set");
         }
-        // device-resident scalars: the shard of device k is read by device k — directly when the vector lives there or peer access
-        // over xGMI exists (matrix recorded by mi_msm_init), through a peer copy of the shard otherwise
+        // device-resident scalars: the shard of device k is read by device k — in place when the vector lives there, through ONE peer
+        // copy of the shard otherwise (can_read)
         int owner = -1;
         if (scalars_on_device && n) owner = device_of_ptr(scalars, "d_scalars");
         auto t0 = std::chrono::steady_clock::now();

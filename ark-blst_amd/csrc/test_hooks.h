@@ -16,8 +16,8 @@ int mi_test_set_pairing(mi_ctx *ctx, unsigned share, unsigned batch, int single_
 int mi_test_set_max_part(mi_ctx *ctx, size_t points);
 /* the next `count` growing device allocations of the process fail (as hipErrorOutOfMemory would) */
 void mi_test_fail_allocs(int count);
-/* pretend that no device of the context can read another device's memory: device-resident scalars of a multi-device context are
- * then staged by peer copies (the path a node without full peer access takes) */
+/* treat every device slot as remote from the scalar vector's device: device-resident scalars of a multi-device context are then
+ * staged by peer copies even on one GPU (the path every slot but the owner's takes on a real multi-GPU node) */
 int mi_test_set_no_peer(mi_ctx *ctx, int no_peer);
 /* the window-size plan of an n-point call (host only, no device): out[13] = c, windows, bucket sets, logL, chunk_log, logT, lo_bits,
  * serial reduce, chunks per window, buckets (hi, lo), chunks, buckets per lane of the serial reduce.  group 0 = G1, 1 = G2; c = 0 in out[0]: no usable plan */

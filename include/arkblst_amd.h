@@ -118,8 +118,8 @@ int mi_msm_g2(mi_ctx *ctx, const mi_g2_affine *bases, const uint8_t *scalars, si
 /* Same computation with the scalars ALREADY in device memory (hipMalloc'd or a torch CUDA tensor's data_ptr) and the bases
  * resident: nothing crosses PCIe except one Jacobian point per window.  The library reads d_scalars on its OWN stream: the
  * caller must have synchronised the stream that produced them (hipStreamSynchronize / torch.cuda.synchronize) before the
- * call.  With a multi-device context device k reads its shard [lo_k, hi_k) of the one vector: directly when the vector lives on
- * that device or peer access over xGMI exists, through a peer copy of the shard otherwise.  A pointer the runtime does not know
+ * call.  With a multi-device context device k reads its shard [lo_k, hi_k) of the one vector: in place when the vector lives on
+ * that device, through one peer copy of the shard (hipMemcpyPeerAsync) otherwise.  A pointer the runtime does not know
  * (host memory; memory of a second HIP runtime in the process) is MI_E_INVALID. */
 int mi_msm_g1_device(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g1 *out);
 int mi_msm_g2_device(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g2 *out);
