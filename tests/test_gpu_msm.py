@@ -877,3 +877,21 @@ def test_host_slices_in_chunks_g2_and_large_window(pkg, co):
         with pkg.Context([0]) as cx:
             cx.set_window_bits(c)
             assert _canon(co, group, cx.msm(group, bases, scalars, n, pkg.SCALAR_CANONICAL)) == co.dlog_expected(group, scalars, SEED_B + 271, n)
+
+
+def test_plain_set_bases_gives_back_the_table_allocation(pkg, co):
+    """mi_msm_g1_set_bases after mi_msm_g1_set_bases_precomputed must not keep the W x table allocation for the life of the context
+    (DevBuf::ensure_fit): the device's free memory comes back."""
+    import torch
+
+    n = 1 << 18
+    bases = co.gen_bases("g1", SEED_B + 280, n, 8)
+    with pkg.Context([0]) as c:
+        torch.cuda.synchronize()
+        c.set_bases_precomputed("g1", bases, n, 13)           # 20 tables of 32 MiB
+        free_tables = torch.cuda.mem_get_info()[0]
+        c.set_bases("g1", bases[:96 * 1000], 1000)
+        free_plain = torch.cuda.mem_get_info()[0]
+        assert free_plain - free_tables > 400 << 20, (free_tables, free_plain)
+        sc = co.gen_scalars(SEED_S + 280, 1000)
+        assert _canon(co, "g1", c.msm("g1", None, sc, 1000, pkg.SCALAR_CANONICAL)) == co.dlog_expected("g1", sc, SEED_B + 280, 1000)
