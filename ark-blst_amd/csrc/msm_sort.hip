@@ -179,7 +179,10 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
             if (t1 > t0) count_tiles(t1 - t0);
         }
         gg.tile0 = 0;
-        if (host_scalars) HIP_TRY(hipEventRecord(d.cev[9], d.copy_stream));
+        if (host_scalars) {
+            HIP_TRY(hipEventRecord(d.cev[9], d.copy_stream));
+            HIP_TRY(hipStreamWaitEvent(s, d.cev[9], 0));   // the call's final synchronisation of `s` then covers the event read for h2d_ms
+        }
     };
     msmk::SortGeom g{};
     g.n = (uint32_t)n; g.fmt = fmt; g.c = pl.c; g.nwin = pl.nwin;
