@@ -281,8 +281,10 @@ FP_HD Fp fp_mul4add(const Fp& a, const Fp& b, const Fp& c2, const Fp& d, const F
 // The shared multiplier instance.  The out-of-line bodies keep the operand-scanning form: register pressure is no concern
 // inside a function of its own, and with product-scanning bodies behind these by-value signatures the test-only single-lane
 // Miller kernel (4 KB of scratch per lane, ~10^3 calls) stopped agreeing with the production path on the GPU while the same
-// source agrees with the oracle on the host (tests/host/pairing_host_check.cpp) — not root-caused, so the bodies that six
-// soak seeds have exercised stay as they were.
+// source agrees with the oracle on the host (tests/host/pairing_host_check.cpp).  Bisected on the GPU: fp_mul_call alone triggers it
+// (fp_sqr_call and fp_mul2add_call with product-scanning bodies pass); in that translation unit the function receives its second
+// operand through a scratch pointer and starts multiplying while the loads are in flight.  Not root-caused beyond that, so the
+// bodies that six soak seeds have exercised stay as they were.
 // On the device this is a REAL function (by-value args travel in v0..v27, the
 // result in v0..v13): one ~4.5 KB body per kernel instead of one per use keeps bucket kernels inside the
 // 64 KB instruction cache (see ec.cuh).  On the host it is plain inline code.
