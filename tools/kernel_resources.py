@@ -146,11 +146,75 @@ def scratch_in_hot_loops(lib: str | None = None) -> dict[str, int]:
     return out
 
 
+# cycles per wave-instruction at two waves per SIMD (profiles/r03_ubench_carry.txt, r03_ubench_mad_banks.txt); VOP3 encodings ~4.4-5.0, VOP1/2 ~2.6
+COST = {"v_mad_u64_u32": 4.8, "v_mul_lo_u32": 4.4, "v_lshrrev_b64": 4.6, "v_lshl_add_u64": 5.05, "v_ashrrev_i64": 4.5, "v_alignbit_b32": 4.6,
+        "v_lshl_add_u32": 4.4, "v_add3_u32": 4.4, "v_or3_b32": 4.4, "v_lshl_or_b32": 4.4, "v_bitop3_b32": 4.4, "v_mov_b64_e32": 4.4,
+        "v_lshlrev_b64": 4.6, "v_cndmask_b32_e64": 4.4, "v_cmp_eq_u32_e64": 4.4, "v_cmp_lt_u32_e64": 4.4, "v_mov_b32_dpp": 2.7}
+DEFAULT_VALU, DEFAULT_OTHER = 2.6, 1.0
+
+
+def instruction_mix(lib: str | None, needle: str):
+    """Histogram of the largest arithmetic loop (most v_mad_u64_u32 inside one backward-branch span) of the kernel whose demangled
+    name contains `needle`, priced with COST: what one trip of the loop costs a SIMD when it issues at the measured instruction rates."""
+    lib = lib or os.path.join(ROOT, "ark-blst_amd", "lib", "libarkblst_amd.so")
+    with tempfile.TemporaryDirectory() as tmp:
+        for elf in code_objects(lib, tmp):
+            txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", elf], capture_output=True, text=True, check=True).stdout
+            sym, base, ins, blocks = None, 0, [], []
+            for line in txt.splitlines():
+                m = re.match(r"^([0-9a-f]{16}) <(.+)>:$", line)
+                if m:
+                    if sym is not None:
+                        blocks.append((sym, ins))
+                    sym, base, ins = m.group(2), int(m.group(1), 16), []
+                    continue
+                m = re.match(r"^\s+(\S+).*// ([0-9A-F]{12}):", line)
+                if m and sym is not None:
+                    tgt = None
+                    if m.group(1).startswith(("s_cbranch", "s_branch")):
+                        t = re.search(r"<[^>]*\+0x([0-9a-f]+)>", line)
+                        tgt = int(t.group(1), 16) if t else 0
+                    ins.append((int(m.group(2), 16) - base, m.group(1), tgt))
+            if sym is not None:
+                blocks.append((sym, ins))
+            names = demangle([b[0] for b in blocks])
+            for raw, ins in blocks:
+                if needle not in names[raw] or "k_" not in names[raw]:
+                    continue
+                best = None
+                for off, mn, tgt in ins:
+                    if tgt is None or tgt >= off:
+                        continue
+                    body = [i[1] for i in ins if tgt <= i[0] <= off]
+                    mads = sum(1 for x in body if x == "v_mad_u64_u32")
+                    if best is None or mads > best[0]:
+                        best = (mads, body)
+                if best:
+                    return names[raw], best[1]
+    return None, []
+
+
 def main() -> None:
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     res = resources(args[0] if args else None)
     if "--json" in sys.argv:
         print(json.dumps(res, indent=1, sort_keys=True))
+        return
+    mix = [a for a in sys.argv if a.startswith("--mix=")]
+    if mix:
+        import collections
+        name, body = instruction_mix(args[0] if args else None, mix[0].split("=", 1)[1])
+        if not body:
+            print("no such kernel / loop")
+            return
+        hist = collections.Counter(body)
+        total = 0.0
+        print(f"largest arithmetic loop of {name[:100]}: {len(body)} instructions (a rarely taken branch body inside the span is counted too)")
+        for mn, c in hist.most_common():
+            cost = COST.get(mn, DEFAULT_VALU if mn.startswith("v_") else DEFAULT_OTHER)
+            total += c * cost
+            print(f"  {c:6d}  {mn:24s} x {cost:4.2f} = {c * cost:9.0f} cycles")
+        print(f"  sum of measured instruction costs (two waves per SIMD): {total:.0f} cycles per trip and SIMD")
         return
     if "--loops" in sys.argv:
         for k, v in sorted(scratch_in_hot_loops(args[0] if args else None).items()):
