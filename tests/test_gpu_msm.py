@@ -549,7 +549,7 @@ def test_bench_two_ranks_exchange_from_device_memory():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300),
            os.path.join(root, "bench.py"), "--gpus", "2", "--total-log-n", "15", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--share-device"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
