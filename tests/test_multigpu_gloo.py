@@ -1,5 +1,5 @@
-"""The N>1 path on CPU: world_size-2 `gloo` run of the exchange step bench.py uses (all-gather of the per-rank
-partial sums + deterministic fold in rank order via the C ABI's mi_g1_sum).  The per-rank partials come from the
+"""The N>1 path on CPU: world_size-2 `gloo` run of the exchange steps (all-gather of per-rank partial sums + deterministic fold in
+rank order via mi_g1_sum; and, what bench.py uses since round 3, all_gather_into_tensor of per-WINDOW sums + mi_g1_fold_windows).  The per-rank partials come from the
 oracle here (no GPU); on the GPU box the same code path gathers the partials the HIP pipeline produced."""
 import os
 import subprocess
@@ -36,6 +36,19 @@ WORKER = textwrap.dedent("""
     chk = [None] * world
     dist.all_gather_object(chk, total)
     assert all(c == chk[0] for c in chk), "ranks disagree"
+    # round 3: the exchange bench.py uses at N > 1 — every rank contributes its PER-WINDOW sums (here: known multiples of the
+    # generator standing in for what mi_msm_g1_device_windows leaves in device memory), all_gather_into_tensor, mi_g1_fold_windows
+    # on every rank (ranks added per window in rank order, then the Horner fold); expected value from the Python big-int oracle
+    from oracle import bls12_381 as o
+    import random
+    c, nwin = 16, 16
+    ks = [[random.Random(1000 * r + w).randrange(1, 1 << 60) for w in range(nwin)] for r in range(world)]
+    mine_w = b"".join(o.jac_to_bytes(o.F1, o.jac_from_aff(o.F1, o.scalar_mul(o.F1, o.G1_GEN, k))) for k in ks[rank])
+    gw = torch.empty(world * nwin * 144, dtype=torch.uint8)
+    dist.all_gather_into_tensor(gw, torch.frombuffer(bytearray(mine_w), dtype=torch.uint8))
+    folded = pkg.fold_windows("g1", gw.numpy(), world, nwin, c, nwin)
+    total_k = sum((1 << (c * w)) * sum(ks[r][w] for r in range(world)) for w in range(nwin)) % o.R_ORDER
+    assert co.to_affine("g1", folded) == o.affine_to_bytes(o.F1, o.scalar_mul(o.F1, o.G1_GEN, total_k)), "window fold mismatch"
     dist.barrier()
     if rank == 0:
         print("GLOO_FOLD_OK")
