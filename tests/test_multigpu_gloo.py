@@ -47,7 +47,7 @@ WORKER = textwrap.dedent("""
     gw = torch.empty(world * nwin * 144, dtype=torch.uint8)
     dist.all_gather_into_tensor(gw, torch.frombuffer(bytearray(mine_w), dtype=torch.uint8))
     folded = pkg.fold_windows("g1", gw.numpy(), world, nwin, c, nwin)
-    total_k = sum((1 << (c * w)) * sum(ks[r][w] for r in range(world)) for w in range(nwin)) % o.R_ORDER
+    total_k = sum((1 << (c * w)) * sum(ks[r][w] for r in range(world)) for w in range(nwin)) %% o.R_ORDER
     assert co.to_affine("g1", folded) == o.affine_to_bytes(o.F1, o.scalar_mul(o.F1, o.G1_GEN, total_k)), "window fold mismatch"
     dist.barrier()
     if rank == 0:
