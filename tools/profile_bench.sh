@@ -4,7 +4,7 @@
 # Run on the GPU box via gpurun:   tools/profile_bench.sh <tag> [bench.py arguments...]
 # then, back in the container:     python tools/summarize_profile.py gpurun_out/prof_<tag> <tag> <group> <log_n> [precomputed]
 set -e
-TAG=${1:-r02_g1_2p20}; shift || true
+TAG=${1:-r03_g1_2p20}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
