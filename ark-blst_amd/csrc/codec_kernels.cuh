@@ -51,7 +51,7 @@ __device__ __noinline__ void g1_mul_z(ec::Proj<ec::FpOps>& r, const ec::Proj<ec:
     }
 }
 
-__global__ void __launch_bounds__(256) k_deserialize_g1(const uint8_t* __restrict__ bytes, uint32_t n, int compressed, int validate,
+__global__ void __launch_bounds__(256, 2) k_deserialize_g1(const uint8_t* __restrict__ bytes, uint32_t n, int compressed, int validate,
                                                         uint32_t* __restrict__ out_aff, uint8_t* __restrict__ status) {
     using F = ec::FpOps;
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) k_deserialize_g1(const uint8_t* __restric
 }
 
 // affine (blst form) -> ZCash encoding
-__global__ void __launch_bounds__(256) k_serialize_g1(const uint32_t* __restrict__ aff, uint32_t n, int compressed, uint8_t* __restrict__ bytes) {
+__global__ void __launch_bounds__(256, 2) k_serialize_g1(const uint32_t* __restrict__ aff, uint32_t n, int compressed, uint8_t* __restrict__ bytes) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t* q = aff + (size_t)i * 24;
@@ -216,7 +216,7 @@ __device__ __forceinline__ bool fp2_lex_largest(const ec::Fp2& y) {  // c1 first
     return canon_gt_half(fp_to_canonical(y.c0));
 }
 
-__global__ void __launch_bounds__(256) k_deserialize_g2(const uint8_t* __restrict__ bytes, uint32_t n, int compressed, int validate,
+__global__ void __launch_bounds__(256, 2) k_deserialize_g2(const uint8_t* __restrict__ bytes, uint32_t n, int compressed, int validate,
                                                         uint32_t* __restrict__ out_aff, uint8_t* __restrict__ status) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -298,7 +298,7 @@ __device__ __forceinline__ void words_to_be48(uint8_t* d, const uint32_t (&w)[12
         q[0] = (uint8_t)(w[k] >> 24); q[1] = (uint8_t)(w[k] >> 16); q[2] = (uint8_t)(w[k] >> 8); q[3] = (uint8_t)w[k];
     }
 }
-__global__ void __launch_bounds__(256) k_serialize_g2(const uint32_t* __restrict__ aff, uint32_t n, int compressed, uint8_t* __restrict__ bytes) {
+__global__ void __launch_bounds__(256, 2) k_serialize_g2(const uint32_t* __restrict__ aff, uint32_t n, int compressed, uint8_t* __restrict__ bytes) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t* q = aff + (size_t)i * 48;
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(256) k_serialize_g2(const uint32_t* __restrict
 
 // ---------------------------------------------------------------------------------------------- field test hook
 #if defined(MI_TEST_HOOKS)
-__global__ void __launch_bounds__(256) k_test_fp_op(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+__global__ void __launch_bounds__(256, 2) k_test_fp_op(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
                                                     uint32_t* __restrict__ out, uint32_t n) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;

@@ -1,4 +1,9 @@
 // Curve-generic kernels of the MSM pipeline (ingest, accumulate, merge, reduce, combine) and normalize_batch.
+//
+// Launch-bounds rule (csrc/Makefile, DESIGN.md §9 "call-ABI miscompare"): a kernel whose body or callees contain a CALL of an
+// out-of-line device function is declared with two waves per SIMD (second __launch_bounds__ argument 2): at most 256 registers per
+// lane, hence no AGPRs — ROCm 7.2's hipcc miscompiles calls combined with VGPR spills into AGPRs.  Kernels built for one wave per
+// SIMD (512 registers: PairG2 reduce, the Fp12 kernels) contain no call.  tests/test_cabi.py checks both on the shipped code objects.
 #pragma once
 #include "kernels_common.cuh"
 
@@ -7,7 +12,7 @@ namespace msmk {
 // ---------------------------------------------------------------------------------------------- ingest
 // raw: n affine points in the reference's form.  One thread per point.
 template <class C>
-__global__ void __launch_bounds__(256) k_ingest(const uint32_t* __restrict__ raw, uint32_t* __restrict__ out,
+__global__ void __launch_bounds__(256, 2) k_ingest(const uint32_t* __restrict__ raw, uint32_t* __restrict__ out,
                                                 uint8_t* __restrict__ inf_flags, uint32_t n) {
     using E = typename C::F::E;
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -84,7 +89,7 @@ __global__ void __launch_bounds__(64, C::OCC) k_accumulate(const uint32_t* __res
         e++;
     }
     ec::Proj<F> out = ec::proj_inf<F>();
-    if (!inf) out = ec::xyzz_to_proj<F>(reinterpret_cast<const ec::Xyzz<F>&>(acc));
+    if (!inf) out = ec::xyzz_to_proj<F>(acc);   // Xyzz<FA> and Xyzz<F> are one type (ec.cuh)
     while (e < end) {  // cold path (never taken on random inputs): complete additions
         uint32_t ent = sorted[e];
         E x, y;
@@ -183,7 +188,7 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_g2_coop(const uint32_t* __
 // chunk index is a multiple of 2d.  After ceil(log2(max items)) levels partial[woff[b]] is bucket b.  Launched only
 // when some bucket was split (meta[1] > 1), over the items of split buckets only (merge_list, meta[3] entries).
 template <class C>
-__global__ void __launch_bounds__(256, 1) k_merge(uint32_t* __restrict__ partial, const uint32_t* __restrict__ item_bucket,
+__global__ void __launch_bounds__(256, 2) k_merge(uint32_t* __restrict__ partial, const uint32_t* __restrict__ item_bucket,
                                                        const uint32_t* __restrict__ woff, const uint32_t* __restrict__ merge_list,
                                                        uint32_t nlist, uint32_t d) {
     uint32_t j = blockIdx.x * 256 + threadIdx.x;
@@ -206,7 +211,7 @@ __global__ void __launch_bounds__(256, 1) k_merge(uint32_t* __restrict__ partial
 // cofactors are odd), so a multiple of a finite point is finite; a Z of zero (input not on the curve) is kept out of the
 // shared inversion and only spoils its own entry.
 template <class C>
-__global__ void __launch_bounds__(256) k_table_dbl(const uint32_t* __restrict__ prev, const uint8_t* __restrict__ inf_flags, uint32_t n, uint32_t c,
+__global__ void __launch_bounds__(256, 2) k_table_dbl(const uint32_t* __restrict__ prev, const uint8_t* __restrict__ inf_flags, uint32_t n, uint32_t c,
                                                    uint32_t* __restrict__ proj, uint32_t* __restrict__ vals) {
     using F = typename C::F;
     using E = typename F::E;
@@ -225,7 +230,7 @@ __global__ void __launch_bounds__(256) k_table_dbl(const uint32_t* __restrict__ 
     ElemIO<E>::store(vals + (size_t)i * Geo<C>::SLOT, F::select(skip, p.z, F::one()));
 }
 template <class C>
-__global__ void __launch_bounds__(256) k_table_affine(const uint32_t* __restrict__ proj, const uint32_t* __restrict__ zinv,
+__global__ void __launch_bounds__(256, 2) k_table_affine(const uint32_t* __restrict__ proj, const uint32_t* __restrict__ zinv,
                                                       const uint8_t* __restrict__ inf_flags, uint32_t n, uint32_t* __restrict__ out) {
     using F = typename C::F;
     using E = typename F::E;
@@ -543,7 +548,6 @@ __global__ void __launch_bounds__(64, 2) k_reduce_serial(const uint32_t* __restr
     using FR = typename C::FR;
     using E = typename F::E;
     using PJ = ec::Proj<F>;
-    using PR = ec::Proj<FR>;
     constexpr int BK = Geo<C>::BK_WORDS, SLOT = Geo<C>::SLOT;
     __shared__ uint32_t park[64 * BK];   // one point per lane, slot-interleaved: [coordinate][lane][SLOT words]; acc, later S
     const uint32_t lane = threadIdx.x;
@@ -606,7 +610,7 @@ __global__ void __launch_bounds__(64, 2) k_reduce_serial(const uint32_t* __restr
                 bit--;
             }
         }
-        ec::proj_add<FR>(reinterpret_cast<PR&>(A), reinterpret_cast<const PR&>(B));
+        ec::proj_add<FR>(A, B);   // Proj<F> and Proj<FR> are one type (ec.cuh): FR only selects the multiplier form
         if (phase1 && !even) park_store(A);
         else run = A;
     }
@@ -686,7 +690,7 @@ __global__ void __launch_bounds__(64, CS::MAX_OCC) k_combine(const uint32_t* __r
 constexpr uint32_t NORM_K = 32;
 
 template <class C>
-__global__ void __launch_bounds__(256) k_norm_load(const uint32_t* __restrict__ raw_jac, uint32_t n, uint32_t* __restrict__ vals) {
+__global__ void __launch_bounds__(256, 2) k_norm_load(const uint32_t* __restrict__ raw_jac, uint32_t n, uint32_t* __restrict__ vals) {
     using F = typename C::F;
     using E = typename F::E;
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -702,7 +706,7 @@ __global__ void __launch_bounds__(256) k_norm_load(const uint32_t* __restrict__ 
 }
 
 template <class C>
-__global__ void __launch_bounds__(256) k_norm_up(const uint32_t* __restrict__ vals, uint32_t m, uint32_t* __restrict__ pref,
+__global__ void __launch_bounds__(256, 2) k_norm_up(const uint32_t* __restrict__ vals, uint32_t m, uint32_t* __restrict__ pref,
                                                  uint32_t* __restrict__ tot) {
     using F = typename C::F;
     using E = typename F::E;
@@ -720,7 +724,7 @@ __global__ void __launch_bounds__(256) k_norm_up(const uint32_t* __restrict__ va
 }
 
 template <class C>
-__global__ void __launch_bounds__(256) k_norm_down(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ pref,
+__global__ void __launch_bounds__(256, 2) k_norm_down(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ pref,
                                                    const uint32_t* __restrict__ inv_tot, uint32_t m, uint32_t* __restrict__ inv_vals) {
     using F = typename C::F;
     using E = typename F::E;
@@ -739,7 +743,7 @@ __global__ void __launch_bounds__(256) k_norm_down(const uint32_t* __restrict__ 
 }
 
 template <class C>
-__global__ void __launch_bounds__(256) k_norm_final(const uint32_t* __restrict__ raw_jac, const uint32_t* __restrict__ zinv, uint32_t n,
+__global__ void __launch_bounds__(256, 2) k_norm_final(const uint32_t* __restrict__ raw_jac, const uint32_t* __restrict__ zinv, uint32_t n,
                                                     uint32_t* __restrict__ raw_aff) {
     using F = typename C::F;
     using E = typename F::E;
@@ -763,7 +767,7 @@ __global__ void __launch_bounds__(256) k_norm_final(const uint32_t* __restrict__
 
 // device form <-> reference form for a short vector of field elements (top of the product tree, host inversion)
 template <class C>
-__global__ void __launch_bounds__(64) k_elems_to_raw(const uint32_t* __restrict__ dev, uint32_t m, uint32_t* __restrict__ raw) {
+__global__ void __launch_bounds__(64, 2) k_elems_to_raw(const uint32_t* __restrict__ dev, uint32_t m, uint32_t* __restrict__ raw) {
     using E = typename C::F::E;
     uint32_t i = threadIdx.x;
     if (i >= m) return;
@@ -772,7 +776,7 @@ __global__ void __launch_bounds__(64) k_elems_to_raw(const uint32_t* __restrict_
     ElemIO<E>::to_raw(raw + (size_t)i * ElemIO<E>::RAW, v, true);
 }
 template <class C>
-__global__ void __launch_bounds__(64) k_elems_from_raw(const uint32_t* __restrict__ raw, uint32_t m, uint32_t* __restrict__ dev) {
+__global__ void __launch_bounds__(64, 2) k_elems_from_raw(const uint32_t* __restrict__ raw, uint32_t m, uint32_t* __restrict__ dev) {
     using E = typename C::F::E;
     uint32_t i = threadIdx.x;
     if (i >= m) return;

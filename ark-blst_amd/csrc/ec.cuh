@@ -160,14 +160,22 @@ struct Fp2OpsT {
 using Fp2Ops = Fp2OpsT<false>;
 using Fp2OpsInline = Fp2OpsT<true>;
 
-template <class F>
-struct Xyzz {
-    typename F::E x, y, zz, zzz;
+// Points are structs over the ELEMENT type, and Xyzz<F> / Proj<F> are aliases: every operation class with the same element
+// (FpOps / FpOpsInline / FpOpsInlinePS; CoopF2 / CoopF2A) names ONE struct type, so a value computed with one multiplier form
+// is handed to code instantiated for another without a cast (round 3 cast between distinct instantiations: undefined behaviour
+// under the strict-aliasing rules the build uses).  F is not deducible through the alias: callers name it, proj_add<F>(a, b).
+template <class E>
+struct XyzzE {
+    E x, y, zz, zzz;
+};
+template <class E>
+struct ProjE {
+    E x, y, z;
 };
 template <class F>
-struct Proj {
-    typename F::E x, y, z;
-};
+using Xyzz = XyzzE<typename F::E>;
+template <class F>
+using Proj = ProjE<typename F::E>;
 
 template <class F>
 FP_HD Proj<F> proj_inf() {

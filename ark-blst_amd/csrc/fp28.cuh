@@ -289,7 +289,11 @@ FP_HD Fp fp_mul4add(const Fp& a, const Fp& b, const Fp& c2, const Fp& d, const F
 // result in v0..v13): one ~4.5 KB body per kernel instead of one per use keeps bucket kernels inside the
 // 64 KB instruction cache (see ec.cuh).  On the host it is plain inline code.
 #if defined(__HIP_DEVICE_COMPILE__)
+#if defined(MI_CALL_PS)   // reproducer switch (tools/call_abi/): the product-scanning body behind the by-value signature
+static __device__ __noinline__ Fp fp_mul_call(Fp a, Fp b) { return fp_mul(a, b); }
+#else
 static __device__ __noinline__ Fp fp_mul_call(Fp a, Fp b) { return fp_mul_os(a, b); }
+#endif
 #else
 FP_HD_NOINLINE Fp fp_mul_call(const Fp& a, const Fp& b) { return fp_mul_os(a, b); }
 #endif

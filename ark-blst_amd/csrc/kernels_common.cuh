@@ -128,11 +128,7 @@ __device__ __forceinline__ void store_bucket(uint32_t* p, const ec::Proj<typenam
 
 // Complete addition as ONE out-of-line body per curve: the reduce / merge / cold paths call it from several sites.
 // G1 inlines its twelve multiplications inside it (latency-bound callers; ~16 % faster than the shared multiplier).
-__device__ __noinline__ void add_inplace(ec::Proj<ec::FpOps>& a, const ec::Proj<ec::FpOps>& b) {
-    ec::Proj<ec::FpOpsInline>& ai = reinterpret_cast<ec::Proj<ec::FpOpsInline>&>(a);
-    const ec::Proj<ec::FpOpsInline>& bi = reinterpret_cast<const ec::Proj<ec::FpOpsInline>&>(b);
-    ec::proj_add<ec::FpOpsInline>(ai, bi);
-}
+__device__ __noinline__ void add_inplace(ec::Proj<ec::FpOps>& a, const ec::Proj<ec::FpOps>& b) { ec::proj_add<ec::FpOpsInline>(a, b); }
 __device__ __noinline__ void add_inplace(ec::Proj<ec::Fp2Ops>& a, const ec::Proj<ec::Fp2Ops>& b) { ec::proj_add<ec::Fp2Ops>(a, b); }
 
 // ---------------------------------------------------------------------------------------------- scalars

@@ -235,7 +235,7 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
 
     if (wo) return J::inf();
     auto t0 = std::chrono::steady_clock::now();
-    J r = horner<J>(reinterpret_cast<const J*>(d.h_pairs), pl);
+    J r = horner<J>(static_cast<const J*>(d.h_pairs), pl);   // pinned bytes the D2H copy just wrote
     d.prof.host_fold_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return r;
 }

@@ -21,21 +21,21 @@ constexpr int FP12_WORDS = 12 * 16;
 constexpr uint32_t FP12_TREE_K = 2;   // a tree level is one latency chain of K - 1 products per wave: (K - 1) log_K(n) is smallest at K = 2
                                       // (2^16 pairs: 0.25 ms for 12 levels of 2 against 0.31 ms for 6 levels of 4)
 
-__device__ __forceinline__ PTower::E12 load_fp12(const uint32_t* p) {
+__device__ __forceinline__ PTower::E12 load_fp12(const uint32_t* p) {   // member by member: no pointer walk across struct members
+    using IO = ElemIO<ec::Fp2>;
     PTower::E12 r;
-    ec::Fp2* c = &r.c0.c0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) ElemIO<ec::Fp2>::load(c[i], p + 32 * i);
+    IO::load(r.c0.c0, p); IO::load(r.c0.c1, p + 32); IO::load(r.c0.c2, p + 64);
+    IO::load(r.c1.c0, p + 96); IO::load(r.c1.c1, p + 128); IO::load(r.c1.c2, p + 160);
     return r;
 }
 __device__ __forceinline__ void store_fp12(uint32_t* p, const PTower::E12& a) {
-    const ec::Fp2* c = &a.c0.c0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) ElemIO<ec::Fp2>::store(p + 32 * i, c[i]);
+    using IO = ElemIO<ec::Fp2>;
+    IO::store(p, a.c0.c0); IO::store(p + 32, a.c0.c1); IO::store(p + 64, a.c0.c2);
+    IO::store(p + 96, a.c1.c0); IO::store(p + 128, a.c1.c1); IO::store(p + 160, a.c1.c2);
 }
 
 #if defined(MI_TEST_HOOKS)   // the first version, one lane per pair: a second implementation for cross-checks (test builds only)
-__global__ void __launch_bounds__(64, 1) k_miller_loop(const uint32_t* __restrict__ g1_raw, const uint32_t* __restrict__ g2_raw, uint32_t n,
+__global__ void __launch_bounds__(64, 2) k_miller_loop(const uint32_t* __restrict__ g1_raw, const uint32_t* __restrict__ g2_raw, uint32_t n,
                                                        uint32_t* __restrict__ out) {
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
@@ -392,7 +392,10 @@ __global__ void __launch_bounds__(64, 1) k_miller_accumulate(const uint32_t* __r
         if ((fp28c::Z_ABS >> b) & 1) mul_line();
     }
     // z < 0: conjugate (w -> -w: odd coefficients negated); flat w^k -> tower slot c_{k&1}.c_{k>>1}
-    if (k & 1) own = pairing::PF2::norm2(ec::Fp2Ops::neg<4>(own));       // exact again: the tree takes coefficients < 2p
+    if (k & 1) {   // exact again (the tree takes coefficients < 2p): multiplied by one INLINE — this kernel uses AGPRs, so it must not call
+        const ec::Fp2 neg = ec::Fp2Ops::neg<4>(own);
+        own = ec::Fp2{fp28::fp_mul(neg.c0, fp28::fp_one()), fp28::fp_mul(neg.c1, fp28::fp_one())};
+    }
     if (valid) ElemIO<ec::Fp2>::store(out + (size_t)g_idx * FP12_WORDS + ((k & 1) * 3 + (k >> 1)) * 32, own);
 }
 
@@ -442,7 +445,7 @@ __global__ void __launch_bounds__(64, 1) k_fp12_prod(const uint32_t* __restrict_
     if (valid) ElemIO<ec::Fp2>::store(out + (size_t)g * FP12_WORDS + slot(k), own);
 }
 
-__global__ void __launch_bounds__(64) k_fp12_to_raw(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ raw) {
+__global__ void __launch_bounds__(64, 2) k_fp12_to_raw(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ raw) {
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
 #pragma unroll 1

@@ -2,7 +2,9 @@
 """bench.py — G1 MSM points/sec on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n L] [--group g1|g2]
-  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+  N > 1:  either the bare command above (bench.py then starts its N ranks itself: a child `python -m torch.distributed.run`
+          spawned BEFORE the parent touches the GPU; the parent relays the child's output and exit code), or the launcher form
+          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
               bench.py --gpus N --steps K --warmup W
 
 A "step" is one full MSM over one batch of synthetic (base, scalar) pairs through the C ABI (mi_msm_g1_device): digit
@@ -43,9 +45,38 @@ MAD_MEASURED_T = 33.4                          # tools/ubench_valu.hip on MI355X
 # k_accumulate<G1C>: instructions of one mixed addition in the shipped code object (tools/kernel_resources.py + llvm-objdump) priced
 # with the measured per-instruction costs at two waves per SIMD (profiles/r03_ubench_carry.txt): 3542 v_mad_u64_u32 x 4.8 + 126 v_mul_lo x 4.4
 # + 234 v_lshrrev_b64 x 4.6 + 235 v_lshl_add_u64 x 5.05 + 257 v_and x 2.6 + ~330 others x 2.6
-G1_ADD_INSTRUCTION_COST_CYCLES = 21300.0
 SIMDS, CLOCK_HZ = 1024, 2.4e9
+# Sum of the measured per-instruction issue costs (real cycles at the measured shader clock; tools/ubench_carry.hip re-based with
+# tools/probe/clock_probe.hip: clock64 ticks 100 MHz, the figures of profiles/r03_ubench_*.txt are 2.4-GHz pseudo-cycles and shrink by
+# clock / 2.4) of ONE wave-wide mixed addition, counted off the shipped code objects by tools/kernel_resources.py --mix; filled from
+# profiles/r04_instruction_costs.json when present
+def _load_instruction_costs():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r04_instruction_costs.json")))
+    except Exception:
+        return {}
+ADD_INSTRUCTION_COST = _load_instruction_costs()
 PAIRING_FP_MULS_PER_PAIR = 63 * (31 + 39) + 5 * (41 + 39)   # line + sparse Fp12 product per step, squarings shared
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as ONE child process tree (`python -m
+    torch.distributed.run`, one rank per GPU) and relay its output and exit code.  The parent has not imported torch and never
+    touches the GPU (a process that has initialised the GPU must not be replaced or re-executed on this pool)."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def _host_threads() -> int:
@@ -153,29 +184,85 @@ def _distort(scalars: bytes, n: int, dist: str) -> bytes:
     return a.tobytes()
 
 
+def _measured_clock(kernel_key: str, g: str = None, log_n=None):
+    """Shader clock of the timed kernel: GRBM_GUI_ACTIVE cycles per launch (a committed rocprofv3 PMC pass) / the kernel's average
+    duration in the kernel trace of the SAME profile run (tools/summarize_profile.py writes both; the r03 summaries carry the cycles
+    and their kernel_stats.csv the duration).  Returns (GHz, source) or (None, None)."""
+    try:
+        import csv
+        pdir = os.path.join(ROOT, "profiles")
+        for f in sorted((f for f in os.listdir(pdir) if f.endswith("_pmc_summary.json")), reverse=True):
+            pj = json.load(open(os.path.join(pdir, f)))
+            wl = pj.get("workload") or {}
+            if g is not None and (wl.get("group"), wl.get("log_n")) != (g, log_n):
+                continue
+            for k, v in pj.get("kernels", {}).items():
+                if kernel_key not in k:
+                    continue
+                if "shader_clock_ghz" in v:
+                    return v["shader_clock_ghz"], "profiles/" + f
+                if "gpu_cycles_per_launch" not in v:
+                    continue
+                stats = os.path.join(pdir, f.replace("_pmc_summary.json", "_kernel_stats.csv"))
+                for r in csv.DictReader(open(stats)):
+                    if kernel_key in r["Name"]:
+                        return v["gpu_cycles_per_launch"] / float(r["AverageNs"]), "profiles/" + f + " + " + os.path.basename(stats)
+    except Exception:
+        pass
+    return None, None
+
+
+def _valu_roofline(kernel: str, model: str, mads_per_launch: float, kernel_ms: float, clock, clock_src, extra: dict) -> dict:
+    """The binding roofline of this path: integer multiply-add issue.  peak = 1024 SIMDs x 64 lanes / 4 cycles per
+    wave64 v_mad_u64_u32 x 2.4 GHz (the guide's peak clock) = 39.3 T MAD/s; the kernels run at a lower clock under this load, so the
+    same bound at the MEASURED shader clock is printed beside it."""
+    tmad = mads_per_launch / (kernel_ms * 1e-3) / 1e12
+    r = {"bound": "valu_int_mad", "kernel": kernel, "achieved": tmad, "peak": MAD_PEAK_T, "unit": "T MAD/s", "frac": tmad / MAD_PEAK_T,
+         "model": model, "model_mads_per_launch": mads_per_launch, "kernel_ms": kernel_ms,
+         "measured_peak": MAD_MEASURED_T, "frac_of_measured_peak": tmad / MAD_MEASURED_T,
+         "shader_clock_ghz": clock, "shader_clock_source": clock_src}
+    if clock:
+        peak_clk = SIMDS * 64 * clock * 1e9 / 4 / 1e12
+        r["peak_at_measured_clock"] = peak_clk
+        r["frac_at_measured_clock"] = tmad / peak_clk
+    r.update(extra)
+    return r
+
+
 def _rooflines(g: str, n: int, log_n, acc_ms: float, nwin: int, precomputed: bool) -> dict:
     alg_bytes = ALG_BYTES_PER_POINT[g] * n
     gbs = alg_bytes / (acc_ms * 1e-3) / 1e9
     traffic, src = _traffic(g, log_n, precomputed) if log_n is not None else (None, None)
     mads = nwin * FP_MULS_PER_ADD[g] * MADS_PER_FP_MUL       # window-aware: one mixed addition per point and window
-    tmad = mads * n / (acc_ms * 1e-3) / 1e12
-    # cycles one SIMD spends per wave-wide mixed addition (64 additions), incl. the per-bucket set-up and the kernel's tail
-    cyc_per_wave_add = acc_ms * 1e-3 * CLOCK_HZ * SIMDS / (nwin * n / 64.0)
+    kernel = "k_accumulate<G1C>" if g == "g1" else "k_accumulate_g2_coop<G2C>"
+    key = "k_accumulate<msmk::G1C>" if g == "g1" else "k_accumulate_g2_coop"
+    clock, clock_src = _measured_clock(key, g, log_n)
+    if clock is None:
+        clock, clock_src = _measured_clock(key)
+    # real cycles one SIMD spends per wave-wide mixed addition (64 additions), incl. the per-bucket set-up and the kernel's tail
+    wave_adds = nwin * n / 64.0
+    cyc = lambda hz: acc_ms * 1e-3 * hz * SIMDS / wave_adds
+    cost = ADD_INSTRUCTION_COST.get(g)
+    extra = {"traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": alg_bytes,
+             "model_mads_per_point": mads,
+             "cycles_per_wave_addition": cyc(clock * 1e9) if clock else None,
+             "cycles_per_wave_addition_at_2p4ghz": cyc(CLOCK_HZ),
+             "instruction_cost_sum_cycles": cost["cycles"] if cost else None,
+             "instruction_cost_source": cost["source"] if cost else None,
+             "frac_of_instruction_cost_bound": (cost["cycles"] / cyc(clock * 1e9)) if (cost and clock) else None,
+             "note": "integer VALU (v_mad_u64_u32) is the bound of this path.  frac prices the MODEL's multiply-adds (300 per field "
+                     "multiplication on 32-bit limbs) at 4 cycles and 2.4 GHz; the kernel executes 28-bit limbs (406 multiply-adds per "
+                     "multiplication, no carry instructions) at the measured shader clock: instruction_cost_sum_cycles is the sum of its "
+                     "instructions' measured issue costs per wave-wide addition, frac_of_instruction_cost_bound how close it runs to that"}
+    valu = _valu_roofline(kernel, f"{nwin} windows x {FP_MULS_PER_ADD[g]} Fp-mul x {MADS_PER_FP_MUL} MAD per point", mads * n, acc_ms, clock, clock_src, extra)
     return {
-        "roofline": {"bound": "hbm", "kernel": "k_accumulate<G1C>" if g == "g1" else "k_accumulate_g2_coop<G2C>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": alg_bytes,
-                     "kernel_ms": acc_ms,
-                     "note": "the bucket method re-reads each device point once per window: traffic ~ windows x algorithmic by "
-                             "design; the kernel is bound by integer VALU issue, see valu_roofline"},
-        "valu_roofline": {"model_mads_per_point": mads, "model": f"{nwin} windows x {FP_MULS_PER_ADD[g]} Fp-mul x {MADS_PER_FP_MUL} MAD",
-                          "achieved_Tmad_s": tmad, "peak_Tmad_s": MAD_PEAK_T, "frac": tmad / MAD_PEAK_T,
-                          "measured_peak_Tmad_s": MAD_MEASURED_T, "frac_of_measured_peak": tmad / MAD_MEASURED_T,
-                          "cycles_per_wave_addition": cyc_per_wave_add,
-                          "instruction_cost_sum_cycles": G1_ADD_INSTRUCTION_COST_CYCLES if g == "g1" else None,
-                          "frac_of_instruction_cost_bound": (G1_ADD_INSTRUCTION_COST_CYCLES / cyc_per_wave_add) if g == "g1" else None,
-                          "note": "integer VALU (v_mad_u64_u32) is the real bound of this path; HBM frac is low by construction.  "
-                                  "frac prices the MODEL's 3000 multiply-adds per addition at 4 cycles; the kernel executes 4770 instructions "
-                                  "per addition (3542 multiply-adds at a measured 4.8 cycles) and runs at the sum of their measured costs"},
+        "roofline": valu,
+        "hbm_roofline": {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel_ms": acc_ms,
+                         "note": "reported because the north star asks for it; low by construction (the bucket method re-reads each "
+                                 "device point once per window: traffic ~ windows x algorithmic bytes, still far below 8 TB/s)"},
+        "valu_roofline": valu,   # alias of `roofline` (the key of rounds 1-3), kept for one more round
     }
 
 
@@ -278,24 +365,28 @@ def _pairing_leg(pkg, co, ncpu, device) -> dict:
         sample_ok = ctx.multi_pairing(p1[:96 * m], q2[:192 * m]) == cpu_gt
     acc_ms, lines_ms, miller_ms = pp["accumulate_ms"], pp["lines_ms"], pp["miller_ms"]
     mads = PAIRING_FP_MULS_PER_PAIR * MADS_PER_FP_MUL
-    tmad = mads * n / (miller_ms * 1e-3) / 1e12
     gbs = 288.0 * n / (miller_ms * 1e-3) / 1e9
     traffic, tsrc = _pairing_traffic()
+    clock, clock_src = _measured_clock("k_miller_accumulate")
+    pc = ADD_INSTRUCTION_COST.get("pairing") or {}
+    valu = _valu_roofline("k_miller_lines2 + k_miller_accumulate",
+                          f"{PAIRING_FP_MULS_PER_PAIR} Fp-mul per pair (63 doubling + 5 addition steps: line + sparse Fp12 product; "
+                          f"Fp12 squarings shared by all pairs) x {MADS_PER_FP_MUL} MAD", mads * n, miller_ms, clock, clock_src,
+                          {"traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": 288 * n, "model_mads_per_pair": mads,
+                           "per_kernel": {"k_miller_lines2": {"ms": lines_ms, "model_Tmad_s": (63 * 31 + 5 * 41) * MADS_PER_FP_MUL * n / (lines_ms * 1e-3) / 1e12},
+                                          "k_miller_accumulate": {"ms": acc_ms, "model_Tmad_s": 68 * 39 * MADS_PER_FP_MUL * n / (acc_ms * 1e-3) / 1e12}},
+                           "instruction_cost": pc or None})
     return {"metric": "pairs/s, batched Miller loop + final exponentiation (host buffers in, Gt out)", "value": n / best, "unit": "pairs/s",
             "n_pairs": n, "ms": best * 1e3, "miller_kernels_ms": miller_ms, "k_miller_lines2_ms": lines_ms,
             "k_miller_accumulate_ms": acc_ms, "pairs_per_accumulator": pp["pairs_per_accumulator"], "fp12_tree_ms": pp["tree_ms"], "h2d_ms": pp["h2d_ms"],
             "host_tail_ms": pp["host_ms"],
             "product_cancels_to_one": gt == pr_oracle.fp12_to_bytes(pr_oracle.FP12_ONE), f"bit_exact_{m}_pairs_vs_c_oracle": sample_ok,
             "bit_exact": sample_ok,
-            "roofline": {"bound": "hbm", "kernel": "k_miller_lines2 + k_miller_accumulate", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": 288 * n, "kernel_ms": miller_ms,
-                         "note": "288 B per pair in (96 B G1 + 192 B G2 affine); the 26 KB of line coefficients per pair written and "
-                                 "re-read between the two kernels are counted as traffic, not as algorithmic bytes"},
-            "valu_roofline": {"model_mads_per_pair": mads,
-                              "model": f"{PAIRING_FP_MULS_PER_PAIR} Fp-mul per pair (63 doubling + 5 addition steps: line + sparse Fp12 product; "
-                                       f"Fp12 squarings shared by all pairs) x {MADS_PER_FP_MUL} MAD",
-                              "achieved_Tmad_s": tmad, "peak_Tmad_s": MAD_PEAK_T, "frac": tmad / MAD_PEAK_T,
-                              "measured_peak_Tmad_s": MAD_MEASURED_T, "frac_of_measured_peak": tmad / MAD_MEASURED_T},
+            "roofline": valu, "valu_roofline": valu,
+            "hbm_roofline": {"bound": "hbm", "kernel": "k_miller_lines2 + k_miller_accumulate", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": 288 * n, "kernel_ms": miller_ms,
+                             "note": "288 B per pair in (96 B G1 + 192 B G2 affine); the 26 KB of line coefficients per pair written and "
+                                     "re-read between the two kernels are counted as traffic, not as algorithmic bytes"},
             "cpu_baseline": {"value": m / cpu_s, "unit": "pairs/s", "cores": ncpu, "kind": "port", "cpu_model": _cpu_model(),
                              "sample": f"{m} pairs incl. one final exponentiation; textbook affine Miller loop in portable C "
                                        "(oracle/pairing_oracle.c), an order of magnitude slower per core than assembly libraries", "seconds": cpu_s}}
@@ -306,6 +397,8 @@ def _in_process_leg(pkg, co, torch, ncpu, slots: int, log_n: int, steps: int) ->
     threads, no RCCL): `slots` device slots over the visible GPUs (round-robin; on a one-GPU box device 0 listed `slots`
     times — a rehearsal of the host plumbing, the slots then share the chip)."""
     ndev = torch.cuda.device_count()
+    if slots <= 0:   # default: every visible GPU (at most 8) once; on a one-GPU box device 0 twice (plumbing rehearsal)
+        slots = min(8, ndev) if ndev > 1 else 2
     ids = [k % ndev for k in range(slots)]
     n = 1 << log_n
     bases = co.gen_bases("g1", SEED_B + 7, n, ncpu)
@@ -360,11 +453,22 @@ def main() -> None:
                     help="scalar distribution (secondary robustness figures; the headline is uniform)")
     ap.add_argument("--no-secondary", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--in-process", type=int, default=0, metavar="SLOTS",
-                    help="N = 1 only: device slots of the in-library multi-GPU leg of the secondary set (default 2)")
+                    help="N = 1 only: device slots of the in-library multi-GPU leg of the secondary set (default: every visible GPU, at most 8; "
+                         "device 0 twice on a one-GPU box)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device rehearses the N>1 path on a single-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (rehearsal only)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the N > 1 exchange path (device_windows -> all_gather_into_tensor -> one D2H -> fold_windows) at any world "
+                         "size, including 1: a one-GPU box then executes the RCCL branch under a one-rank nccl group")
+    ap.add_argument("--timing-breakdown", action="store_true",
+                    help="N > 1: put a barrier between the library call and the exchange INSIDE the timed steps (msm / wait / exchange "
+                         "per step; costs one more collective per step).  Default: the timed steps carry no extra barrier and the "
+                         "breakdown is taken from a few extra steps after the timed region")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args.gpus))   # nothing below has run: this process never initialises the GPU
 
     import torch  # plumbing only: device buffers, synchronize, torch.distributed (RCCL)
     import torch.distributed as dist
@@ -373,14 +477,30 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("BENCH_LAUNCH_PROBE") == "1":
+        # launcher rehearsal for the CPU suite (tests/test_multigpu_gloo.py): the ranks meet over gloo, rank 0 prints ONE line
+        dist.init_process_group("gloo")
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, local_rank))
+        if rank == 0:
+            print(json.dumps({"launch_probe": True, "n_gpus": world, "ranks": sorted(r for r, _ in seen), "argv": sys.argv[1:]}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the MSM path")
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     on_gpu = args.backend == "nccl"   # collectives on device tensors (RCCL) or on host tensors (gloo rehearsal)
-    if world > 1:
+    exchange = world > 1 or args.force_exchange   # the N > 1 step; --force-exchange runs it under a one-rank group too
+    if exchange:
+        if world == 1:   # no launcher set the rendezvous up
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if on_gpu:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -420,8 +540,9 @@ def main() -> None:
     # ---- exchange step at N > 1: the library leaves this rank's per-window sums in DEVICE memory
     # (mi_msm_g1_device_windows: no D2H, no host fold), RCCL all-gathers them over xGMI, ONE D2H copy of the gathered block,
     # mi_g1_fold_windows adds the ranks per window in rank order and runs the Horner fold — identical result on every rank.
-    win_dev = torch.empty(pkg.MAX_WINDOWS * jac_bytes, dtype=torch.uint8, device="cuda") if world > 1 else None
-    xchg = {"info": None, "gather": None, "gather_host": None, "msm_s": 0.0, "wait_s": 0.0, "exchange_s": 0.0, "steps": 0}
+    win_dev = torch.empty(pkg.MAX_WINDOWS * jac_bytes, dtype=torch.uint8, device="cuda") if exchange else None
+    xchg = {"info": None, "gather": None, "gather_host": None, "msm_s": 0.0, "wait_s": 0.0, "exchange_s": 0.0, "steps": 0,
+            "barrier": bool(args.timing_breakdown)}
 
     def setup_exchange():
         """one untimed call: learn the window geometry, make every rank agree on it, size the gather buffers"""
@@ -440,12 +561,13 @@ def main() -> None:
         xchg["gather_host"] = gh.pin_memory() if on_gpu else gh
 
     def step() -> bytes:
-        if world == 1:
+        if not exchange:
             return leg.call()
         t_a = time.perf_counter()
         info = leg.ctx.msm_device_windows(g, leg.d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL, win_dev.data_ptr())
         t_b = time.perf_counter()
-        dist.barrier()   # separates waiting for the slowest rank (wait_ms) from the exchange proper (exchange_ms)
+        if xchg["barrier"]:
+            dist.barrier()   # separates waiting for the slowest rank (wait_ms) from the exchange proper (exchange_ms)
         t_w = time.perf_counter()
         nb = info[1] * jac_bytes
         if on_gpu:
@@ -463,11 +585,11 @@ def main() -> None:
         return out
 
     def fence():
-        if world > 1:
+        if exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world > 1:
+    if exchange:
         setup_exchange()
     for _ in range(args.warmup):
         step()
@@ -481,14 +603,24 @@ def main() -> None:
         prof_acc.append(leg.ctx.profile())
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if exchange:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        if not xchg["barrier"]:
+            # breakdown pass OUTSIDE the timed region: the timed steps carry no barrier (one collective less per step); a few more
+            # steps with one tell how a step splits into library call / waiting for the slowest rank / exchange proper
+            headline_steps = {k: xchg[k] for k in ("msm_s", "exchange_s", "steps")}
+            xchg.update(msm_s=0.0, wait_s=0.0, exchange_s=0.0, steps=0, barrier=True)
+            for _ in range(min(5, max(2, args.steps))):
+                step()
+            fence()
+            xchg["barrier"] = False
+            xchg["headline_steps"] = headline_steps
 
     # ---- parity: closed form over ALL ranks' inputs
     mine_expected = leg.expected_affine()          # affine bytes of this rank's shard
-    if world > 1:
+    if exchange:
         buf = [torch.empty(aff, dtype=torch.uint8, device=cdev) for _ in range(world)]
         dist.all_gather(buf, torch.frombuffer(bytearray(mine_expected), dtype=torch.uint8).to(cdev))
         expected_parts = [t.cpu().numpy().tobytes() for t in buf]
@@ -579,7 +711,7 @@ def main() -> None:
             guarded("g2_2p20", lambda: _secondary_msm(pkg, co, torch, "g2", 20, 4, ncpu, local_rank, 5))
             guarded("g1_2p20_precomputed_tables", lambda: _secondary_msm(pkg, co, torch, "g1", 20, 0, ncpu, local_rank, 10, precomputed=True))
         guarded("pairing_2p16", lambda: _pairing_leg(pkg, co, ncpu, local_rank))
-        guarded("in_process_multi_device", lambda: _in_process_leg(pkg, co, torch, ncpu, args.in_process or 2, 20, 5))
+        guarded("in_process_multi_device", lambda: _in_process_leg(pkg, co, torch, ncpu, args.in_process, 20, 5))
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -606,7 +738,7 @@ def main() -> None:
             "input_gen_s": gen_s,
         }
         out.update(_rooflines(g, headline_n, log_n, acc_ms, p0["num_windows"], args.precomputed))
-        if world > 1:
+        if exchange:
             exp_ms, exp_src = _expected_ms(g, log_n) if log_n is not None else (None, None)
             out["config"]["expected_ms_per_rank"] = exp_ms
             out["config"]["expected_ms_source"] = exp_src
@@ -614,18 +746,27 @@ def main() -> None:
             out["msm_ms"] = xchg["msm_s"] / ks * 1e3            # rank 0: the library call up to the window sums in device memory
             out["wait_ms"] = xchg["wait_s"] / ks * 1e3          # rank 0: barrier until the slowest rank has its window sums (load imbalance)
             out["exchange_ms"] = xchg["exchange_s"] / ks * 1e3  # rank 0: all-gather + one D2H + host fold (mi_g1_fold_windows)
-            out["exchange"] = {"backend": args.backend, "bytes_per_rank": xchg["info"][1] * jac_bytes, "windows": xchg["info"][1],
-                               "window_bits": xchg["info"][0],
+            out["exchange"] = {"backend": args.backend, "world_size": world, "bytes_per_rank": xchg["info"][1] * jac_bytes,
+                               "windows": xchg["info"][1], "window_bits": xchg["info"][0],
+                               "breakdown_from": "the timed steps (--timing-breakdown: a barrier inside every step)" if args.timing_breakdown
+                               else f"{ks} extra steps with a barrier, run after the timed region (the timed steps carry none)",
                                "path": "window sums in device memory -> all_gather_into_tensor -> one D2H of the gathered block -> mi_%s_fold_windows" % g}
+            if "headline_steps" in xchg:
+                hs = xchg["headline_steps"]
+                out["exchange"]["timed_steps_msm_ms"] = hs["msm_s"] / max(1, hs["steps"]) * 1e3
+                out["exchange"]["timed_steps_exchange_incl_wait_ms"] = hs["exchange_s"] / max(1, hs["steps"]) * 1e3
         if cpu_baseline:
             out["cpu_baseline"] = cpu_baseline
         if secondary:
             out["secondary"] = secondary
+            for k in ("pairing_2p16", "two_host_threads", "call_shapes"):   # top-level names of rounds 1-2, kept as aliases for one more round
+                if k in secondary:
+                    out[k] = secondary[k]
         # compact recap LAST: a log tail always shows the north-star figures (the driver keeps the last 2000 characters)
         def _brief(d):
             b = {"value": d.get("value"), "ms_per_step": d.get("ms_per_step", d.get("ms")), "bit_exact": d.get("bit_exact")}
-            if "valu_roofline" in d:
-                b["valu_frac"] = round(d["valu_roofline"]["frac"], 3)
+            if "roofline" in d and d["roofline"].get("bound") == "valu_int_mad":
+                b["valu_frac"] = round(d["roofline"]["frac"], 3)
             return b
         summary = {f"{g}_2p{log_n}" if log_n is not None else f"{g}_{headline_n}": _brief(out)}
         for k in ("g1_2p24", "g2_2p20", "pairing_2p16", "g1_2p20_precomputed_tables"):
@@ -633,7 +774,7 @@ def main() -> None:
                 summary[k] = _brief(secondary[k])
         if "call_shapes" in secondary:
             summary["call_shapes_ms"] = {k: round(v, 3) for k, v in secondary["call_shapes"].items() if isinstance(v, float)}
-        if world > 1:
+        if exchange:
             summary["n_gpus"] = world
             summary["exchange_ms"] = round(out["exchange_ms"], 4)
             summary["wait_ms"] = round(out["wait_ms"], 4)
@@ -641,7 +782,7 @@ def main() -> None:
             summary["cpu_points_per_s"] = cpu_baseline["value"]
         out["summary"] = summary
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if exchange:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -68,6 +68,27 @@ def test_hot_kernels_do_not_spill(pkg):
         assert v["vgpr_count"] + v.get("agpr_count", 0) <= 256, (k, v)
 
 
+def test_no_kernel_mixes_calls_and_agprs(pkg):
+    """Guard for the compiler issue of round 4 (csrc/Makefile, DESIGN.md §9 "call-ABI miscompare"; reproducer
+    tools/call_abi/repro_tower.hip): ROCm 7.2's hipcc miscompiles a kernel that keeps values across calls of out-of-line device
+    functions when interprocedural register allocation meets VGPR spills into AGPRs.  The library never lets the two meet: a
+    kernel with a call in its body is built for <= 256 registers per lane (.agpr_count, which the assembler maximises over the
+    callees, is 0), a kernel that uses AGPRs contains no call.  Read off the shipped code objects of BOTH builds."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import kernel_resources as kr
+
+    for test_hooks in (False, True):
+        lib = pkg.lib_path(test_hooks)
+        res, calls = kr.resources(lib), kr.kernels_with_calls(lib)
+        assert len(res) > 60 and set(res) == set(calls)
+        mixed = {k: (v["vgpr_count"], v["agpr_count"]) for k, v in res.items() if calls[k] and v.get("agpr_count", 0) > 0}
+        assert not mixed, mixed
+        assert any(calls.values()) and any(v.get("agpr_count", 0) > 0 for v in res.values())   # both kinds exist: the check is not vacuous
+
+
 def test_layout_sizes_match_reference_types(pkg):
     # blst_p1_affine 96, blst_p1 144, blst_p2_affine 192, blst_p2 288 (SURVEY Appendix A; src/gpu.rs:69-71)
     from ark_blst_amd import binding as b

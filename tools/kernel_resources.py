@@ -146,6 +146,30 @@ def scratch_in_hot_loops(lib: str | None = None) -> dict[str, int]:
     return out
 
 
+def kernels_with_calls(lib: str | None = None) -> dict[str, bool]:
+    """demangled kernel name -> its own body contains a call (s_swappc_b64), read off the disassembly of the shipped code objects.
+    Together with .agpr_count (which covers the kernel's whole call graph: the assembler takes the maximum over the callees) this is
+    the invariant of csrc/Makefile's compiler-issue note: a kernel with calls uses no AGPRs."""
+    lib = lib or os.path.join(ROOT, "ark-blst_amd", "lib", "libarkblst_amd.so")
+    out: dict[str, bool] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for elf in code_objects(lib, tmp):
+            kernels = set(kernels_of(elf))
+            txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", elf], capture_output=True, text=True, check=True).stdout
+            sym, found = None, {}
+            for line in txt.splitlines():
+                m = re.match(r"^[0-9a-f]{16} <(.+)>:$", line)
+                if m:
+                    sym = m.group(1)
+                    found.setdefault(sym, False)
+                elif sym is not None and "s_swappc_b64" in line:
+                    found[sym] = True
+            names = demangle([k for k in found if k in kernels])
+            for raw, name in names.items():
+                out[name] = found[raw]
+    return out
+
+
 # cycles per wave-instruction at two waves per SIMD (profiles/r03_ubench_carry.txt, r03_ubench_mad_banks.txt); VOP3 encodings ~4.4-5.0, VOP1/2 ~2.6
 COST = {"v_mad_u64_u32": 4.8, "v_mul_lo_u32": 4.4, "v_lshrrev_b64": 4.6, "v_lshl_add_u64": 5.05, "v_ashrrev_i64": 4.5, "v_alignbit_b32": 4.6,
         "v_lshl_add_u32": 4.4, "v_add3_u32": 4.4, "v_or3_b32": 4.4, "v_lshl_or_b32": 4.4, "v_bitop3_b32": 4.4, "v_mov_b64_e32": 4.4,

@@ -47,6 +47,15 @@ for k, v in out.items():
         v["hbm_bytes_largest_launch_corrected"] = (2.0 * v["FETCH_SIZE_max"] + v["WRITE_SIZE_max"]) * 1024.0
     if "GRBM_GUI_ACTIVE" in v:
         v["gpu_cycles_per_launch"] = v["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+# shader clock of each kernel under its own load: cycles per launch (PMC pass) / average duration (kernel trace of the stats pass)
+try:
+    dur = {r["Name"].split("(")[0].replace("void ", ""): float(r["AverageNs"]) for r in csv.DictReader(open(f"profiles/{tag}_kernel_stats.csv"))}
+    for k, v in out.items():
+        if "gpu_cycles_per_launch" in v and k in dur and dur[k] > 0:
+            v["avg_ns_in_kernel_trace"] = dur[k]
+            v["shader_clock_ghz"] = v["gpu_cycles_per_launch"] / dur[k]
+except Exception as e:
+    print("no shader clock:", e)
 json.dump({"source": f"rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*, one pass each) of `python3 {cmd}` "
                      "(means over all launches of a kernel in the run, warm-up launches included)",
            "workload": {"group": group, "log_n": log_n, "precomputed": precomputed},
