@@ -392,6 +392,85 @@ def _pairing_leg(pkg, co, ncpu, device) -> dict:
                                        "(oracle/pairing_oracle.c), an order of magnitude slower per core than assembly libraries", "seconds": cpu_s}}
 
 
+NORM_FP_MULS_PER_POINT = 12          # product tree up + down (fan-out 32): ~5, Z^-2, Z^-3, x and y: 4, conversions in and out: 3
+DESER_FP_MULS_PER_POINT = 570 + 1650  # y = (x^3 + 4)^((p+1)/4): 378 squarings + ~190 products; subgroup test: two 64-bit ladders on complete formulas
+
+
+def _normalize_leg(pkg, co, ncpu, device, log_n=20) -> dict:
+    """Row (f)-2 of SURVEY.md 8: CurveGroup::normalize_batch (src/g1.rs:537-543) for 2^20 G1 points with non-trivial Z through
+    mi_g1_normalize_batch (host buffers in and out; the kernels are timed on the library's stream), a sample checked against the C
+    oracle, which is also the timed CPU baseline."""
+    n = 1 << log_n
+    m = 1 << 12
+    bases = co.gen_bases("g1", SEED_B + 201, m + 1, ncpu)
+    one = _mont_one()
+    jac = b"".join(co.sum_jac("g1", bases[96 * i:96 * i + 96] + one + bases[96 * (i + 1):96 * (i + 2)] + one, 2) for i in range(m))
+    blob = jac * (n // m)
+    with pkg.Context([device]) as ctx:
+        ctx.normalize_batch("g1", blob[:144 * 1024])
+        best, kms, out = 1e30, None, b""
+        for _ in range(3):
+            t1 = time.perf_counter()
+            out = ctx.normalize_batch("g1", blob)
+            dt = time.perf_counter() - t1
+            if dt < best:
+                best, kms = dt, ctx.profile()["accumulate_ms"]
+    t1 = time.perf_counter()
+    cpu = co.normalize_batch("g1", blob, ncpu)
+    cpu_s = time.perf_counter() - t1
+    ok = out == cpu
+    mads = NORM_FP_MULS_PER_POINT * MADS_PER_FP_MUL
+    clock, clock_src = _measured_clock("k_accumulate<msmk::G1C>")
+    gbs = (144 + 96) * n / (kms * 1e-3) / 1e9
+    return {"metric": "G1 points/s, normalize_batch (Jacobian -> affine, one inversion)", "value": n / (kms * 1e-3), "unit": "points/s", "n": n,
+            "kernels_ms": kms, "call_ms_host_buffers": best * 1e3, "bit_exact": ok,
+            "workload": f"2^{log_n} G1 Jacobian points with non-trivial Z, host buffers in and out (PCIe-inclusive figure: call_ms_host_buffers)",
+            "roofline": {"bound": "hbm", "kernel": "k_norm_load + k_norm_up/down x levels + k_norm_final", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": (144 + 96) * n, "kernel_ms": kms,
+                         "note": "algorithmic bytes = 144 B Jacobian in + 96 B affine out per point; the product tree adds ~3 x 64 B of "
+                                 "intermediate values per point and level-0 element; arithmetic is 12 field multiplications per point, "
+                                 "so neither roof is close: the row is bound by its five dependent passes over the data"},
+            "valu_roofline": _valu_roofline("normalize kernels", f"{NORM_FP_MULS_PER_POINT} Fp-mul x {MADS_PER_FP_MUL} MAD per point", mads * n, kms, clock, clock_src, {}),
+            "cpu_baseline": {"value": n / cpu_s, "unit": "points/s", "cores": ncpu, "kind": "port", "cpu_model": _cpu_model(), "seconds": cpu_s,
+                             "sample": f"the same 2^{log_n} points: Montgomery's simultaneous inversion per thread slice (oracle/msm_oracle.c "
+                                       "orc_g1_normalize_batch), what blstrs batch_normalize does"}}
+
+
+def _deserialize_leg(pkg, co, ncpu, device, log_n=20) -> dict:
+    """Row (f)-4: bulk G1 point decoding (src/g1.rs:386-431), 2^20 compressed encodings with Valid::check on, through
+    mi_g1_deserialize_batch; all points checked against the inputs they were serialised from, a sample against the C oracle."""
+    n = 1 << log_n
+    bases = co.gen_bases("g1", SEED_B + 202, n, ncpu)
+    with pkg.Context([device]) as ctx:
+        enc = ctx.g1_serialize_batch(bases, True)
+        ctx.g1_deserialize_batch(enc[:48 * 1024], True, True)
+        t1 = time.perf_counter()
+        dec, st = ctx.g1_deserialize_batch(enc, True, True)
+        wall = time.perf_counter() - t1
+        kms = ctx.profile()["accumulate_ms"]
+        t1 = time.perf_counter()
+        ctx.g1_deserialize_batch(enc, True, False)
+        kms_novalidate = ctx.profile()["accumulate_ms"]
+    m = 1 << 16   # CPU sample: ~1 s on 16 threads
+    t1 = time.perf_counter()
+    cdec, cst = co.g1_deserialize_batch(enc[:48 * m], True, True, 1, ncpu)
+    cpu_s = time.perf_counter() - t1
+    ok = dec == bases and st == bytes(n) and cdec == bases[:96 * m] and cst == bytes(m)
+    mads = DESER_FP_MULS_PER_POINT * MADS_PER_FP_MUL
+    clock, clock_src = _measured_clock("k_accumulate<msmk::G1C>")
+    gbs = (48 + 96) * n / (kms * 1e-3) / 1e9
+    return {"metric": "G1 points/s, deserialize_batch (compressed, validate on)", "value": n / (kms * 1e-3), "unit": "points/s", "n": n,
+            "kernel_ms": kms, "kernel_ms_validate_off": kms_novalidate, "call_ms_host_buffers": wall * 1e3, "bit_exact": ok,
+            "workload": f"2^{log_n} compressed G1 encodings (48 B), decompression + on-curve + subgroup check, host buffers in and out",
+            "roofline": _valu_roofline("k_deserialize_g1", f"{DESER_FP_MULS_PER_POINT} Fp-mul (square root 570 + subgroup test 1650) x {MADS_PER_FP_MUL} MAD per point",
+                                       mads * n, kms, clock, clock_src, {"traffic": None, "algorithmic_bytes_per_launch": (48 + 96) * n}),
+            "hbm_roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": (48 + 96) * n},
+            "cpu_baseline": {"value": m / cpu_s, "unit": "points/s", "cores": ncpu, "kind": "port", "cpu_model": _cpu_model(), "seconds": cpu_s,
+                             "sample": f"{m} of the encodings: square root by exponentiation + endomorphism subgroup test in C "
+                                       "(oracle/msm_oracle.c orc_g1_deserialize_batch, mode 1)"}}
+
+
 def _in_process_leg(pkg, co, torch, ncpu, slots: int, log_n: int, steps: int) -> dict:
     """The in-library multi-device path INTEGRATION.md binds (one context over several devices, persistent per-device host
     threads, no RCCL): `slots` device slots over the visible GPUs (round-robin; on a one-GPU box device 0 listed `slots`
@@ -711,6 +790,9 @@ def main() -> None:
             guarded("g2_2p20", lambda: _secondary_msm(pkg, co, torch, "g2", 20, 4, ncpu, local_rank, 5))
             guarded("g1_2p20_precomputed_tables", lambda: _secondary_msm(pkg, co, torch, "g1", 20, 0, ncpu, local_rank, 10, precomputed=True))
         guarded("pairing_2p16", lambda: _pairing_leg(pkg, co, ncpu, local_rank))
+        if g == "g1" and log_n == 20 and not args.precomputed and args.dist == "uniform":
+            guarded("normalize_2p20", lambda: _normalize_leg(pkg, co, ncpu, local_rank))
+            guarded("deserialize_2p20", lambda: _deserialize_leg(pkg, co, ncpu, local_rank))
         guarded("in_process_multi_device", lambda: _in_process_leg(pkg, co, torch, ncpu, args.in_process, 20, 5))
 
     if rank == 0:
@@ -764,12 +846,12 @@ def main() -> None:
                     out[k] = secondary[k]
         # compact recap LAST: a log tail always shows the north-star figures (the driver keeps the last 2000 characters)
         def _brief(d):
-            b = {"value": d.get("value"), "ms_per_step": d.get("ms_per_step", d.get("ms")), "bit_exact": d.get("bit_exact")}
+            b = {"value": d.get("value"), "ms_per_step": d.get("ms_per_step", d.get("ms", d.get("kernel_ms", d.get("kernels_ms")))), "bit_exact": d.get("bit_exact")}
             if "roofline" in d and d["roofline"].get("bound") == "valu_int_mad":
                 b["valu_frac"] = round(d["roofline"]["frac"], 3)
             return b
         summary = {f"{g}_2p{log_n}" if log_n is not None else f"{g}_{headline_n}": _brief(out)}
-        for k in ("g1_2p24", "g2_2p20", "pairing_2p16", "g1_2p20_precomputed_tables"):
+        for k in ("g1_2p24", "g2_2p20", "pairing_2p16", "g1_2p20_precomputed_tables", "normalize_2p20", "deserialize_2p20"):
             if k in secondary and "error" not in secondary[k]:
                 summary[k] = _brief(secondary[k])
         if "call_shapes" in secondary:

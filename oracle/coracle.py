@@ -40,6 +40,9 @@ def lib():
             getattr(L, f"orc_{g}_gen_bases").argtypes = [u64, sz, i32, u8p]
             getattr(L, f"orc_{g}_on_curve").argtypes = [u8p]
             getattr(L, f"orc_{g}_on_curve").restype = i32
+            getattr(L, f"orc_{g}_normalize_batch").argtypes = [u8p, sz, i32, u8p]
+        L.orc_g1_deserialize_batch.argtypes = [u8p, sz, i32, i32, i32, i32, u8p, u8p]
+        L.orc_g1_deserialize_batch.restype = i32
         L.orc_gen_scalars.argtypes = [u64, sz, i32, u8p]
         L.orc_gen_dlogs.argtypes = [u64, sz, u8p]
         L.orc_dot_mod_r.argtypes = [u8p, u64, sz, u8p]
@@ -127,6 +130,28 @@ def dlog_expected(group: str, scalars_canon: bytes, seed_bases: int, n: int) -> 
     dot = C.create_string_buffer(32)
     lib().orc_dot_mod_r(scalars_canon, seed_bases, n, dot)
     return mul_gen(group, int.from_bytes(dot.raw, "little"))
+
+
+def normalize_batch(group: str, jac: bytes, nthreads: int = 1) -> bytes:
+    """CurveGroup::normalize_batch (src/g1.rs:537-543): Jacobian -> affine with one inversion per thread slice."""
+    aff, jsz = _sizes(group)
+    n = len(jac) // jsz
+    assert len(jac) == n * jsz
+    out = C.create_string_buffer(aff * n)
+    getattr(lib(), f"orc_{group}_normalize_batch")(jac, n, nthreads, out)
+    return out.raw
+
+
+def g1_deserialize_batch(data: bytes, compressed: bool, validate: bool, subgroup_mode: int = 0, nthreads: int = 1):
+    """G1 point decoding + Valid::check (src/g1.rs:386-431).  subgroup_mode 0: [r] P == infinity (the definition, the checker);
+    1: the endomorphism test (the timed baseline).  Returns (affine bytes, status bytes)."""
+    size = 48 if compressed else 96
+    n = len(data) // size
+    assert len(data) == n * size
+    out, st = C.create_string_buffer(G1_AFF * n), C.create_string_buffer(n)
+    rc = lib().orc_g1_deserialize_batch(data, n, int(compressed), int(validate), subgroup_mode, nthreads, out, st)
+    assert rc == 0
+    return out.raw, st.raw
 
 
 def fp_mul(a: bytes, b: bytes) -> bytes:

@@ -366,3 +366,177 @@ int orc_selfcheck(void) {
     if (!g2_jac_is_inf(&t2)) return 8;
     return 0;
 }
+
+/* ============================================================================================================
+ * Rows (f)-2 and (f)-4 of SURVEY.md §8: the callers either side of the MSM, restated for the checker and the timed CPU baseline.
+ *
+ * orc_g{1,2}_normalize_batch — CurveGroup::normalize_batch (/root/reference/src/g1.rs:537-543, src/g2.rs:517-523) forwards to
+ *   blstrs::G{1,2}Projective::batch_normalize [third-party, absent]: Montgomery's simultaneous inversion — prefix products of the
+ *   Z coordinates (infinity skipped), ONE field inversion, back-substitution; x = X / Z^2, y = Y / Z^3; infinity -> all-zero.
+ *   Threads split the input into contiguous slices, each with its own inversion (what a rayon caller would do).
+ * orc_g1_deserialize_batch — CanonicalDeserialize + Valid::check for G1 (/root/reference/src/g1.rs:386-431): the ZCash / IETF
+ *   encoding (flags 0x80 compressed, 0x40 infinity, 0x20 larger root), y = (x^3 + 4)^((p+1)/4), on-curve test and subgroup
+ *   membership.  subgroup_mode 0 = the definition ([r] P == infinity, bit-serial: the CHECKER), 1 = the endomorphism test
+ *   (beta x, y) == -[z^2] (x, y) of M. Scott, eprint 2021/1130 (two 64-bit ladders; what assembly libraries do in comparable
+ *   time: the TIMED baseline; tests hold the two modes against each other on points inside and outside the subgroup).
+ *   status: 0 ok, 1 malformed encoding, 2 not on the curve, 3 not in the subgroup; rejected points are written as all-zero.
+ * ============================================================================================================ */
+typedef struct { const uint8_t *in; uint8_t *out; size_t n, per; } norm_ctx;
+
+#define DEFINE_NORMALIZE(G_, FE_, F_)                                                                                      \
+    static void G_##_norm_slice(void *vctx, size_t t) {                                                                    \
+        norm_ctx *c = (norm_ctx *)vctx;                                                                                    \
+        size_t lo = t * c->per, hi = lo + c->per < c->n ? lo + c->per : c->n;                                              \
+        if (lo >= hi) return;                                                                                              \
+        size_t m = hi - lo;                                                                                                \
+        const G_##_jac *p = (const G_##_jac *)c->in + lo;                                                                  \
+        G_##_affine *o = (G_##_affine *)c->out + lo;                                                                       \
+        FE_ *pre = (FE_ *)malloc(sizeof(FE_) * m);                                                                         \
+        FE_ acc = F_##_one();                                                                                              \
+        for (size_t i = 0; i < m; i++) { /* pre[i] = product of the finite Z before i */                                   \
+            pre[i] = acc;                                                                                                  \
+            if (!G_##_jac_is_inf(&p[i])) F_##_mul(&acc, &acc, &p[i].z);                                                    \
+        }                                                                                                                  \
+        FE_ inv;                                                                                                           \
+        F_##_inv(&inv, &acc);                                                                                              \
+        for (size_t i = m; i-- > 0;) {                                                                                     \
+            if (G_##_jac_is_inf(&p[i])) { memset(&o[i], 0, sizeof o[i]); continue; }                                       \
+            FE_ zi, zi2, zi3;                                                                                              \
+            F_##_mul(&zi, &inv, &pre[i]);       /* 1 / Z_i */                                                              \
+            F_##_mul(&inv, &inv, &p[i].z);      /* drop Z_i from the running inverse */                                    \
+            F_##_sqr(&zi2, &zi);                                                                                           \
+            F_##_mul(&zi3, &zi2, &zi);                                                                                     \
+            F_##_mul(&o[i].x, &p[i].x, &zi2);                                                                              \
+            F_##_mul(&o[i].y, &p[i].y, &zi3);                                                                              \
+        }                                                                                                                  \
+        free(pre);                                                                                                         \
+    }                                                                                                                      \
+    void orc_##G_##_normalize_batch(const uint8_t *jac, size_t n, int nthreads, uint8_t *out_aff) {                        \
+        if (nthreads < 1) nthreads = 1;                                                                                    \
+        norm_ctx c = {jac, out_aff, n, (n + (size_t)nthreads - 1) / (size_t)nthreads};                                     \
+        if (n) parallel_for((size_t)nthreads, nthreads, G_##_norm_slice, &c);                                              \
+    }
+DEFINE_NORMALIZE(g1, fp, fp)
+DEFINE_NORMALIZE(g2, fp2, fp2)
+
+/* a^e for a little-endian 6-limb exponent */
+static void fp_pow6(fp *r, const fp *a, const uint64_t e[6]) {
+    fp acc = FP_ONE;
+    int top = 383;
+    while (top > 0 && !((e[top >> 6] >> (top & 63)) & 1)) top--;
+    for (int i = top; i >= 0; i--) {
+        fp_sqr(&acc, &acc);
+        if ((e[i >> 6] >> (i & 63)) & 1) fp_mul(&acc, &acc, a);
+    }
+    *r = acc;
+}
+static int be48_to_fp_canon(uint64_t out[6], const uint8_t *b, uint8_t top_mask) { /* returns 1 when the integer is < p */
+    for (int k = 0; k < 6; k++) {
+        uint64_t v = 0;
+        for (int j = 0; j < 8; j++) {
+            uint8_t byte = b[40 - 8 * k + j];
+            if (k == 5 && j == 0) byte &= top_mask;
+            v = (v << 8) | byte;
+        }
+        out[k] = v;
+    }
+    return !fp_geq_p(out);
+}
+static int fp_canon_gt_half(const fp *y_mont) { /* canonical y > (p-1)/2 */
+    fp c; fp_from_mont(&c, y_mont);
+    uint64_t half[6], carry = 0;
+    for (int i = 5; i >= 0; i--) { uint64_t v = FP_P.l[i]; half[i] = (v >> 1) | (carry << 63); carry = v & 1; }
+    for (int i = 5; i >= 0; i--) if (c.l[i] != half[i]) return c.l[i] > half[i];
+    return 0;
+}
+/* beta: the cube root of unity with (beta x, y) = [-z^2] (x, y) on the r-torsion; found at first use as one of the two non-trivial
+ * roots 2^((p-1)/3) powers by testing the generator (no table copied from anywhere) */
+static fp G1_BETA; static int G1_BETA_READY = 0; static pthread_mutex_t BETA_MU = PTHREAD_MUTEX_INITIALIZER;
+static void g1_mul_u64(g1_jac *r, const g1_jac *p, uint64_t k) {
+    g1_jac acc; g1_jac_set_inf(&acc);
+    for (int i = 63; i >= 0; i--) {
+        g1_jac_double(&acc, &acc);
+        if ((k >> i) & 1) g1_jac_add(&acc, &acc, p);
+    }
+    *r = acc;
+}
+static int g1_endo_holds(const fp *beta, const g1_affine *p) { /* (beta x, y) == -[z^2] P */
+    g1_jac j, q; g1_jac_from_affine(&j, p);
+    g1_mul_u64(&q, &j, 0xd201000000010000ULL);
+    g1_mul_u64(&q, &q, 0xd201000000010000ULL);
+    if (g1_jac_is_inf(&q)) return 0;
+    g1_affine qa; g1_jac_to_affine(&qa, &q);
+    fp bx, ny; fp_mul(&bx, beta, &p->x); fp_neg(&ny, &p->y);
+    return fp_eq(&qa.x, &bx) && fp_eq(&qa.y, &ny);
+}
+static void g1_beta_init(void) {
+    pthread_mutex_lock(&BETA_MU);
+    if (!G1_BETA_READY) {
+        uint64_t e[6], rem = 0; /* (p - 1) / 3 */
+        fp pm1 = FP_P; pm1.l[0] -= 1;
+        for (int i = 5; i >= 0; i--) { unsigned __int128 v = ((unsigned __int128)rem << 64) | pm1.l[i]; e[i] = (uint64_t)(v / 3); rem = (uint64_t)(v % 3); }
+        fp two, w, w2; fp_add(&two, &FP_ONE, &FP_ONE);
+        fp_pow6(&w, &two, e);                 /* a cube root of unity (2 is not a cube mod p, so w != 1) */
+        fp_sqr(&w2, &w);
+        g1_affine g; g1_generator(&g);
+        G1_BETA = g1_endo_holds(&w, &g) ? w : w2;
+        G1_BETA_READY = g1_endo_holds(&G1_BETA, &g) ? 1 : -1;
+    }
+    pthread_mutex_unlock(&BETA_MU);
+}
+typedef struct { const uint8_t *bytes; size_t n, per; int compressed, validate, mode; uint8_t *out, *status; } deser_ctx;
+static uint8_t g1_deserialize_one(const uint8_t *b, int compressed, int validate, int mode, g1_affine *out) {
+    memset(out, 0, sizeof *out);
+    unsigned c_flag = b[0] >> 7, i_flag = (b[0] >> 6) & 1, s_flag = (b[0] >> 5) & 1;
+    if (c_flag != (unsigned)(compressed ? 1 : 0)) return 1;
+    uint64_t xc[6], yc[6] = {0, 0, 0, 0, 0, 0};
+    int x_ok = be48_to_fp_canon(xc, b, 0x1f), y_ok = 1;
+    if (!compressed) y_ok = be48_to_fp_canon(yc, b + 48, 0xff);
+    if (i_flag) {
+        uint64_t any = s_flag;
+        for (int k = 0; k < 6; k++) any |= xc[k] | yc[k];
+        return any ? 1 : 0;   /* infinity: the all-zero point */
+    }
+    if (!x_ok || !y_ok || (!compressed && s_flag)) return 1;
+    fp t, x, y, rhs, four, y2;
+    memcpy(t.l, xc, 48); fp_to_mont(&x, &t);
+    fp_add(&four, &FP_ONE, &FP_ONE); fp_add(&four, &four, &four);
+    fp_sqr(&rhs, &x); fp_mul(&rhs, &rhs, &x); fp_add(&rhs, &rhs, &four);
+    if (compressed) {
+        uint64_t e[6], carry = 0; /* (p + 1) / 4 */
+        fp pp1 = FP_P; pp1.l[0] += 1;
+        for (int i = 5; i >= 0; i--) { uint64_t v = pp1.l[i]; e[i] = (v >> 2) | (carry << 62); carry = v & 3; }
+        fp_pow6(&y, &rhs, e);
+        fp_sqr(&y2, &y);
+        if (!fp_eq(&y2, &rhs)) return 1;
+        if (fp_canon_gt_half(&y) != (int)s_flag) fp_neg(&y, &y);
+    } else {
+        memcpy(t.l, yc, 48); fp_to_mont(&y, &t);
+        fp_sqr(&y2, &y);
+        if (validate && !fp_eq(&y2, &rhs)) return 2;
+    }
+    g1_affine p; p.x = x; p.y = y;
+    if (validate) {
+        if (mode == 0) {
+            g1_jac r; g1_mul_naive(&r, &p, FR_R.l);
+            if (!g1_jac_is_inf(&r)) return 3;
+        } else if (!g1_endo_holds(&G1_BETA, &p)) return 3;
+    }
+    *out = p;
+    return 0;
+}
+static void g1_deser_slice(void *vctx, size_t t) {
+    deser_ctx *c = (deser_ctx *)vctx;
+    size_t lo = t * c->per, hi = lo + c->per < c->n ? lo + c->per : c->n, size = c->compressed ? 48 : 96;
+    for (size_t i = lo; i < hi; i++)
+        c->status[i] = g1_deserialize_one(c->bytes + i * size, c->compressed, c->validate, c->mode, (g1_affine *)c->out + i);
+}
+int orc_g1_deserialize_batch(const uint8_t *bytes, size_t n, int compressed, int validate, int subgroup_mode, int nthreads,
+                             uint8_t *out_aff, uint8_t *status) {
+    if (subgroup_mode == 1) { g1_beta_init(); if (G1_BETA_READY != 1) return -1; }
+    if (nthreads < 1) nthreads = 1;
+    size_t chunks = (size_t)nthreads * 8;   /* finer than one slice per thread: the work per point is uneven only across statuses */
+    deser_ctx c = {bytes, n, (n + chunks - 1) / chunks, compressed, validate, subgroup_mode, out_aff, status};
+    if (n) parallel_for(chunks, nthreads, g1_deser_slice, &c);
+    return 0;
+}

@@ -513,6 +513,36 @@ def test_msm_batch_over_resident_bases(ctx, co, pkg, group):
     assert [co.to_affine(group, x) for x in dev] == [co.to_affine(group, x) for x in got]
 
 
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_cofactor_clearing_through_the_hip_path(ctx, co, o, group):
+    """The same property on the GPU (tests/test_oracle.py::test_cofactor_clearing_pins_the_group_law holds it for the two oracles):
+    a curve point OUTSIDE the prime-order subgroup times the reference-held cofactor (src/g1.rs:42, src/g2.rs:45-54), computed by
+    mi_msm_g{1,2}, equals both oracles' value, is not infinity, and r times it is infinity."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cofactor_util import H1, H2, off_subgroup_points, h2_pieces, SPLIT_BITS
+
+    F = o.F1 if group == "g1" else o.F2
+    h = H1 if group == "g1" else H2
+    for pt in off_subgroup_points(o, group, 3):
+        want = o.affine_to_bytes(F, o.scalar_mul(F, pt, h))
+        if group == "g1":
+            bases, sc, n = o.affine_to_bytes(F, pt), h.to_bytes(32, "little"), 1
+        else:
+            bases = b"".join(o.affine_to_bytes(F, o.scalar_mul(F, pt, 1 << (SPLIT_BITS * i))) for i in range(3))
+            sc, n = b"".join(a.to_bytes(32, "little") for a in h2_pieces()), 3
+        got = _canon(co, group, ctx.msm(group, bases, sc, n, 0))
+        assert got == want and got != bytes(len(want))
+        assert got == co.to_affine(group, co.msm(group, bases, sc, n, 0, 1))
+        rq = ctx.msm(group, got + got, (o.R_ORDER - 1).to_bytes(32, "little") + (1).to_bytes(32, "little"), 2, 0)
+        assert _canon(co, group, rq) == bytes(len(want))               # r * (h P) = infinity
+        # ... and r * P itself is NOT: the point really was outside the subgroup (so the property above is not vacuous)
+        rp = ctx.msm(group, o.affine_to_bytes(F, pt) * 2, (o.R_ORDER - 1).to_bytes(32, "little") + (1).to_bytes(32, "little"), 2, 0)
+        assert _canon(co, group, rp) == o.affine_to_bytes(F, o.scalar_mul(F, pt, o.R_ORDER))
+        assert _canon(co, group, rp) != bytes(len(want))
+
+
 def test_call_abi_reproducer():
     """The compiler issue behind round 3's "codegen-dependent miscompares" (csrc/Makefile): tools/call_abi/repro_tower.hip
     — the test-only single-lane Miller loop's shape: a kernel that keeps the point and the line state across ~40 calls of
@@ -556,6 +586,9 @@ def test_bench_json_contract():
     assert d["unit"] == "points/s" and d["higher_is_better"] is True and "workload" in d["config"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in d["roofline"], k
+    # the roofline key names the BINDING bound of this path (integer multiply-add issue); the HBM line the north star asks for sits beside it
+    assert d["roofline"]["bound"] == "valu_int_mad" and d["roofline"]["unit"] == "T MAD/s" and 0.05 < d["roofline"]["frac"] < 1.0
+    assert d["hbm_roofline"]["bound"] == "hbm" and d["hbm_roofline"]["unit"] == "GB/s" and d["valu_roofline"] == d["roofline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port"
@@ -582,6 +615,48 @@ def test_bench_two_ranks_exchange_from_device_memory():
     assert d["n_gpus"] == 2 and d["bit_exact"] is True and d["scaling"] == "strong" and d["config"]["total_points"] == 1 << 15
     assert d["exchange_ms"] > 0 and d["msm_ms"] > 0 and d["exchange"]["windows"] == d["config"]["num_windows"]
     assert d["summary"]["n_gpus"] == 2 and "expected_ms_per_rank" in d["config"]
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` with NO launcher in the command and no WORLD_SIZE in the environment (the form the driver uses for
+    N = 1): bench.py starts its two ranks itself; here they share GPU 0 and meet over gloo (RCCL refuses two ranks per device)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--total-log-n", "15", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--share-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["bit_exact"] is True and d["scaling"] == "strong" and d["exchange"]["world_size"] == 2
+    assert d["exchange"]["timed_steps_msm_ms"] > 0 and d["wait_ms"] >= 0   # breakdown from the extra steps, none inside the timed ones
+
+
+def test_bench_exchange_runs_under_one_rank_rccl():
+    """The RCCL branch of bench.py's exchange on a one-GPU box: --force-exchange runs the N > 1 step at world size 1 under an `nccl`
+    process group — mi_msm_g1_device_windows leaves the window sums in device memory, all_gather_into_tensor on the DEVICE buffer
+    (RCCL), the pinned D2H copy, mi_g1_fold_windows — and the result is bit-exact.  (The gloo rehearsals never execute this branch.)"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-exchange", "--log-n", "16", "--steps", "3", "--warmup", "1", "--no-secondary",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["bit_exact"] is True
+    assert d["exchange"]["backend"] == "nccl" and d["exchange"]["world_size"] == 1 and d["exchange"]["windows"] == d["config"]["num_windows"]
+    assert d["exchange_ms"] > 0 and d["msm_ms"] > 0
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE sizes

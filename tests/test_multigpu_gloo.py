@@ -64,3 +64,27 @@ def test_two_rank_gloo_allgather_and_fold(tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "GLOO_FOLD_OK" in out.stdout
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher in the command line and no WORLD_SIZE in the environment: bench.py spawns the
+    ranks itself (a child `python -m torch.distributed.run`, started before the parent imports torch or touches a GPU) and relays
+    output and exit code.  There is no GPU here, so the ranks run bench.py's launch probe (BENCH_LAUNCH_PROBE=1: meet over gloo,
+    rank 0 prints one line); the same command without the probe is a `-m gpu` test (tests/test_gpu_msm.py)."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BENCH_LAUNCH_PROBE="1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "3", "--warmup", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d == {"launch_probe": True, "n_gpus": 2, "ranks": [0, 1], "argv": ["--gpus", "2", "--backend", "gloo", "--share-device", "--steps", "3", "--warmup", "1"]}
+    # a rank that fails makes the launcher fail: without a GPU and without the probe every rank exits with bench.py's message
+    env.pop("BENCH_LAUNCH_PROBE")
+    import torch
+    if not torch.cuda.is_available():
+        bad = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert bad.returncode != 0 and "needs an MI355X" in bad.stderr

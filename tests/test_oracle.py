@@ -108,3 +108,84 @@ def test_g2_encoding_oracle_vs_fixtures(o, golden):
     x, y = o.G2_GEN
     psi = (o.F2.mul((x[0], (-x[1]) % o.P), cx), o.F2.mul((y[0], (-y[1]) % o.P), cy))
     assert psi == o.scalar_mul(o.F2, o.G2_GEN, (-0xD201000000010000) % o.R_ORDER)
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_cofactor_clearing_pins_the_group_law(co, o, group):
+    """Points OUTSIDE the prime-order subgroup times the reference-held cofactor (src/g1.rs:42, src/g2.rs:45-54) land INSIDE it, in
+    both oracles: the group law and the scalar path are tied to a constant the reference holds (the generators alone would not
+    notice a formula that is only right on the r-torsion)."""
+    from cofactor_util import H1, H2, off_subgroup_points, h2_pieces, SPLIT_BITS
+
+    F = o.F1 if group == "g1" else o.F2
+    h = H1 if group == "g1" else H2
+    assert h == (o.H1 if group == "g1" else h)
+    for pt in off_subgroup_points(o, group, 2):
+        q = o.scalar_mul(F, pt, h)
+        assert q is not o.INF and o.on_curve(F, q)
+        assert o.scalar_mul(F, q, o.R_ORDER) is o.INF                          # h * P is in the r-torsion ...
+        assert o.scalar_mul(F, o.scalar_mul(F, pt, h - 1), o.R_ORDER) is not o.INF   # ... and it takes exactly h
+        want = o.affine_to_bytes(F, q)
+        base = o.affine_to_bytes(F, pt)
+        if group == "g1":
+            sc = h.to_bytes(32, "little")
+            assert co.to_affine(group, co.msm(group, base, sc, 1, 0, 1)) == want       # C oracle, Pippenger path
+            assert co.to_affine(group, co.msm_naive(group, base, sc, 1)) == want       # C oracle, double-and-add
+        else:
+            # h2 has 507 bits: three pieces below r over the bases P, 2^250 P, 2^500 P
+            bases = b"".join(o.affine_to_bytes(F, o.scalar_mul(F, pt, 1 << (SPLIT_BITS * i))) for i in range(3))
+            sc = b"".join(a.to_bytes(32, "little") for a in h2_pieces())
+            assert co.to_affine(group, co.msm(group, bases, sc, 3, 0, 1)) == want
+            assert co.to_affine(group, co.msm_naive(group, bases, sc, 3)) == want
+        # r * (h P) = infinity in the C oracle as well: r = (r - 1) + 1 over the base h P twice (scalars stay below r)
+        two = want + want
+        sc = (o.R_ORDER - 1).to_bytes(32, "little") + (1).to_bytes(32, "little")
+        assert co.to_affine(group, co.msm(group, two, sc, 2, 0, 1)) == bytes(len(want))
+
+
+def test_c_oracle_normalize_batch(co, o):
+    """orc_g{1,2}_normalize_batch (the restatement behind bench.py's normalize cpu_baseline; CurveGroup::normalize_batch,
+    src/g1.rs:537-543) against the per-point conversion and the Python oracle, infinity included, for several thread splits."""
+    for group, F, gen, jsz in (("g1", o.F1, o.G1_GEN, 144), ("g2", o.F2, o.G2_GEN, 288)):
+        pts = [o.scalar_mul(F, gen, k) for k in (1, 2, 3, 12345, o.R_ORDER - 1)]
+        jac = []
+        for i, p in enumerate(pts):   # non-trivial Z: the projective sum of two multiples, as a Jacobian triple from the oracle
+            X, Y, Z = o.jac_add(F, o.jac_from_aff(F, p), o.jac_double(F, o.jac_from_aff(F, pts[(i + 1) % len(pts)])))
+            assert not F.eq(Z, F.one)
+            jac.append(o._felt_bytes(F, X) + o._felt_bytes(F, Y) + o._felt_bytes(F, Z))
+        jac.insert(2, bytes(jsz))                                    # infinity (Z = 0)
+        blob = b"".join(jac)
+        want = b"".join(co.to_affine(group, j) for j in jac)
+        for threads in (1, 2, 7):
+            assert co.normalize_batch(group, blob, threads) == want
+        assert want[2 * (jsz * 2 // 3):3 * (jsz * 2 // 3)] == bytes(jsz * 2 // 3)
+        k0 = (1 + 2 * 2) % o.R_ORDER
+        assert want[:jsz * 2 // 3] == o.affine_to_bytes(F, o.scalar_mul(F, gen, k0))
+    assert co.normalize_batch("g1", b"", 4) == b""
+
+
+def test_c_oracle_g1_deserialize(co, o, golden):
+    """orc_g1_deserialize_batch (bench.py's deserialize cpu_baseline; src/g1.rs:386-431) against the frozen encoding fixtures and
+    the Python oracle: both subgroup tests (the definition [r] P and the endomorphism form) agree on points inside AND outside the
+    subgroup, malformed encodings and off-curve points get the reference's statuses."""
+    from cofactor_util import off_subgroup_points
+
+    for case in golden["g1_encoding"]:
+        for mode in (0, 1):
+            out, st = co.g1_deserialize_batch(bytes.fromhex(case["bytes"]), case["compressed"], case["validate"], mode, 1)
+            assert st[0] == case["status"], (case["name"], mode)
+            assert out.hex() == (case["affine"] if st[0] == 0 and case["affine"] else bytes(96).hex()), case["name"]
+    # points on the curve but outside the prime-order subgroup: status 3 with validation, accepted without
+    off = off_subgroup_points(o, "g1", 3)
+    enc = b"".join(o.g1_compress(p) for p in off) + o.g1_compress(o.G1_GEN)
+    for mode in (0, 1):
+        out, st = co.g1_deserialize_batch(enc, True, True, mode, 2)
+        assert st == bytes([3, 3, 3, 0]) and out[:288] == bytes(288) and out[288:] == o.affine_to_bytes(o.F1, o.G1_GEN)
+    out, st = co.g1_deserialize_batch(enc, True, False, 0, 1)
+    assert st == bytes(4) and out == b"".join(o.affine_to_bytes(o.F1, p) for p in off + [o.G1_GEN])
+    # a batch against the Python oracle, compressed and uncompressed
+    pts = [o.scalar_mul(o.F1, o.G1_GEN, k) for k in range(1, 30)]
+    for compressed in (True, False):
+        blob = b"".join((o.g1_compress(p) if compressed else o.g1_uncompressed(p)) for p in pts)
+        out, st = co.g1_deserialize_batch(blob, compressed, True, 1, 3)
+        assert st == bytes(len(pts)) and out == b"".join(o.affine_to_bytes(o.F1, p) for p in pts)
