@@ -80,18 +80,16 @@ int mi_msm_init(mi_ctx** out, const int* device_ids, int n_devices) {
             // one persistent host thread per device and lane (nothing is spawned per call); peer access so that a device can read
             // its shard of a scalar vector that lives on another device of the context (xGMI)
             for (int l = 0; l < NLANES; l++) ctx->workers[l].reset(new DeviceWorkers((size_t)n_devices));
-            // peer_ok[a][b]: device a may dereference memory of device b.  Recorded, not assumed: without peer access the shard of
-            // a device-resident scalar vector is staged by a peer copy instead (msm_impl), never read through a faulting pointer
-            ctx->peer_ok.assign((size_t)n_devices * n_devices, 0);
+            // Peer access is ENABLED where the runtime offers it, so that the one hipMemcpyPeerAsync that stages a remote shard of a
+            // device-resident scalar vector (msm_impl) is a direct xGMI DMA; where it is not offered the runtime stages that copy
+            // through the host by itself.  No kernel of this library reads remote memory in place, so nothing else depends on it.
             for (int a = 0; a < n_devices; a++)
                 for (int b = 0; b < n_devices; b++) {
                     int da = ctx->devs[a].dev, db = ctx->devs[b].dev, can = 0;
-                    if (da == db) { ctx->peer_ok[(size_t)a * n_devices + b] = 1; continue; }
+                    if (da == db) continue;
                     if (hipDeviceCanAccessPeer(&can, da, db) == hipSuccess && can) {
                         (void)hipSetDevice(da);
-                        hipError_t e = hipDeviceEnablePeerAccess(db, 0);
-                        if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) ctx->peer_ok[(size_t)a * n_devices + b] = 1;
-                        if (e != hipSuccess) (void)hipGetLastError();   // already enabled (by torch, or a second context): fine
+                        if (hipDeviceEnablePeerAccess(db, 0) != hipSuccess) (void)hipGetLastError();   // already enabled (by torch, or a second context): fine
                     } else {
                         (void)hipGetLastError();
                     }

@@ -200,7 +200,6 @@ struct mi_ctx {
     std::unique_ptr<mi::DeviceWorkers> workers[mi::NLANES];      // multi-device contexts only: one thread per device and lane
     std::unique_ptr<mi::DeviceWorkers> batch_workers;            // mi_msm_*_batch: two persistent job pullers, created on first use
     std::mutex batch_mu;                                         // one batch call at a time drives them
-    std::vector<char> peer_ok;                                   // [a * ndev + b]: device slot a can read memory of device slot b
     std::mutex lane_mu;                                          // lane bookkeeping
     std::condition_variable lane_cv;
     bool lane_busy[mi::NLANES] = {false, false};

@@ -42,6 +42,16 @@ struct CoopF2 {
         Fp v = fp28::fp_select(hi(), fp28::fp_sub<32>(a, pa), a);
         return fp28::fp_mul(u, v);
     }
+    // s^2 - 12 e^2 as ONE fused two-product reduction per lane (see ec::Fp2OpsT::sqr_sub12sqr): 588 multiply-adds where two
+    // squarings and the subtraction's normalisation would take 784 + a multiplication by one
+    static __device__ __forceinline__ E sqr_sub12sqr(const E& s, const E& e) {
+        Fp ps = partner(s), pe = partner(e);
+        Fp u = fp28::fp_select(hi(), fp28::fp_add(s, ps), fp28::fp_add(ps, ps));               // s0 + s1 | 2 s0
+        Fp v = fp28::fp_select(hi(), fp28::fp_sub<32>(s, ps), s);                               // s0 - s1 | s1
+        Fp ue = fp28::fp_select(hi(), fp28::fp_add(e, pe), fp28::fp_add(pe, pe));              // e0 + e1 | 2 e0
+        Fp we = fp28::fp_mul_small<12>(fp28::fp_select(hi(), fp28::fp_sub<4>(pe, e), fp28::fp_neg<4>(e)));   // 12 (e1 - e0) | -12 e1
+        return fp28::fp_mul2add(u, v, ue, we);
+    }
     static __device__ __forceinline__ E mul2add(const E& a, const E& b, const E& c, const E& d) { return fp28::fp_add(mul(a, b), mul(c, d)); }
     static __device__ __forceinline__ E add(const E& a, const E& b) { return fp28::fp_add(a, b); }
     template <int K>

@@ -134,6 +134,14 @@ struct Fp2OpsT {
         }
         return r;
     }
+    // s^2 - 12 e^2 with ONE reduction per component (the doubling step of the Miller loop: Y3 = (B + 3E)^2 - 12 E^2):
+    //   c0 = (s0 + s1)(s0 - s1) + (e0 + e1) * 12 (e1 - e0),   c1 = (2 s0) s1 + (2 e0) * 12 (-e1);   s <= 22p, e < 3p; result < 2p
+    static FP_HD E sqr_sub12sqr(const E& s, const E& e) {
+        E r;
+        r.c0 = m2(fp28::fp_add(s.c0, s.c1), fp28::fp_sub<32>(s.c0, s.c1), fp28::fp_add(e.c0, e.c1), fp28::fp_mul_small<12>(fp28::fp_sub<4>(e.c1, e.c0)));
+        r.c1 = m2(fp28::fp_add(s.c0, s.c0), s.c1, fp28::fp_add(e.c0, e.c0), fp28::fp_mul_small<12>(fp28::fp_neg<4>(e.c1)));
+        return r;
+    }
     static FP_HD E add(const E& a, const E& b) { return E{fp28::fp_add(a.c0, b.c0), fp28::fp_add(a.c1, b.c1)}; }
     template <int K>
     static FP_HD E sub(const E& a, const E& b) { return E{fp28::fp_sub<K>(a.c0, b.c0), fp28::fp_sub<K>(a.c1, b.c1)}; }

@@ -2,6 +2,7 @@
 // in msm_g1.hip and msm_g2.hip.  Replaces crate::gpu::msm + SingleMultiexpKernel::multiexp of the reference
 // (/root/reference/src/gpu.rs:126-241) behind <G{1,2}Projective as VariableBaseMSM>::msm (src/g1.rs:602-632, src/g2.rs:582-612).
 #pragma once
+#include <exception>
 #include "internal.hpp"
 #include "curve_kernels.cuh"
 
@@ -13,7 +14,7 @@ template <> struct HostCurve<msmk::G1C> {
     using J = hostec::G1;
     static constexpr int IDX = 0;
     // accumulate 7.1e9 additions/s, 11 us per addition and lane; quad-lane complete addition ~6 us per step, two waves per SIMD
-    static CurveCost cost() { return CurveCost{msmk::QuadG1::LOG_LL, msmk::QuadG1::LOG_LL, 2048, 7400.0, 11.0, 9.5, 5.6, 60.0, 1ull << 21, 25.0}; }
+    static CurveCost cost() { return CurveCost{msmk::QuadG1::LOG_LL, msmk::QuadG1::LOG_LL, 2048, 7400.0, 14.0, 9.5, 5.6, 110.0, 1ull << 21, 25.0}; }
 };
 template <> struct HostCurve<msmk::G2C> {
     using J = hostec::G2;
@@ -47,8 +48,8 @@ inline int device_of_ptr(const void* p, const char* what) {
     return a.device;
 }
 // Does device slot k of the context read its shard of a scalar vector that lives on device `owner` IN PLACE?  Only when it is the
-// same device.  A remote shard is copied once with hipMemcpyPeerAsync (DMA over xGMI, or through the host where two devices have no
-// peer access — the matrix recorded by mi_msm_init says which) instead of being read twice by the sort's count and scatter passes
+// same device.  A remote shard is copied once with hipMemcpyPeerAsync (a DMA over xGMI where mi_msm_init could enable peer access,
+// staged through the host by the runtime where it could not) instead of being read twice by the sort's count and scatter passes
 // through a peer mapping: half the link traffic, and no kernel ever dereferences a pointer its device may not be able to map.
 inline bool can_read(const mi_ctx* ctx, size_t k, int owner) {
 #if defined(MI_TEST_HOOKS)
@@ -255,6 +256,19 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
     const bool shared = !bases && res.tables > 1;
     const size_t part_max = max_part(ctx);
     if (wo && n > part_max) throw HipFail{"device_windows: n exceeds one pass of the pipeline (2^26 points per device)", false, true};
+    // A failure between enqueueing the chunked H2D copies (copy stream) and the call's final synchronisation must not return while
+    // copies still read the caller's host buffers and write this lane's scratch: drain both streams before the error leaves
+    struct DrainOnFailure {
+        DevState& d;
+        int live = std::uncaught_exceptions();
+        ~DrainOnFailure() {
+            if (std::uncaught_exceptions() > live) {
+                (void)hipStreamSynchronize(d.copy_stream);
+                (void)hipStreamSynchronize(d.stream);
+                (void)hipGetLastError();
+            }
+        }
+    } drain{d};
     for (size_t lo = 0; lo < n; lo += part_max) {   // one pass unless n exceeds the per-pass limit
         const size_t m = std::min(part_max, n - lo);
         HIP_TRY(hipEventRecord(d.ev[0], s));
@@ -459,12 +473,15 @@ int msm_windows_impl(mi_ctx* ctx, const uint8_t* d_scalars, size_t n, unsigned f
         info->window_bits = 0;
         info->num_windows = 0;
         if (n == 0) return MI_OK;
-        (void)device_of_ptr(d_scalars, "d_scalars");
-        (void)device_of_ptr(d_out, "d_out_windows");
+        // the window sums are written by a plain device-to-device copy on this context's device: the buffer must live there; a scalar
+        // vector on another GPU is staged by ONE peer copy, exactly as mi_msm_g1_device does, never read in place
+        const int owner = device_of_ptr(d_scalars, "d_scalars");
+        if (device_of_ptr(d_out, "d_out_windows") != d.dev)
+            return fail(ctx, MI_E_INVALID, "d_out_windows must live on the context's device");
         auto t0 = std::chrono::steady_clock::now();
         WinOut wo;
         wo.d_out = static_cast<uint32_t*>(d_out);
-        (void)device_msm<C>(ctx, d, nullptr, 0, d_scalars, true, n, fmt, -1, &wo);
+        (void)device_msm<C>(ctx, d, nullptr, 0, d_scalars, true, n, fmt, can_read(ctx, 0, owner) ? -1 : owner, &wo);
         *info = wo.info;
         mi_profile pr = d.prof;
         pr.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -80,7 +80,10 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         int merge_levels = 0;
         for (double x = per_bucket; x > T; x *= 0.5) merge_levels++;
         // entries the longest ordinary lane walks serially: bucket loads are Poisson distributed, the kernel ends with the tail
-        const double tail = mean + 3.0 * std::sqrt(mean);
+        // (round 4: the kernel ends with the LONGEST of ~10^5 items — mean + 4.5 sigma, not + 3 — and a lone lane's addition costs 14 us
+        // with its dependent gather, not 11; with the old figures the plan chose c = 13 at 2^14 points, 0.86 ms where c = 16 takes 0.79:
+        // profiles/r04_scan_c_g1_2p14_2p18.jsonl)
+        const double tail = mean + 4.5 * std::sqrt(mean);
         const double item_len = std::min(T, std::max(tail, std::min(per_bucket, T)));
         const double rounds = (double)((p.nchunks + cc.max_chunks - 1) / cc.max_chunks);
         int levels = 0;

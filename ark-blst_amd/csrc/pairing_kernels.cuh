@@ -80,7 +80,13 @@ __global__ void __launch_bounds__(64, 2) k_miller_loop(const uint32_t* __restric
 // or Q at infinity gets the lines (1, 0, 0): f stays 1.
 constexpr int MILLER_LINES = 68;          // 63 doublings + 5 additions for |z| = 0xd201000000010000
 constexpr int MILLER_GROUPS = 10;         // pairs per wave in k_miller_accumulate
-constexpr int LDS_COEFF_WORDS = 36;       // one Fp2 coefficient in LDS: 2 x 16 words + 4 words of padding (bank spread)
+constexpr int LDS_COEFF_WORDS = 36;       // one Fp2 coefficient in LDS (k_fp12_prod): 2 x 16 words + 4 words of padding (bank spread)
+// k_miller_accumulate keeps FIVE values per coefficient f_j = (c0, c1) (round 4): c0 | c1 | s = c0 + c1 | d = c0 - c1 + 4p | d + s.
+// A consumer's Karatsuba operands (a0', a1', a0' + a1') for the term f_j g are (c0, c1, s), or (d, s, d + s) when the index wrapped
+// (times xi = 1 + u: (c0 - c1, c0 + c1)): three LDS reads at computed addresses instead of a subtraction, two additions, their
+// carry passes and two 14-limb selects PER TERM in each of the three lanes that read f_j — the owner forms s, d, d + s once per
+// product (about 420 of the 1415 non-multiply instructions of a line product).
+constexpr int ACC_COEFF_WORDS = 5 * 16 + 4;
 
 using CTower = pairing::Tower<CoopF2>;
 
@@ -105,31 +111,30 @@ struct LineSink {   // where the three coefficients of one line go: [line][pair]
     }
 };
 
-// tangent line at T (scaled by 2YZ) evaluated at P, then T <- 2T (RCB16 Alg. 9, a = 0): 3 S + 7 M.  T <= 6p in, < 4p out.
+// tangent line at T (scaled by 2YZ) evaluated at P, then T <- 2T: the formulas of pairing::Tower::line_dbl (round 4: 4 S + 3 M + one
+// fused difference of squares), ordered so that a coefficient is stored the moment it is computed.  T <= 6p in, < 4p out.
 __device__ __forceinline__ void coop_line_dbl(ec::Proj<CoopF2>& T, const uint32_t* lds_p, const LineSink& out) {
     using F2 = CoopF2;
-    Fp t0 = F2::sqr(T.y);                                                    // Y^2
-    Fp t1 = F2::mul(T.y, T.z);                                               // Y Z
+    Fp B = F2::sqr(T.y);                                                     // Y^2
+    Fp C = F2::sqr(T.z);                                                     // Z^2
+    Fp H = F2::sub<8>(F2::sqr(F2::add(T.y, T.z)), F2::add(B, C));            // 2 Y Z                  < 10p
     {
         Fp yp;
         load_fp16(yp, lds_p + 16);
-        out.put(2, F2::mul_fp(F2::dbl(t1), yp));                             // c4 = 2 Y Z yP
+        out.put(2, F2::mul_fp(H, yp));                                       // c4 = 2 Y Z yP
     }
-    Fp t2 = F2::mul_b3(F2::sqr(T.z));                                        // b3 Z^2 = 3b' Z^2
-    out.put(0, F2::sub<4>(t0, t2));                                          // c0 = Y^2 - 3b' Z^2     < 6p
+    Fp E = F2::mul_b3(C);                                                    // b3 Z^2 = 3b' Z^2
+    out.put(0, F2::sub<4>(B, E));                                            // c0 = Y^2 - 3b' Z^2     < 6p
     {
         Fp nx;
         load_fp16(nx, lds_p);
         out.put(1, F2::mul_fp(F2::mul3(F2::sqr(T.x)), nx));                  // c1 = -3 X^2 xP
     }
     Fp xy = F2::mul(T.x, T.y);
-    Fp z8 = F2::dbl(F2::dbl(F2::dbl(t0)));                                   // 8 Y^2                  < 16p
-    T.z = F2::mul(t1, z8);                                                   // 8 Y^3 Z
-    Fp x3 = F2::mul(t2, z8);
-    Fp d = F2::sub<8>(t0, F2::add(F2::add(t2, t2), t2));                     // Y^2 - 3 b3 Z^2         < 10p
-    Fp y3 = F2::add(t0, t2);                                                 // Y^2 + b3 Z^2           < 4p
-    T.y = F2::add(x3, F2::mul(d, y3));
-    T.x = F2::dbl(F2::mul(d, xy));
+    Fp E3 = F2::mul3(E);                                                     //                        < 6p
+    T.x = F2::dbl(F2::mul(F2::sub<8>(B, E3), xy));                           // 2 XY (B - 3E)          < 4p
+    T.z = F2::mul(F2::dbl(F2::dbl(H)), B);                                   // 4 H B = 8 Y^3 Z        < 2p
+    T.y = F2::sqr_sub12sqr(F2::add(B, E3), E);                               // (B + 3E)^2 - 12 E^2    < 2p
 }
 // line through T and Q (scaled by X - xQ Z) evaluated at P, then T <- T + Q
 __device__ __forceinline__ void coop_line_add(ec::Proj<CoopF2>& T, const uint32_t* lds_q, const uint32_t* lds_p, const LineSink& out) {
@@ -247,7 +252,26 @@ __device__ __forceinline__ void fp2_acc_term(KaraCols& c, const ec::Fp2& a, bool
     Fp a0 = fp28::fp_select(wrapped, a.c0, xa0), a1 = fp28::fp_select(wrapped, a.c1, xa1);
     fp_acc(c.v0, a0, g.c0);
     fp_acc(c.v1, a1, g.c1);
-    fp_acc(c.v2, fp28::fp_add(a0, a1), fp28::fp_add(g.c0, g.c1));
+    fp_acc(c.v2, fp28::fp_add(a0, a1), fp28::fp_add_lazy(g.c0, g.c1));   // g0 + g1 without a carry pass (see fp2_acc_term_pre)
+}
+// the five values of one coefficient (see ACC_COEFF_WORDS); f exact (< 2p per component): s < 4p, d < 6p, d + s < 10p, all N-form
+__device__ __forceinline__ void lds_store_variants(uint32_t* p, const ec::Fp2& f) {
+    const Fp sum = fp28::fp_add(f.c0, f.c1), dif = fp28::fp_sub<4>(f.c0, f.c1);
+    store_fp16(p, f.c0);
+    store_fp16(p + 16, f.c1);
+    store_fp16(p + 32, sum);
+    store_fp16(p + 48, dif);
+    store_fp16(p + 64, fp28::fp_add(dif, sum));
+}
+// cols += f_j * xi^[wrapped] * g with the operands of f_j read ready-made from its five-value LDS record
+__device__ __forceinline__ void fp2_acc_term_pre(KaraCols& c, const uint32_t* rec, bool wrapped, const ec::Fp2& g) {
+    Fp a0, a1, as;
+    load_fp16(a0, rec + (wrapped ? 48 : 0));
+    load_fp16(a1, rec + (wrapped ? 32 : 16));
+    load_fp16(as, rec + (wrapped ? 64 : 32));
+    fp_acc(c.v0, a0, g.c0);
+    fp_acc(c.v1, a1, g.c1);
+    fp_acc(c.v2, as, fp28::fp_add_lazy(g.c0, g.c1));   // no carry pass: limbs <= 2 (2^28 + 64), a V2 column <= the V0 + V1 column bound
 }
 // Montgomery reduction of SIGNED 64-bit columns (|column| < 2^62, value in [0, 2^392 p)): fp28::fp_mont_reduce with arithmetic carries
 __device__ __forceinline__ Fp fp_mont_reduce_signed(int64_t (&c)[2 * fp28::NL]) {
@@ -305,16 +329,16 @@ __device__ __forceinline__ void fp2_acc_term4(uint64_t (&c0)[2 * fp28::NL], uint
 // for m pairs, as blst's miller_loop_n does); out[g] = product of the Miller values of pairs [g m, g m + m).
 __global__ void __launch_bounds__(64, 1) k_miller_accumulate(const uint32_t* __restrict__ lines, uint32_t n, uint32_t m, uint32_t blk,
                                                              uint32_t* __restrict__ out) {
-    __shared__ uint32_t fs[(MILLER_GROUPS + 1) * 6 * LDS_COEFF_WORDS];   // + one dummy group for the idle lanes
+    __shared__ uint32_t fs[(MILLER_GROUPS + 1) * 6 * ACC_COEFF_WORDS];   // + one dummy group for the idle lanes
     const uint32_t lane = threadIdx.x;
     const uint32_t grp = lane / 6, k = lane - grp * 6;                   // lanes 60..63: group 10 (dummy)
     const uint32_t ngroups = (n + m - 1) / m;
     const uint32_t g_idx = blockIdx.x * MILLER_GROUPS + grp;
     const bool valid = grp < MILLER_GROUPS && g_idx < ngroups;
     const uint32_t first = (valid ? g_idx : ngroups - 1) * m;            // idle lanes shadow a real group, write nothing
-    uint32_t* fg = fs + grp * 6 * LDS_COEFF_WORDS;
+    uint32_t* fg = fs + grp * 6 * ACC_COEFF_WORDS;
     ec::Fp2 own = k == 0 ? ec::Fp2Ops::one() : ec::Fp2Ops::zero();
-    lds_store_fp2(fg + k * LDS_COEFF_WORDS, own);
+    lds_store_variants(fg + k * ACC_COEFF_WORDS, own);
     __syncthreads();
     int line = 0;
     // squaring terms of this lane: the i <= j of the pairs i + j = k (mod 6): four of them for even k, three for odd k
@@ -348,20 +372,20 @@ __global__ void __launch_bounds__(64, 1) k_miller_accumulate(const uint32_t* __r
             cols.clear();
             {   // terms at w^0, w^2, w^3: f_j with j = k, k - 2, k - 3 (mod 6), times xi when the index wrapped
                 int j = (int)k;
-                fp2_acc_term(cols, lds_load_fp2(fg + j * LDS_COEFF_WORDS), false, g0);
+                fp2_acc_term_pre(cols, fg + j * ACC_COEFF_WORDS, false, g0);
                 j = (int)k - 2;
                 bool wrapped = j < 0;
                 if (wrapped) j += 6;
-                fp2_acc_term(cols, lds_load_fp2(fg + j * LDS_COEFF_WORDS), wrapped, g1);
+                fp2_acc_term_pre(cols, fg + j * ACC_COEFF_WORDS, wrapped, g1);
                 j = (int)k - 3;
                 wrapped = j < 0;
                 if (wrapped) j += 6;
-                fp2_acc_term(cols, lds_load_fp2(fg + j * LDS_COEFF_WORDS), wrapped, g2);
+                fp2_acc_term_pre(cols, fg + j * ACC_COEFF_WORDS, wrapped, g2);
             }
             ec::Fp2 r = fp2_kara_reduce(cols);
             own = ec::Fp2Ops::select(live, own, r);
             __syncthreads();                                             // every lane has read the old f
-            lds_store_fp2(fg + k * LDS_COEFF_WORDS, own);
+            lds_store_variants(fg + k * ACC_COEFF_WORDS, own);
             __syncthreads();
             g0 = n0; g1 = n1; g2 = n2;
         }
@@ -377,15 +401,15 @@ __global__ void __launch_bounds__(64, 1) k_miller_accumulate(const uint32_t* __r
                 uint32_t i = (sq_tab >> (3 * t)) & 7u;
                 int j = (int)k - (int)i;
                 if (j < 0) j += 6;
-                ec::Fp2 a = lds_load_fp2(fg + i * LDS_COEFF_WORDS);
+                ec::Fp2 a = lds_load_fp2(fg + i * ACC_COEFF_WORDS);
                 ec::Fp2 a2 = ec::Fp2Ops::add(a, a);
                 a = ec::Fp2Ops::select((int)i != j, a, a2);
                 a = ec::Fp2Ops::select(t >= sq_cnt, a, ec::Fp2Ops::zero());          // odd k has three terms only
-                fp2_acc_term(cols, a, i + (uint32_t)j >= 6, lds_load_fp2(fg + j * LDS_COEFF_WORDS));
+                fp2_acc_term(cols, a, i + (uint32_t)j >= 6, lds_load_fp2(fg + j * ACC_COEFF_WORDS));
             }
             own = fp2_kara_reduce(cols);
             __syncthreads();
-            lds_store_fp2(fg + k * LDS_COEFF_WORDS, own);
+            lds_store_variants(fg + k * ACC_COEFF_WORDS, own);
             __syncthreads();
         }
         mul_line();

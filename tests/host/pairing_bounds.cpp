@@ -49,6 +49,11 @@ struct BoundF2 {
         double d = fsub(32, a.c0, a.c1, "Fp2 sqr: a.c1");
         return {mont((a.c0 + a.c1) * d), mont(2 * a.c0 * a.c1)};
     }
+    static E sqr_sub12sqr(const E& s, const E& e) {   // one fused two-product reduction per component (ec.cuh)
+        double d = fsub(32, s.c0, s.c1, "sqr_sub12sqr: s.c1");
+        double w0 = chk_val(12 * fsub(4, e.c1, e.c0, "sqr_sub12sqr: e.c0")), w1 = chk_val(12 * fsub(4, 0, e.c1, "sqr_sub12sqr: e.c1"));
+        return {mont((s.c0 + s.c1) * d + (e.c0 + e.c1) * w0), mont(2 * s.c0 * s.c1 + 2 * e.c0 * w1)};
+    }
     static E mul2add(const E& a, const E& b, const E& c, const E& d) {   // the shared (non-inlined) variant: two reductions per component
         if (b.c1 > 31 || d.c1 > 31) fail("Fp2 mul2add: c1", std::max(b.c1, d.c1), 31);
         return {chk_val(mont(a.c0 * b.c0 + a.c1 * 32.0) + mont(c.c0 * d.c0 + c.c1 * 32.0)),

@@ -545,23 +545,22 @@ def test_cofactor_clearing_through_the_hip_path(ctx, co, o, group):
 
 def test_call_abi_reproducer():
     """The compiler issue behind round 3's "codegen-dependent miscompares" (csrc/Makefile): tools/call_abi/repro_tower.hip
-    — the test-only single-lane Miller loop's shape: a kernel that keeps the point and the line state across ~40 calls of
-    out-of-line tower functions per round — built twice from the shipped headers.  With IPRA off it must agree with the host run
-    of the same source on all 64 lanes; with the compiler's defaults (IPRA + VGPR spills into AGPRs) it is EXPECTED to differ while
-    the compiler issue exists, which is why no shipped kernel mixes calls and AGPRs (tests/test_cabi.py).  Should a later compiler
-    fix it, this test says so instead of failing."""
+    — the test-only single-lane Miller loop's shape: a 512-register kernel that keeps the point and the line state across ~40 calls
+    of out-of-line tower functions per round — built twice from the shipped headers.  With the library's flags (VGPR spill slots are
+    NOT turned into AGPRs) it must agree with the host run of the same source on all 64 lanes; with the compiler's default it is
+    EXPECTED to differ while the compiler issue exists.  Should a later compiler fix it, this test says so instead of failing."""
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(root, "ark-blst_amd", "lib")
-    good = subprocess.run([os.path.join(lib, "repro_call_abi_noipra")], capture_output=True, text=True, timeout=300)
+    good = subprocess.run([os.path.join(lib, "repro_call_abi")], capture_output=True, text=True, timeout=300)
     assert good.returncode == 0 and "miller loop, 63 rounds: 0 of 64" in good.stdout, good.stdout[-1500:] + good.stderr[-500:]
-    dflt = subprocess.run([os.path.join(lib, "repro_call_abi")], capture_output=True, text=True, timeout=300)
+    dflt = subprocess.run([os.path.join(lib, "repro_call_abi_compiler_default")], capture_output=True, text=True, timeout=300)
     # the isolated tower functions are right either way; only the loop kernel is affected
     for piece in ("conj12", "sqr12", "mul_by_014", "chain"):
         assert f"{piece}: 0 of 64" in dflt.stdout, dflt.stdout[-1500:]
     if dflt.returncode == 0:
-        print("NOTE: repro_call_abi passes with default flags: the compiler issue is gone on this toolchain")
+        print("NOTE: the reproducer passes with the compiler's default flags: the compiler issue is gone on this toolchain")
     else:
         assert "miller loop, 1 rounds: 64 of 64" in dflt.stdout, dflt.stdout[-1500:]
 

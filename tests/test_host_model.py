@@ -129,5 +129,10 @@ def test_karatsuba_column_and_bias_bounds():
         assert (v0 + bias) // R + p < 2 * p and cross // R + p < 2 * p, name   # outputs < 2p, as every consumer assumes
         col = terms * 14 * prod                                   # one column of one column set
         assert col + (1 << 52) + 14 * prod < 1 << 63, name        # |V0 - V1| + bias column + the reduction's 14 m_i p_j
-        assert 2 * col + 14 * prod + (1 << 36) < 1 << 63, name    # |V2 - (V0 + V1)| + reduction terms + carry
+        # |V2 - (V0 + V1)| + reduction terms + carry.  Round 4: g0 + g1 enters V2 WITHOUT a carry pass (limbs <= 2 limb), so a V2
+        # column is <= terms * 14 * limb * 2 limb = 2 col, the same bound as the V0 + V1 column; both are non-negative, so the
+        # difference is bounded by the larger one
+        col2 = terms * 14 * limb * (2 * limb)
+        assert col2 == 2 * col
+        assert max(col2, 2 * col) + 14 * prod + (1 << 36) < 1 << 63, name
     assert 2 * 6 * 14 * prod > 1 << 63                            # six terms: why the tree does not use this form
