@@ -39,15 +39,14 @@ __device__ __forceinline__ bool fp_equal(const Fp& a, const Fp& b) {  // a == b 
     return fp28::fp_is_zero_any(fp28::fp_sub<16>(a, b));
 }
 
-// r = [|z|] p on the complete formulas (63 doublings + 5 additions)
+// r = [|z|] p: 63 exception-free doublings (ec::proj_dbl, multiplier inlined: 3 S + 4 M + one fused pair instead of the 12 M of
+// adding a point to itself — round 4) + 5 complete additions through the shared body
 __device__ __noinline__ void g1_mul_z(ec::Proj<ec::FpOps>& r, const ec::Proj<ec::FpOps>& p) {
-    using F = ec::FpOps;
     r = p;
 #pragma unroll 1
     for (int bit = 62; bit >= 0; bit--) {
-        ec::Proj<F> c = r;
-        ec::proj_add<F>(r, c);
-        if ((fp28c::Z_ABS >> bit) & 1) ec::proj_add<F>(r, p);
+        ec::proj_dbl<ec::FpOpsInlinePS>(r);
+        if ((fp28c::Z_ABS >> bit) & 1) add_inplace(r, p);
     }
 }
 
@@ -89,9 +88,9 @@ __global__ void __launch_bounds__(256, 2) k_deserialize_g1(const uint8_t* __rest
             // y = rhs^((p+1)/4): left-to-right square and multiply over the 379-bit exponent
             Fp acc = rhs;
 #pragma unroll 1
-            for (int bit = 377; bit >= 0; bit--) {  // top set bit of (p+1)/4 is bit 378
-                acc = fp28::fp_sqr_call(acc);
-                if ((fp28c::SQRT_EXP32[bit >> 5] >> (bit & 31)) & 1) acc = fp28::fp_mul_call(acc, rhs);
+            for (int bit = 377; bit >= 0; bit--) {  // top set bit of (p+1)/4 is bit 378; multiplier inlined (two bodies): no call, no scratch copy of rhs per step
+                acc = fp28::fp_sqr(acc);
+                if ((fp28c::SQRT_EXP32[bit >> 5] >> (bit & 31)) & 1) acc = fp28::fp_mul(acc, rhs);
             }
             y = acc;
             on_curve = fp_equal(fp28::fp_sqr_call(y), rhs);
@@ -194,8 +193,7 @@ __device__ __noinline__ void g2_mul_z(ec::Proj<G2F>& r, const ec::Proj<G2F>& p) 
     r = p;
 #pragma unroll 1
     for (int bit = 62; bit >= 0; bit--) {
-        ec::Proj<G2F> c = r;
-        ec::proj_add<G2F>(r, c);
+        ec::proj_dbl<G2F>(r);   // 3 S + 4 M + one fused pair over Fp2 (22 field multiplications) instead of the 36 of a complete addition
         if ((fp28c::Z_ABS >> bit) & 1) ec::proj_add<G2F>(r, p);
     }
 }

@@ -60,6 +60,12 @@ struct BoundFp {
     template <int K> static E neg(const E& a) { return sub<K>(zero(), a); }
     static E mul3(const E& a) { limb(3 * a.l); return {3 * a.v, NFORM}; }
     static E mul_b3(const E& a) { limb(12 * a.l); return {12 * a.v, NFORM}; }
+    static E mul_b3_red(const E& a) { return mul(a, E{1, EXACT}); }                       // times the constant 12 (< p) as a field product
+    static E sqr_sub12sqr(const E& s, const E& e) {                                       // one fused reduction (FpOpsInlinePS)
+        E w = neg<4>(e);
+        limb(12 * w.l);
+        return reduce(s.v * s.v + e.v * 12 * w.v, s.l * s.l + e.l * NFORM);
+    }
     static bool is_zero_2p(const E& a) { if (a.v > 2) fail("is_zero_2p operand", a.v, 2); return false; }
     static E select(bool, const E& a, const E& b) { return {std::max(a.v, b.v), std::max(a.l, b.l)}; }
     static bool limbs_all_zero(const E&) { return false; }
@@ -120,6 +126,11 @@ struct BoundFp2 {
     static E norm(const E& a) { return a; }
     static E mul3(const E& a) { return {val(3 * a.c0), val(3 * a.c1)}; }
     static E mul_b3(const E& a) { return mul(a, E{1, 1}); }   // by the constant (12, 12), each component < p
+    static E mul_b3_red(const E& a) { return mul_b3(a); }
+    static E sqr_sub12sqr(const E& s, const E& e) {            // ec::Fp2OpsT::sqr_sub12sqr: one fused two-product reduction per component
+        double d = fsub(32, s.c0, s.c1), w0 = val(12 * fsub(4, e.c1, e.c0)), w1 = val(12 * fsub(4, 0, e.c1));
+        return {red2((s.c0 + s.c1) * d + (e.c0 + e.c1) * w0), red2(2 * s.c0 * s.c1 + 2 * e.c0 * w1)};
+    }
     static bool is_zero_2p(const E& a) { if (a.c0 > 2 || a.c1 > 2) fail("is_zero_2p operand", std::max(a.c0, a.c1), 2); return false; }
     static E select(bool, const E& a, const E& b) { return {std::max(a.c0, b.c0), std::max(a.c1, b.c1)}; }
     static bool limbs_all_zero(const E&) { return false; }
@@ -153,6 +164,15 @@ static void check_g2(const char* tag) {
         pinv = nx;
         if (fix) break;
         if (it == 63) fail("G2 proj_add invariant did not converge", it, 63);
+    }
+    {   // ec::proj_dbl (round 4: the subgroup-test ladders of the point decoder alternate it with proj_add): closed under both
+        ec::Proj<F> d = pinv;
+        for (int it = 0; it < 4; it++) {
+            ec::proj_dbl<F>(d);
+            ec::Proj<F> t = d;
+            ec::proj_add<F>(t, pinv);
+            d = ec::Proj<F>{mx(d.x, t.x), mx(d.y, t.y), mx(d.z, t.z)};
+        }
     }
     printf("%s: xyzz_madd X < %.0fp, Y < %.0fp; proj_add X < %.0fp, Y < %.0fp, Z < %.0fp\n", tag, std::max(inv.x.c0, inv.x.c1),
            std::max(inv.y.c0, inv.y.c1), std::max(pinv.x.c0, pinv.x.c1), std::max(pinv.y.c0, pinv.y.c1), std::max(pinv.z.c0, pinv.z.c1));
@@ -189,6 +209,16 @@ int main() {
         if (it == 63) fail("proj_add invariant did not converge", it, 63);
     }
     printf("proj_add invariant: X < %.0fp, Y < %.0fp, Z < %.0fp\n", pinv.x.v, pinv.y.v, pinv.z.v);
+    {   // ec::proj_dbl alternating with proj_add (the point decoder's subgroup-test ladders, round 4)
+        ec::Proj<F> d = pinv;
+        for (int it = 0; it < 4; it++) {
+            ec::proj_dbl<F>(d);
+            ec::Proj<F> t = d;
+            ec::proj_add<F>(t, pinv);
+            d = ec::Proj<F>{mx(d.x, t.x), mx(d.y, t.y), mx(d.z, t.z)};
+        }
+        printf("proj_dbl / proj_add ladder: X < %.0fp, Y < %.0fp, Z < %.0fp\n", d.x.v, d.y.v, d.z.v);
+    }
     // --- G2: hot loop on the inlined Fp2 variant, everything else on the shared-call variant (msm_kernels.cuh: G2C)
     check_g2<BoundFp2<true>, BoundFp2<false>>("G2");
     printf("msm bounds OK: largest product %.0f p^2 (limit %.0f), largest column sum 2^%.2f (limit 2^%.2f), largest limb 2^%.2f\n",
