@@ -278,16 +278,14 @@ FP_HD Fp fp_mul4add(const Fp& a, const Fp& b, const Fp& c2, const Fp& d, const F
     });
 }
 
-// The shared multiplier instance.  The out-of-line bodies keep the operand-scanning form: register pressure is no concern
-// inside a function of its own, and with product-scanning bodies behind these by-value signatures the test-only single-lane
-// Miller kernel (4 KB of scratch per lane, ~10^3 calls) stopped agreeing with the production path on the GPU while the same
-// source agrees with the oracle on the host (tests/host/pairing_host_check.cpp).  Bisected on the GPU: fp_mul_call alone triggers it
-// (fp_sqr_call and fp_mul2add_call with product-scanning bodies pass); in that translation unit the function receives its second
-// operand through a scratch pointer and starts multiplying while the loads are in flight.  Not root-caused beyond that, so the
-// bodies that six soak seeds have exercised stay as they were.
-// On the device this is a REAL function (by-value args travel in v0..v27, the
-// result in v0..v13): one ~4.5 KB body per kernel instead of one per use keeps bucket kernels inside the
-// 64 KB instruction cache (see ec.cuh).  On the host it is plain inline code.
+// The shared multiplier instance.  The out-of-line bodies keep the operand-scanning form (register pressure is no concern inside a
+// function of its own).  Round 3 saw the test-only single-lane Miller kernel disagree with the production path when this body was the
+// product-scanning one; round 4 pinned that on a code-generation defect of the compiler that has nothing to do with this function's body
+// (the same kernel shape fails with the operand-scanning body too; tools/call_abi/README.md) and fenced it off in the build
+// (csrc/Makefile: VGPR spill slots are not turned into AGPRs, kernels with calls are capped at 256 registers).
+// On the device this is a REAL function: the first operand travels in v0..v13, the second by reference to a scratch copy (the AMDGPU
+// ABI passes at most 16 registers of aggregates directly), the result in v0..v13: one ~4.5 KB body per kernel instead of one per
+// use keeps bucket kernels inside the 64 KB instruction cache (see ec.cuh).  On the host it is plain inline code.
 #if defined(__HIP_DEVICE_COMPILE__)
 #if defined(MI_CALL_PS)   // reproducer switch (tools/call_abi/): the product-scanning body behind the by-value signature
 static __device__ __noinline__ Fp fp_mul_call(Fp a, Fp b) { return fp_mul(a, b); }
