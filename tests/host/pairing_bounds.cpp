@@ -92,8 +92,8 @@ int main() {
     T::E12 g = T::mul12(f, f);
     T::E12 e = T::final_exp(g);
     double m = 0;
-    const B2* c = &e.c0.c0;
-    for (int i = 0; i < 6; i++) m = std::max(m, std::max(c[i].c0, c[i].c1));
+    const B2* c[6] = {&e.c0.c0, &e.c0.c1, &e.c0.c2, &e.c1.c0, &e.c1.c1, &e.c1.c2};
+    for (int i = 0; i < 6; i++) m = std::max(m, std::max(c[i]->c0, c[i]->c1));
     printf("pairing bounds OK: largest multiplier input %.0f p^2 (limit %.0f), largest value %.0f p, outputs < %.0f p\n", g_max_mul,
            LIMIT, g_max_val, m);
     return 0;

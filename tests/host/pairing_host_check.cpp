@@ -19,17 +19,17 @@ static void store_fp(uint8_t* p, const Fp& a) {
     memcpy(p, w, 48);
 }
 static ec::Fp2 load_fp2(const uint8_t* p) { return ec::Fp2{load_fp(p), load_fp(p + 48)}; }
-static T::E12 load_fp12(const uint8_t* p) {
+static T::E12 load_fp12(const uint8_t* p) {   // member by member (no pointer walk across struct members)
     T::E12 r;
-    ec::Fp2* c = &r.c0.c0;
-    for (int i = 0; i < 6; i++) c[i] = load_fp2(p + 96 * i);
+    ec::Fp2* c[6] = {&r.c0.c0, &r.c0.c1, &r.c0.c2, &r.c1.c0, &r.c1.c1, &r.c1.c2};
+    for (int i = 0; i < 6; i++) *c[i] = load_fp2(p + 96 * i);
     return r;
 }
 static void store_fp12(uint8_t* p, const T::E12& a) {
-    const ec::Fp2* c = &a.c0.c0;
+    const ec::Fp2* c[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
     for (int i = 0; i < 6; i++) {
-        store_fp(p + 96 * i, c[i].c0);
-        store_fp(p + 96 * i + 48, c[i].c1);
+        store_fp(p + 96 * i, c[i]->c0);
+        store_fp(p + 96 * i + 48, c[i]->c1);
     }
 }
 

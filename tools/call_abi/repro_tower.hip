@@ -11,21 +11,23 @@
 using T = pairing::Tower<pairing::PF2>;
 using E12 = T::E12;
 static __host__ __device__ E12 make(uint32_t seed) {   // pseudo-random N-form limbs < 2^28 (values < 2^392: legal multiplier input < ~50p? no: keep < 2p)
-    E12 r;
-    fp28::Fp* c = &r.c0.c0.c0;
+    E12 r;   // the twelve Fp components member by member (no pointer walk across struct members: the source is to be beyond reproach)
+    fp28::Fp* c[12] = {&r.c0.c0.c0, &r.c0.c0.c1, &r.c0.c1.c0, &r.c0.c1.c1, &r.c0.c2.c0, &r.c0.c2.c1,
+                       &r.c1.c0.c0, &r.c1.c0.c1, &r.c1.c1.c0, &r.c1.c1.c1, &r.c1.c2.c0, &r.c1.c2.c1};
     uint64_t s = seed * 0x9E3779B97F4A7C15ull + 12345;
     for (int i = 0; i < 12; i++)
         for (int k = 0; k < fp28::NL; k++) {
             s = s * 6364136223846793005ull + 1442695040888963407ull;
-            c[i].l[k] = (uint32_t)(s >> 36) & (k == fp28::NL - 1 ? 0xFFFFu : fp28::MASK);   // top limb small: value < 2^380 < p
+            c[i]->l[k] = (uint32_t)(s >> 36) & (k == fp28::NL - 1 ? 0xFFFFu : fp28::MASK);   // top limb small: value < 2^380 < p
         }
     return r;
 }
 static __host__ __device__ uint64_t sum(const E12& a) {
-    const fp28::Fp* c = &a.c0.c0.c0;
+    const fp28::Fp* c[12] = {&a.c0.c0.c0, &a.c0.c0.c1, &a.c0.c1.c0, &a.c0.c1.c1, &a.c0.c2.c0, &a.c0.c2.c1,
+                             &a.c1.c0.c0, &a.c1.c0.c1, &a.c1.c1.c0, &a.c1.c1.c1, &a.c1.c2.c0, &a.c1.c2.c1};
     uint64_t h = 1469598103934665603ull;
     for (int i = 0; i < 12; i++)
-        for (int k = 0; k < fp28::NL; k++) h = (h ^ c[i].l[k]) * 1099511628211ull;
+        for (int k = 0; k < fp28::NL; k++) h = (h ^ c[i]->l[k]) * 1099511628211ull;
     return h;
 }
 __global__ void k_conj(uint64_t* out) { E12 f = make(threadIdx.x); out[threadIdx.x] = sum(T::conj12(f)); }
