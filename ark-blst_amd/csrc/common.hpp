@@ -50,7 +50,7 @@ extern std::atomic<int> g_fail_allocs;   // > 0: that many upcoming DevBuf::ensu
 #endif
 
 struct Plan {
-    uint32_t c, nwin;     // window bits, digit windows = ceil(256 / c)
+    uint32_t c, nwin;     // window bits, digit windows = ceil(255 / c)
     uint32_t bwin;        // bucket sets: nwin, or 1 when all windows share one (precomputed tables)
     uint32_t nb, logL, chunks_per_win, logT, lo_bits;
     uint32_t cls_shift;   // log2 of the width of a length class of the schedule (follows the typical item, not T)

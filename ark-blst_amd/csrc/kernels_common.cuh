@@ -169,7 +169,12 @@ __device__ __forceinline__ void fr_from_mont(uint32_t (&s)[8]) {
     for (int k = 0; k < 8; k++) s[k] = ge ? d[k] : t[k];
 }
 
-__device__ __forceinline__ void load_scalar(uint32_t (&s)[8], const uint32_t* scalars, uint32_t i, unsigned fmt) {
+// Returns `flip`: the canonical scalar was above (r - 1) / 2 and has been replaced by r - s — the caller inverts the sign of every
+// digit (s P = (r - s)(-P) on the prime-order subgroup, and negating a point is free: NEGATION_IS_CHEAP, src/g1.rs:595).  Round 4:
+// the scalars the recoding sees are then below 2^254, so ceil(255 / c) windows always suffice and the signed recoding never carries
+// out of the top window — for c = 15 and c = 17 (the divisors of 255) that removes the extra window whose single bucket collected
+// a carry from 45 % of the points (a heavy bucket, one merge launch per tree level).
+__device__ __forceinline__ bool load_scalar(uint32_t (&s)[8], const uint32_t* scalars, uint32_t i, unsigned fmt) {
     const uint4* q = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
     uint4 a = q[0], b = q[1];
     s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
@@ -192,6 +197,28 @@ __device__ __forceinline__ void load_scalar(uint32_t (&s)[8], const uint32_t* sc
             for (int k = 0; k < 8; k++) s[k] = borrow ? s[k] : d[k];
         }
     }
+    // s > (r - 1) / 2  <=>  2 s > r - 1  <=>  r - s < s ... decided on d = r - s: flip when d < s
+    uint32_t d[8];
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint64_t v = (uint64_t)fp28c::FR_MOD[k] - s[k] - borrow;
+        d[k] = (uint32_t)v;
+        borrow = (v >> 32) & 1;
+    }
+    uint64_t lt = 0;   // d < s ?
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint64_t v = (uint64_t)d[k] - s[k] - lt;
+        lt = (v >> 32) & 1;
+    }
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) any |= s[k];
+    const bool flip = lt != 0 && any != 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = flip ? d[k] : s[k];
+    return flip;
 }
 
 // c-bit field starting at bit `off` of a 256-bit little-endian integer (zero beyond bit 255)
@@ -210,14 +237,14 @@ __device__ __forceinline__ uint32_t scalar_bits(const uint32_t (&s)[8], uint32_t
 // Signed-digit recoding shared by the histogram and scatter passes.  Calls f(window, bucket, negative) for every
 // non-zero digit; bucket = |d| - 1 in [0, 2^(c-1)).
 template <class Fn>
-__device__ __forceinline__ void for_each_digit(const uint32_t (&s)[8], uint32_t c, uint32_t nwin, Fn f) {
+__device__ __forceinline__ void for_each_digit(const uint32_t (&s)[8], bool flip, uint32_t c, uint32_t nwin, Fn f) {
     uint32_t carry = 0, half = 1u << (c - 1);
     for (uint32_t w = 0; w < nwin; w++) {
         uint32_t raw = scalar_bits(s, w * c, c) + carry;
         bool neg = raw > half;
         carry = neg ? 1u : 0u;
         uint32_t mag = neg ? (1u << c) - raw : raw;
-        if (mag != 0) f(w, mag - 1, neg);
+        if (mag != 0) f(w, mag - 1, neg != flip);
     }
 }
 
@@ -225,8 +252,8 @@ __device__ __forceinline__ void for_each_digit(const uint32_t (&s)[8], uint32_t 
 // becomes one or two shifts on statically indexed words (the runtime version spends 16 selects per window), and
 // windows outside [w0, w1) cost only their carry.  k_coarse is instantiated for c = 7..22.
 template <int CB, class Fn>
-__device__ __forceinline__ void for_each_digit_static(const uint32_t (&s)[8], uint32_t w0, uint32_t w1, Fn f) {
-    constexpr uint32_t NW = (256 + CB - 1) / CB, HALF = 1u << (CB - 1), MASKC = (1u << CB) - 1u;
+__device__ __forceinline__ void for_each_digit_static(const uint32_t (&s)[8], bool flip, uint32_t w0, uint32_t w1, Fn f) {
+    constexpr uint32_t NW = (255 + CB - 1) / CB, HALF = 1u << (CB - 1), MASKC = (1u << CB) - 1u;   // s < 2^254 (load_scalar): no carry out of window NW - 1
     uint32_t carry = 0;
 #pragma unroll
     for (uint32_t w = 0; w < NW; w++) {
@@ -238,7 +265,7 @@ __device__ __forceinline__ void for_each_digit_static(const uint32_t (&s)[8], ui
         bool neg = raw > HALF;
         carry = neg ? 1u : 0u;
         uint32_t mag = neg ? (1u << CB) - raw : raw;
-        if (w >= w0 && w < w1 && mag != 0) f(w, mag - 1, neg);
+        if (w >= w0 && w < w1 && mag != 0) f(w, mag - 1, neg != flip);
     }
 }
 

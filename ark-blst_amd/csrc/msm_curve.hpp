@@ -323,7 +323,7 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
     return total;
 }
 
-// Resident base set.  precompute_c == 0: plain bases.  Otherwise W = ceil(256 / c) tables T_j[i] = 2^(c j) P_i (affine, device
+// Resident base set.  precompute_c == 0: plain bases.  Otherwise W = ceil(255 / c) tables T_j[i] = 2^(c j) P_i (affine, device
 // form): every window of a later MSM then shares ONE bucket set (no per-window reduce, no Horner doublings) and c can be larger.
 template <class C>
 void build_resident(mi_ctx* ctx, DevState& d, Resident& res, const uint8_t* bases, size_t n, unsigned precompute_c) {
@@ -337,7 +337,7 @@ void build_resident(mi_ctx* ctx, DevState& d, Resident& res, const uint8_t* base
         // c == 0: no window size fits the entry encoding (n x windows > 2^30 entries, i.e. more than ~9e7 points per device)
         if (c < 7 || c > 22 || make_plan(n, c, HostCurve<C>::cost(), true, n).c == 0)
             throw HipFail{"window_bits not usable for precomputed tables of this size", false, true};
-        W = (256 + c - 1) / c;
+        W = (255 + c - 1) / c;
     }
     res.buf.ensure_fit(n * W * PTB);
     res.flags.ensure(n);

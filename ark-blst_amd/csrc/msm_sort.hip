@@ -18,7 +18,7 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         if (forced_c && c != forced_c) continue;
         Plan p{};
         p.c = c;
-        p.nwin = (256 + c - 1) / c;
+        p.nwin = (255 + c - 1) / c;   // the digit kernels recode min(s, r - s) < 2^254 (load_scalar): ceil(255 / c) windows, no carry out of the top one
         // sort geometry: lo bits share a 32-bit entry with the point index and the sign; the coarse bins of one
         // window must fit the LDS counter array
         uint32_t idx_bits = 1;
@@ -59,11 +59,11 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
             p.chunks_per_win = (p.nb + p.serial_L - 1) / p.serial_L;
         }
         p.nchunks = (uint64_t)p.chunks_per_win * p.bwin;
-        // The top window holds only 255 - c (nwin - 1) significant bits: its n entries share 2^top_bits buckets (on top of the
+        // The top window holds only 254 - c (nwin - 1) significant bits: its n entries share 2^top_bits buckets (on top of the
         // others' entries when all windows share one bucket set)
         const double entries = (double)n * p.nwin;
         double mean = entries / (double)p.nbuckets;
-        int top_bits = std::max(0, std::min<int>(255 - (int)c * ((int)p.nwin - 1), (int)c - 1));
+        int top_bits = std::max(0, std::min<int>(254 - (int)c * ((int)p.nwin - 1), (int)c - 1));
         double per_bucket = (double)n / (double)(1u << top_bits) + (shared ? mean : 0.0);
         // work-item size: twice the mean bucket load (uniform scalars then never split), at least 32 entries; the fuller buckets
         // of the top window count as the mean while they are within 4x of it (splitting them would cost a merge launch for
@@ -74,7 +74,7 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         // ... and an item may be as long as a lane walks in a fifth of the kernel's time anyway: at 2^24 points (c = 20) the top window's
         // 512-entry buckets then stay whole (8 items each and three merge launches, 0.5 ms, for nothing: the kernel runs 30 ms)
         p.cls_shift = p.logT > 6 ? p.logT - 6 : 0;
-        const double walk = 0.2 * ((entries + 1.4 * (double)p.nbuckets) / cc.add_per_us) / cc.lane_add_us;
+        const double walk = 0.2 * ((entries + 0.2 * (double)p.nbuckets) / cc.add_per_us) / cc.lane_add_us;
         while (p.logT < 20 && (double)(2u << p.logT) <= walk) p.logT++;
         const double T = (double)(1u << p.logT);
         int merge_levels = 0;
@@ -95,8 +95,14 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         const double comb_chain = (2.0 * cc.comb_log_ll + 1.0) * cc.comb_step_us;
         const double comb_us = std::max(1, levels) * (comb_chain + 8.0) +
                                std::max(0.0, std::ceil((double)(p.nchunks >> cc.comb_log_ll) / 2048.0) - 1.0) * comb_chain;
-        // accumulate: every work item also pays ~1.4 additions' worth of set-up and XYZZ -> projective conversion
-        const double acc_adds = entries + 1.4 * (double)p.nbuckets;
+        // accumulate: the first entry of an item only initialises the running sum (no addition), every item pays ~1.2 additions' worth of
+        // dependent index loads, XYZZ -> projective conversion and store; with few work items the kernel's time is a whole number of
+        // rounds of 2048 wave slots and the ragged last round counts (round 4: refitted on profiles/r04_scan_c_g1_2p14_2p23_signfold.jsonl —
+        // the old "+ 1.4 per bucket" made c = 15 look 15 % cheaper than c = 16 at 2^16 points where the two measure the same)
+        const double nonempty = (double)p.nbuckets * (1.0 - std::exp(-mean));
+        double acc_adds = entries - nonempty + 1.2 * (double)p.nbuckets;
+        const double wave_rounds = (double)p.nbuckets / 64.0 / (double)cc.max_chunks;
+        if (wave_rounds < 4.0) acc_adds *= 1.0 + 0.5 * (std::ceil(wave_rounds) - wave_rounds) / std::max(wave_rounds, 0.25);
         double cost = std::max(acc_adds / cc.add_per_us, item_len * cc.lane_add_us) + merge_levels * cc.merge_us + reduce_us + comb_us +
                       entries / 41000.0 + (double)p.nbuckets / 1e4 + (shared ? 20.0 : 100.0);
         if (cost < best_cost) {

@@ -52,8 +52,8 @@ __global__ void __launch_bounds__(1024) k_coarse(const uint32_t* __restrict__ sc
     for (uint32_t i = p0 + t; i < p1; i += nt) {
         if (inf_flags[i] != 0) continue;  // infinity base: contributes nothing
         uint32_t s[8];
-        load_scalar(s, scalars, i, g.fmt);
-        for_each_digit_static<CB>(s, w0, w1, [&](uint32_t w, uint32_t b, bool neg) {
+        const bool flip = load_scalar(s, scalars, i, g.fmt);
+        for_each_digit_static<CB>(s, flip, w0, w1, [&](uint32_t w, uint32_t b, bool neg) {
             uint32_t k = (g.shared ? 0u : (w - w0) * g.H) + (b >> g.lo_bits);
             uint32_t pos = atomicAdd(&cnt[k], 1u);
             uint32_t idx = g.shared ? w * g.stride + i : i;
@@ -103,8 +103,8 @@ __global__ void __launch_bounds__(512) k_coarse_staged(const uint32_t* __restric
     for (uint32_t i = p0 + t; i < p1; i += nt) {
         if (inf_flags[i] != 0) continue;
         uint32_t s[8];
-        load_scalar(s, scalars, i, g.fmt);
-        for_each_digit_static<CB>(s, w0, w1, [&](uint32_t w, uint32_t b, bool neg) {
+        const bool flip = load_scalar(s, scalars, i, g.fmt);
+        for_each_digit_static<CB>(s, flip, w0, w1, [&](uint32_t w, uint32_t b, bool neg) {
             uint32_t k = (w - w0) * g.H + (b >> g.lo_bits);
             uint32_t pos = atomicAdd(&cur[k], 1u);
             stage[pos] = (i << (g.lo_bits + 1)) | ((neg ? 1u : 0u) << g.lo_bits) | (b & lo_mask);
@@ -339,8 +339,8 @@ __global__ void __launch_bounds__(1024) k_coarseA(const uint32_t* __restrict__ s
     for (uint32_t i = p0 + t; i < p1; i += nt) {
         if (inf_flags[i] != 0) continue;
         uint32_t s[8];
-        load_scalar(s, scalars, i, g.fmt);
-        for_each_digit_static<CB>(s, 0, g.nwin, [&](uint32_t w, uint32_t b, bool neg) {
+        const bool flip = load_scalar(s, scalars, i, g.fmt);
+        for_each_digit_static<CB>(s, flip, 0, g.nwin, [&](uint32_t w, uint32_t b, bool neg) {
             uint32_t pos = atomicAdd(&cnt[w * A_BINS + (b >> REM)], 1u);
             if (SCATTER) coarseA[pos] = make_uint2(i, ((neg ? 1u : 0u) << 31) | (b & ((1u << REM) - 1u)));
         });

@@ -77,7 +77,7 @@ typedef struct {
     double host_fold_ms;    /* CPU tail: Horner fold over the window sums, one thread */
     double total_ms;        /* wall time of the call */
     uint32_t window_bits;   /* c */
-    uint32_t num_windows;   /* ceil(256 / c) */
+    uint32_t num_windows;   /* ceil(255 / c): the digit kernels recode min(s, r - s) < 2^254 with the sign folded into the digits */
     uint64_t n;             /* points in the call */
     uint64_t accumulate_adds; /* mixed additions executed by the accumulate kernel */
     uint32_t work_items;      /* lanes of the accumulate kernel: buckets, heavy ones split into chunks */
@@ -97,7 +97,7 @@ int mi_msm_num_devices(const mi_ctx *ctx);
 int mi_msm_g1_set_bases(mi_ctx *ctx, const mi_g1_affine *bases, size_t n);
 int mi_msm_g2_set_bases(mi_ctx *ctx, const mi_g2_affine *bases, size_t n);
 
-/* Opt-in variant for a long-lived SRS: besides the bases, keep W = ceil(256 / c) tables T_j[i] = 2^(c j) * bases[i] resident
+/* Opt-in variant for a long-lived SRS: besides the bases, keep W = ceil(255 / c) tables T_j[i] = 2^(c j) * bases[i] resident
  * (W x the memory, built once on the GPU: c doublings per point and table plus one batch inversion).  Every window of a later
  * MSM over the resident set then feeds ONE bucket set: no per-window bucket reduction, no Horner doublings, and c can be
  * larger (c = 20 at 2^20 points: 13 additions per point instead of 16).  window_bits = 0 lets the time model choose c.
@@ -108,6 +108,9 @@ int mi_msm_g2_set_bases_precomputed(mi_ctx *ctx, const mi_g2_affine *bases, size
 /* out = sum_i scalars[i] * bases[i], i < n.   Replaces gpu::msm::<G1Affine> (src/gpu.rs:226-241) and the CPU
  * multi_exp (src/g1.rs:614-617).  bases == NULL uses the first n resident bases.  Infinity bases contribute
  * nothing (the reference's blst path fails on them, src/g1.rs:682-688).  n == 0 returns infinity.  Blocking.
+ * Bases are expected in the prime-order subgroup, as every G1Affine / G2Affine the reference's deserialisers accept is
+ * (Valid::check, src/g1.rs:419-431): scalars are taken modulo r (a canonical value >= r is reduced) and a scalar above (r - 1) / 2
+ * is processed as -(r - s), so for a point outside the subgroup the result is s P only up to a multiple of r P.
  * Any n: more than 2^26 points per device are processed in several passes whose sums are added (the reference's
  * calc_chunk_size path, src/gpu.rs:64-85,238-239, is unfinished). */
 int mi_msm_g1(mi_ctx *ctx, const mi_g1_affine *bases, const uint8_t *scalars, size_t n, unsigned scalar_fmt,
@@ -199,7 +202,7 @@ int mi_g2_sum(const mi_g2 *partials, size_t n, mi_g2 *out);
  * concatenated shards.  All ranks must report the same mi_window_info — equal shard sizes do; otherwise fix the window size with
  * mi_msm_set_window_bits on every rank.  Single-device contexts, resident bases, at most 2^26 points per call.  The reference has
  * no counterpart (it uses Device::all()[0] only, src/gpu.rs:233-239).  Blocking: the buffer is complete when the call returns. */
-#define MI_MAX_WINDOWS 37   /* ceil(256 / 7) */
+#define MI_MAX_WINDOWS 37   /* ceil(255 / 7) */
 typedef struct { uint32_t window_bits, num_windows; } mi_window_info;
 int mi_msm_g1_device_windows(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scalar_fmt, void *d_out_windows,
                              mi_window_info *info);

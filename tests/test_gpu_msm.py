@@ -535,12 +535,19 @@ def test_cofactor_clearing_through_the_hip_path(ctx, co, o, group):
         got = _canon(co, group, ctx.msm(group, bases, sc, n, 0))
         assert got == want and got != bytes(len(want))
         assert got == co.to_affine(group, co.msm(group, bases, sc, n, 0, 1))
-        rq = ctx.msm(group, got + got, (o.R_ORDER - 1).to_bytes(32, "little") + (1).to_bytes(32, "little"), 2, 0)
+        # r = (r-1)/2 + (r-1)/2 + 1: every scalar at most (r-1)/2, so the library multiplies by the INTEGER (above that it works with
+        # -(r - s), which is the same thing only on the subgroup: include/arkblst_amd.h)
+        half = ((o.R_ORDER - 1) // 2).to_bytes(32, "little")
+        three = half + half + (1).to_bytes(32, "little")
+        rq = ctx.msm(group, got * 3, three, 3, 0)
         assert _canon(co, group, rq) == bytes(len(want))               # r * (h P) = infinity
         # ... and r * P itself is NOT: the point really was outside the subgroup (so the property above is not vacuous)
-        rp = ctx.msm(group, o.affine_to_bytes(F, pt) * 2, (o.R_ORDER - 1).to_bytes(32, "little") + (1).to_bytes(32, "little"), 2, 0)
+        rp = ctx.msm(group, o.affine_to_bytes(F, pt) * 3, three, 3, 0)
         assert _canon(co, group, rp) == o.affine_to_bytes(F, o.scalar_mul(F, pt, o.R_ORDER))
         assert _canon(co, group, rp) != bytes(len(want))
+        # on the subgroup a scalar above (r-1)/2 is exact too: (r - 1) Q = -Q
+        neg = ctx.msm(group, got, (o.R_ORDER - 1).to_bytes(32, "little"), 1, 0)
+        assert _canon(co, group, neg) == o.affine_to_bytes(F, o.aff_neg(F, o.affine_from_bytes(F, got)))
 
 
 def test_call_abi_reproducer():
