@@ -280,7 +280,7 @@ def test_plan(n: int, forced_c: int = 0, group: str = "g1", shared: bool = False
     rc = load_library(True).mi_test_plan(n, forced_c, 0 if group == "g1" else 1, int(shared), stride, out)
     if rc != 0:
         raise MsmError(rc, "mi_test_plan")
-    keys = ("c", "nwin", "bwin", "logL", "chunk_log", "logT", "lo_bits", "serial", "chunks_per_win")
+    keys = ("c", "nwin", "bwin", "coop_L", "chunk_buckets", "logT", "lo_bits", "serial", "chunks_per_win")
     d = {k: int(out[i]) for i, k in enumerate(keys)}
     d["nbuckets"] = (int(out[9]) << 32) | int(out[10])
     d["nchunks"] = int(out[11])

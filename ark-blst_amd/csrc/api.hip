@@ -298,7 +298,7 @@ int mi_test_set_no_peer(mi_ctx* ctx, int no_peer) {
 int mi_test_plan(size_t n, unsigned forced_c, int group, int shared, size_t stride, uint32_t* out) {
     if (!out || n == 0) return MI_E_INVALID;
     Plan p = make_plan(n, forced_c, group == 0 ? g1_cost() : g2_cost(), shared != 0, stride);
-    out[0] = p.c; out[1] = p.nwin; out[2] = p.bwin; out[3] = p.logL; out[4] = p.chunk_log; out[5] = p.logT; out[6] = p.lo_bits;
+    out[0] = p.c; out[1] = p.nwin; out[2] = p.bwin; out[3] = p.coop_L; out[4] = p.chunk_buckets; out[5] = p.logT; out[6] = p.lo_bits;
     out[7] = p.serial_reduce ? 1u : 0u; out[8] = p.chunks_per_win; out[9] = (uint32_t)(p.nbuckets >> 32); out[10] = (uint32_t)p.nbuckets;
     out[11] = (uint32_t)p.nchunks; out[12] = p.serial_reduce ? p.serial_L : 0u;
     return MI_OK;

@@ -52,10 +52,10 @@ extern std::atomic<int> g_fail_allocs;   // > 0: that many upcoming DevBuf::ensu
 struct Plan {
     uint32_t c, nwin;     // window bits, digit windows = ceil(255 / c)
     uint32_t bwin;        // bucket sets: nwin, or 1 when all windows share one (precomputed tables)
-    uint32_t nb, logL, chunks_per_win, logT, lo_bits;
+    uint32_t nb, coop_L, chunks_per_win, logT, lo_bits;   // coop_L: buckets per logical lane of k_reduce_coop (any value 1..64)
     uint32_t cls_shift;   // log2 of the width of a length class of the schedule (follows the typical item, not T)
     uint64_t nbuckets, nchunks;
-    uint32_t chunk_log;   // log2 of the buckets one reduce wave (or, serial form, one reduce lane) covers
+    uint32_t chunk_buckets;   // buckets one reduce wave (or, serial form, one reduce lane) covers; the last chunk of a window may be ragged
     bool serial_reduce;   // throughput form: one lane per serial_L buckets (k_reduce_serial)
     uint32_t serial_L;    // buckets per lane of the serial form (<= 64, any value: chosen so that the lanes fill one round of wave slots)
 };

@@ -457,34 +457,47 @@ template <class C> struct CoopOf;
 template <> struct CoopOf<G1C> { using RS = QuadG1; using CS = QuadG1; };
 template <> struct CoopOf<G2C> { using RS = PairG2; using CS = OctG2; };   // throughput-bound reduce, latency-bound combine
 
-// One wave per chunk of K = NLL * L consecutive buckets of one window (NLL = 2^LOG_LL logical lanes, L = 2^logL).  Logical lane l
-// owns buckets [l L, l L + L) of the chunk.  Output per chunk, in the device bucket layout: pairs[2 chunk] = K * S with
-// S = sum B, pairs[2 chunk + 1] = T = sum (rel + 1) B, rel = index inside the chunk.
+// One wave per chunk of K = NLL * L consecutive buckets of one window (NLL = 2^LOG_LL logical lanes; L is ANY value since round 4,
+// it was a power of two: 2^16 points at c = 15 take L = 9, 1938 waves of 31 steps, where the power-of-two geometry needed L = 16 and
+// 45 steps).  Chunk j of a window covers buckets [j K, j K + K); logical lane l owns [l L, l L + L) of the chunk; buckets beyond
+// the window's nb (last chunk of a window, ragged) are infinity.  Output per chunk, in the device bucket layout:
+// pairs[2 chunk] = K * S with S = sum B, pairs[2 chunk + 1] = T = sum (rel + 1) B, rel = index inside the chunk.
 //
 // The whole reduction is ONE loop with ONE inlined addition site: the operands of step s are selected by the (wave-uniform)
 // step number (an out-of-line addition passes its operands through scratch; several inlined sites would multiply the code).
 //   [0, 2L)            t = L-1 .. 0 :  run += B_t ;  acc += run          (lane-serial running sums)
 //   LOG_LL steps       run += shfl_down(run, 1, 2, 4, ..)                 (suffix scan: run_l = sum_{j>=l} S_j)
-//   logL steps         LP = 2 LP  (LP starts as run)                      (L * P_l)
+//   chain steps        LP = L * run by double-and-add over L's bits       (one doubling per bit below the top one, one addition per set bit)
 //   one step           acc += (l == 0 ? inf : LP)                         (V_l = T_l + L P_l)
 //   LOG_LL steps       acc += shfl_down(acc, NLL/2, .., 1)                (sum over lanes)
 // The last logical lane is idle in the final butterfly after its value has been read in the first step: it doubles
 // LP_0 = L * S there, LOG_LL times, which gives K * S without a single extra step ("rider").
 template <class CS>
 __global__ void __launch_bounds__(64, CS::MAX_OCC) k_reduce_coop(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ woff,
-                                                                 uint32_t* __restrict__ pairs, uint32_t logL) {
+                                                                 uint32_t* __restrict__ pairs, uint32_t L, uint32_t nb, uint32_t cpw) {
     using Pt = typename CS::Pt;
     constexpr int NLL = 1 << CS::LOG_LL, BK = Geo<typename CS::C>::BK_WORDS;
     const uint32_t chunk = blockIdx.x, ll = CS::ll();
-    const uint32_t L = 1u << logL;
-    const uint32_t* wp = woff + (size_t)chunk * NLL * L + (size_t)ll * L;   // bucket b lives at partial[woff[b]]
+    const uint32_t w = chunk / cpw, j = chunk - w * cpw;
+    const uint32_t first = (j * NLL + ll) * L;                                   // this logical lane's buckets: first .. first + cnt - 1 of window w
+    const uint32_t cnt = first >= nb ? 0u : (nb - first < L ? nb - first : L);
+    const uint32_t* wp = woff + (size_t)w * nb + (cnt ? first : 0u);            // bucket b lives at partial[woff[b]]; only rel < cnt is dereferenced as such
     Pt run = CS::inf(), acc = CS::inf(), LP = CS::inf();
-    const uint32_t s_scan = 2 * L, s_dbl = s_scan + CS::LOG_LL, s_comb = s_dbl + logL, s_end = s_comb + 1 + CS::LOG_LL;
+    int top = 0;                                                                 // index of L's top bit
+    while ((L >> top) > 1u) top++;
+    uint32_t chain = 0;
+    for (int b = top - 1; b >= 0; b--) chain += 1 + ((L >> b) & 1u);
+    const uint32_t s_scan = 2 * L, s_dbl = s_scan + CS::LOG_LL, s_comb = s_dbl + chain, s_end = s_comb + 1 + CS::LOG_LL;
     const bool rider = ll == NLL - 1;
+    int bit = top - 1;                                                           // wave-uniform state of the chain
+    bool pend_add = false;
     // software pipeline of the bucket loads: the bucket of pair p + 1 and the index of pair p + 2 are requested while pair p
-    // is being added (two dependent loads of ~2 us would otherwise sit in front of every other step of the chain)
-    Pt nb = CS::load(partial + (size_t)wp[L - 1] * BK);
-    uint32_t idx2 = L > 1 ? wp[L - 2] : 0u;
+    // is being added (two dependent loads of ~2 us would otherwise sit in front of every other step of the chain).  A ragged
+    // lane loads bucket 0 of its range in place of the missing ones and replaces the value by infinity.
+    auto index_of = [&](uint32_t rel) { return wp[rel < cnt ? rel : 0u]; };
+    auto bucket_of = [&](uint32_t idx, uint32_t rel) { return CS::select(rel < cnt, CS::inf(), CS::load(partial + (size_t)idx * BK)); };
+    Pt nbk = bucket_of(index_of(L - 1), L - 1);
+    uint32_t idx2 = L > 1 ? index_of(L - 2) : 0u;
 #pragma unroll 1
     for (uint32_t s = 0; s < s_end; s++) {
         Pt A, B;
@@ -492,10 +505,10 @@ __global__ void __launch_bounds__(64, CS::MAX_OCC) k_reduce_coop(const uint32_t*
         if (s < s_scan) {
             if ((s & 1u) == 0) {
                 const uint32_t p = s >> 1;
-                A = run; B = nb; dst = 0;
+                A = run; B = nbk; dst = 0;
                 if (p + 1 < L) {
-                    nb = CS::load(partial + (size_t)idx2 * BK);
-                    if (p + 2 < L) idx2 = wp[L - 3 - p];
+                    nbk = bucket_of(idx2, L - 2 - p);
+                    if (p + 2 < L) idx2 = index_of(L - 3 - p);
                 }
             } else {
                 A = acc; B = run; dst = 1;
@@ -507,9 +520,18 @@ __global__ void __launch_bounds__(64, CS::MAX_OCC) k_reduce_coop(const uint32_t*
             dst = 0;
         } else if (s < s_comb) {
             if (s == s_dbl) LP = run;
-            A = LP; B = LP; dst = 2;
+            A = LP;
+            if (pend_add) {          // LP = 2 LP + run
+                B = run;
+                pend_add = false;
+            } else {                 // LP = 2 LP, then + run if this bit of L is set
+                B = LP;
+                pend_add = ((L >> bit) & 1u) != 0;
+                bit--;
+            }
+            dst = 2;
         } else if (s == s_comb) {
-            if (logL == 0) LP = run;
+            if (chain == 0) LP = run;
             A = acc;
             B = CS::select(ll == 0, LP, CS::inf());
             dst = 1;

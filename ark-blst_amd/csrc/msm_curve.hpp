@@ -180,7 +180,7 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
         hipLaunchKernelGGL(msmk::k_merge<C>, dim3((nlist + 255) / 256), dim3(256), 0, s, (uint32_t*)d.partial.p,
                            (const uint32_t*)d.item_bucket.p, (const uint32_t*)d.woff.p, (const uint32_t*)d.merge_list.p, nlist, dd);
     HIP_TRY(hipEventRecord(d.ev[ev0 + 4], s));
-    // bucket reduction: one wave per chunk of 2^chunk_log buckets -> (K S, T) pairs; then the per-window combine, 2^LOG_LL pairs per
+    // bucket reduction: one wave per chunk of chunk_buckets buckets -> (K S, T) pairs; then the per-window combine, 2^LOG_LL pairs per
     // wave and level, down to one Jacobian point per window
     bool reduced = false;
     if constexpr (std::is_same<C, msmk::G1C>::value) {   // the throughput form exists for G1 only (HostCurve<G2C>::cost() never asks for it)
@@ -193,7 +193,7 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     if (!reduced) {
         if (pl.serial_reduce) throw HipFail{"serial reduce requested for a curve without it"};
         hipLaunchKernelGGL(msmk::k_reduce_coop<RS>, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
-                           (const uint32_t*)d.woff.p, (uint32_t*)d.pairs.p, pl.logL);
+                           (const uint32_t*)d.woff.p, (uint32_t*)d.pairs.p, pl.coop_L, pl.nb, pl.chunks_per_win);
     }
     HIP_TRY(hipEventRecord(d.ev[ev0 + 5], s));
     uint32_t* jac_dev = (uint32_t*)((char*)d.pairs2.p + d.pairs2.cap - (size_t)pl.bwin * jac_bytes<C>());

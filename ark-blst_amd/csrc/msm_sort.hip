@@ -9,7 +9,7 @@ namespace mi {
 // Window size c by a time model of the pipeline on one MI355X (microseconds; constants measured):
 //   accumulate  max(throughput: N W mixed additions at cc.add_per_us,  latency: one lane walks an item of T entries)
 //   merge       one launch per binary-tree level when the short top window overfills its buckets
-//   reduce      a latency chain of 2L + 2 LOG_LL + logL + 1 complete additions per wave, max_chunks waves per round
+//   reduce      a latency chain of 2L + 2 LOG_LL + chain(L) + 1 complete additions per wave, max_chunks waves per round
 //   combine     2 LOG_LL + 1 additions per level;  sort  N W entries at 4.1e10 /s;  schedule ~ buckets / 1e4;  host Horner ~ 100 us
 Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, size_t stride) {
     Plan best{};
@@ -32,15 +32,27 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         p.nb = 1u << (c - 1);
         p.bwin = shared ? 1 : p.nwin;
         p.nbuckets = (uint64_t)p.nb * p.bwin;
-        // reduce geometry: the smallest L = 2^logL buckets per logical lane that still lets every chunk's wave run at once
-        // (<= max_chunks chunks of NLL * L buckets), capped at L = 64
+        // reduce geometry: L buckets per logical lane, ANY value up to 64 (round 4; a power of two before): the L that costs the fewest
+        // (rounds of max_chunks wave slots) x (steps of the wave's latency chain).  2^16 points at c = 15 (17 windows of 2^14 buckets):
+        // L = 9, 1938 waves of 31 steps; the power-of-two geometry needed L = 16 (L = 8 gives 2176 waves, a second round) and 45 steps.
         const uint32_t log_ll = (uint32_t)cc.log_ll;
         if (c - 1 < log_ll) continue;
-        p.logL = 0;
-        while (p.logL < 6 && p.logL + log_ll < c - 1 && (p.nbuckets >> (log_ll + p.logL)) > cc.max_chunks) p.logL++;
-        p.chunk_log = log_ll + p.logL;
+        double coop_steps = 0, coop_rounds = 0;
+        {
+            double best = 1e300;
+            const uint32_t max_L = std::min<uint32_t>(64, std::max<uint32_t>(1, p.nb >> log_ll));
+            for (uint32_t L = 1; L <= max_L; L++) {
+                const uint64_t chunks = (uint64_t)((p.nb + (L << log_ll) - 1) / (L << log_ll)) * p.bwin;
+                const double rounds = (double)((chunks + cc.max_chunks - 1) / cc.max_chunks);
+                uint32_t bits = 0, ones = 0;
+                for (uint32_t v = L; v; v >>= 1) { bits++; ones += v & 1u; }
+                const double steps = 2.0 * L + 2.0 * log_ll + (bits - 1) + (ones - 1) + 1.0;
+                if (rounds * steps < best) { best = rounds * steps; p.coop_L = L; coop_steps = steps; coop_rounds = rounds; }
+            }
+        }
+        p.chunk_buckets = p.coop_L << log_ll;
         p.serial_reduce = cc.serial_buckets != 0 && p.nbuckets >= cc.serial_buckets && c - 1 >= 6;
-        p.chunks_per_win = p.nb >> p.chunk_log;
+        p.chunks_per_win = (p.nb + p.chunk_buckets - 1) / p.chunk_buckets;
         double serial_steps = 0, serial_rounds = 0;
         if (p.serial_reduce) {
             // one lane per L consecutive buckets of a window, L <= 64 and NOT necessarily a power of two: the L that costs the fewest
@@ -55,7 +67,7 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
                 const double steps = 2.0 * L + (bits - 1) + (ones - 1);
                 if (rounds * steps < best) { best = rounds * steps; p.serial_L = L; serial_steps = steps; serial_rounds = rounds; }
             }
-            p.chunk_log = 6; p.logL = 6;   // (unused by the serial form; kept within the coop form's range)
+            p.chunk_buckets = p.serial_L; p.coop_L = 0;
             p.chunks_per_win = (p.nb + p.serial_L - 1) / p.serial_L;
         }
         p.nchunks = (uint64_t)p.chunks_per_win * p.bwin;
@@ -85,11 +97,10 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         // profiles/r04_scan_c_g1_2p14_2p18.jsonl)
         const double tail = mean + 4.5 * std::sqrt(mean);
         const double item_len = std::min(T, std::max(tail, std::min(per_bucket, T)));
-        const double rounds = (double)((p.nchunks + cc.max_chunks - 1) / cc.max_chunks);
         int levels = 0;
         for (uint32_t m = p.chunks_per_win; m > 1; m = (m + (1u << cc.comb_log_ll) - 1) >> cc.comb_log_ll) levels++;
         const double reduce_us = p.serial_reduce ? serial_rounds * serial_steps * cc.serial_step_us
-                                                 : rounds * (2.0 * (1u << p.logL) + 2.0 * log_ll + p.logL + 1.0) *
+                                                 : coop_rounds * coop_steps *
                                                        (p.nchunks <= 1024 ? std::min(cc.step_us, cc.comb_step_us * 1.05) : cc.step_us);   // lone waves step faster
         // combine: one latency chain per level; the first level of a long pair list runs in several rounds of 2048 waves
         const double comb_chain = (2.0 * cc.comb_log_ll + 1.0) * cc.comb_step_us;

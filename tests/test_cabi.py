@@ -210,14 +210,18 @@ def test_plan_geometry_invariants(pkg):
                         assert group == "g1" and p["nbuckets"] >= 1 << 21 and 8 <= p["serial_L"] <= 64
                         assert p["chunks_per_win"] == -(-nb // p["serial_L"])
                     else:
-                        assert p["chunk_log"] <= cc - 1 and p["chunks_per_win"] == nb >> p["chunk_log"] and p["serial_L"] == 0
-                        assert p["chunk_log"] == p["logL"] + (4 if group == "g1" else 5) and p["logL"] <= 6
+                        # one wave per chunk_buckets = NLL x coop_L buckets (any L <= 64), ragged last chunk of a window
+                        assert p["chunk_buckets"] <= nb and p["chunks_per_win"] == -(-nb // p["chunk_buckets"]) and p["serial_L"] == 0
+                        assert p["chunk_buckets"] == p["coop_L"] * (16 if group == "g1" else 32) and 1 <= p["coop_L"] <= 64
     # no window size fits the entry encoding of precomputed tables beyond ~9e7 points per device (n x windows > 2^30 entries): the plan
     # says so (c = 0) and mi_msm_g1_set_bases_precomputed turns that into MI_E_INVALID before it divides by c
     assert pkg.test_plan(100_000_000, 0, "g1", True, 100_000_000)["c"] == 0
     # the sizes the benchmark configs use keep their measured choices
     # (round 4: with the scalar's sign folded into the digits c = 17 needs 15 windows, not 16, and wins from 2^22 up: 21.5 vs 22.1 ms at 2^23)
     assert pkg.test_plan(1 << 20)["c"] == 16 and pkg.test_plan(1 << 21)["c"] == 16 and pkg.test_plan(1 << 23)["c"] == 17
-    assert pkg.test_plan(1 << 23)["nwin"] == 15 and pkg.test_plan(1 << 16)["c"] == 16
+    assert pkg.test_plan(1 << 23)["nwin"] == 15 and pkg.test_plan(1 << 16)["c"] == 15
     assert pkg.test_plan(1 << 24)["c"] == 20 and pkg.test_plan(1 << 24)["serial"] == 1 and pkg.test_plan(1 << 24)["serial_L"] == 53
     assert pkg.test_plan(1 << 20, 0, "g2")["c"] == 16
+    # the reduce wave's L is not tied to powers of two: 17 windows of 2^14 buckets fit one round of wave slots at L = 9
+    assert pkg.test_plan(1 << 16, 15)["coop_L"] == 9 and pkg.test_plan(1 << 16, 15)["nchunks"] == 17 * 114
+    assert pkg.test_plan(1 << 20)["coop_L"] == 16 and pkg.test_plan(1 << 20)["nchunks"] == 2048
