@@ -54,12 +54,12 @@ template <class C>
 __global__ void __launch_bounds__(64, C::OCC) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                             const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ woff,
                                                             const uint32_t* __restrict__ order, const uint32_t* __restrict__ item_bucket,
-                                                            uint32_t nitems, uint32_t logT, uint32_t* __restrict__ partial) {
+                                                            const uint32_t* __restrict__ meta, uint32_t logT, uint32_t* __restrict__ partial) {
     using F = typename C::F;
     using FA = typename C::FA;
     using E = typename F::E;
     uint32_t j = blockIdx.x * 64 + threadIdx.x;
-    if (j >= nitems) return;
+    if (j >= meta[0]) return;       // the item count stays on the device: the grid is the host's upper bound (run_msm), surplus waves leave here
     uint32_t i = order[j];          // items are processed longest class first; partial[] keeps natural item order
     uint32_t b = item_bucket[i];
     uint32_t k = i - woff[b];
@@ -137,11 +137,11 @@ template <class C>   // C = G2C (a template so that only the G2 translation unit
 __global__ void __launch_bounds__(64, 2) k_accumulate_g2_coop(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                                const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ woff,
                                                                const uint32_t* __restrict__ order, const uint32_t* __restrict__ item_bucket,
-                                                               uint32_t nitems, uint32_t logT, uint32_t* __restrict__ partial) {
+                                                               const uint32_t* __restrict__ meta, uint32_t logT, uint32_t* __restrict__ partial) {
     using FA = CoopF2A;
     const uint32_t h = threadIdx.x & 1u;
     uint32_t j = (blockIdx.x * 64 + threadIdx.x) >> 1;
-    if (j >= nitems) return;        // pairs never straddle the bound (even block size)
+    if (j >= meta[0]) return;       // pairs never straddle the bound (even block size); the grid is an upper bound, as for k_accumulate
     uint32_t i = order[j];
     uint32_t b = item_bucket[i];
     uint32_t k = i - woff[b];

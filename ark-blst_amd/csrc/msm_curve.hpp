@@ -139,13 +139,14 @@ J horner(const J* win, const Plan& pl) {
 // the dominant kernel: one lane per work item for G1, a lane pair per work item for G2 (k_accumulate_g2_coop)
 template <class C>
 void launch_accumulate(hipStream_t s, const uint32_t* bases, const uint32_t* sorted, const uint32_t* offsets, const uint32_t* woff,
-                       const uint32_t* order, const uint32_t* item_bucket, uint32_t nitems, uint32_t logT, uint32_t* partial) {
+                       const uint32_t* order, const uint32_t* item_bucket, size_t items_cap, const uint32_t* meta, uint32_t logT, uint32_t* partial) {
+    // grid = the host's upper bound of the item count; the kernels read the count itself from meta[0]
     if constexpr (std::is_same<C, msmk::G2C>::value) {
-        hipLaunchKernelGGL(msmk::k_accumulate_g2_coop<C>, dim3((2 * nitems + 63) / 64), dim3(64), 0, s, bases, sorted, offsets, woff, order,
-                           item_bucket, nitems, logT, partial);
+        hipLaunchKernelGGL(msmk::k_accumulate_g2_coop<C>, dim3((uint32_t)((2 * items_cap + 63) / 64)), dim3(64), 0, s, bases, sorted, offsets, woff, order,
+                           item_bucket, meta, logT, partial);
     } else {
-        hipLaunchKernelGGL(msmk::k_accumulate<C>, dim3((nitems + 63) / 64), dim3(64), 0, s, bases, sorted, offsets, woff, order, item_bucket,
-                           nitems, logT, partial);
+        hipLaunchKernelGGL(msmk::k_accumulate<C>, dim3((uint32_t)((items_cap + 63) / 64)), dim3(64), 0, s, bases, sorted, offsets, woff, order, item_bucket,
+                           meta, logT, partial);
     }
 }
 
@@ -171,10 +172,14 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     sort_and_schedule(d, pl, d_scalars, d_flags, n, fmt, shared, stride, ev0, so, host_scalars);
 
     hipStream_t s = d.stream;
-    const uint32_t nitems = so.nitems, max_items = so.max_items;
-    d.partial.ensure((size_t)nitems * BK * 4);
+    // the accumulate kernel is queued behind the schedule BEFORE the host learns the item count (only the merge launches need it):
+    // the read-back's latency is hidden behind the kernel instead of idling the device between the two
+    d.partial.ensure(so.items_cap * BK * 4);
     launch_accumulate<C>(s, d_bases, (const uint32_t*)d.sorted.p, (const uint32_t*)d.offsets.p, (const uint32_t*)d.woff.p,
-                         (const uint32_t*)d.order.p, (const uint32_t*)d.item_bucket.p, nitems, pl.logT, (uint32_t*)d.partial.p);
+                         (const uint32_t*)d.order.p, (const uint32_t*)d.item_bucket.p, so.items_cap, (const uint32_t*)d.meta.p, pl.logT,
+                         (uint32_t*)d.partial.p);
+    read_schedule(d, ev0, so);
+    const uint32_t nitems = so.nitems, max_items = so.max_items;
     uint32_t nlist = so.nlist;
     for (uint32_t dd = 1; dd < max_items && nlist; dd <<= 1)
         hipLaunchKernelGGL(msmk::k_merge<C>, dim3((nlist + 255) / 256), dim3(256), 0, s, (uint32_t*)d.partial.p,

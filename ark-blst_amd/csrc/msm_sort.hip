@@ -316,7 +316,9 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
     uint32_t per_blk = 4096;
     while ((pl.nbuckets + per_blk - 1) / per_blk > 256) per_blk <<= 1;
     uint32_t nblk = (uint32_t)((pl.nbuckets + per_blk - 1) / per_blk);
-    size_t items_cap = pl.nbuckets + (entries_cap >> pl.logT) + 1;  // one per bucket plus one per T entries
+    // every bucket has at least one item (an empty bucket's item leaves infinity for the reduce), plus one per T entries
+    const size_t items_cap = pl.nbuckets + (entries_cap >> pl.logT) + 1;
+    out.items_cap = items_cap;
     d.sched.ensure((size_t)(3 + msmk::SCHED_CLASSES) * nblk * 4);
     d.order.ensure(items_cap * 4);
     d.item_bucket.ensure(items_cap * 4);
@@ -333,15 +335,19 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
                        nblk, (const uint32_t*)blk_e, (const uint32_t*)blk_i, (const uint32_t*)blk_cls, (uint32_t*)d.offsets.p,
                        (uint32_t*)d.woff.p, (uint32_t*)d.order.p, (uint32_t*)d.item_bucket.p, (uint32_t*)d.merge_list.p,
                        (uint32_t*)d.meta.p);
-    // the item count sizes the next launches: one small read-back into pinned memory (the only mid-pipeline sync)
+    // the merge launches are sized by the schedule's counts: one small read-back into pinned memory, waited for by read_schedule
     HIP_TRY(hipMemcpyAsync(d.h_meta, d.meta.p, 16, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(d.ev[ev0 + 3], s));
-    HIP_TRY(hipStreamSynchronize(s));
+}
+
+void read_schedule(DevState& d, int ev0, SortOut& out) {
+    HIP_TRY(hipEventSynchronize(d.ev[ev0 + 3]));
     HIP_TRY(hipGetLastError());
     out.nitems = d.h_meta[0];
     out.max_items = d.h_meta[1];
     out.entries = d.h_meta[2];
     out.nlist = d.h_meta[3];
+    if (out.nitems > out.items_cap) throw HipFail{"schedule produced more work items than its bound"};
 }
 
 }  // namespace mi
