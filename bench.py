@@ -786,6 +786,7 @@ def main() -> None:
             except Exception as e:
                 secondary[name] = {"error": repr(e)}
         if g == "g1" and log_n == 20 and not args.precomputed and args.dist == "uniform":
+            guarded("g1_2p16", lambda: _secondary_msm(pkg, co, torch, "g1", 16, 16, ncpu, local_rank, 50))   # config #1's size (the reference's CPU-runnable case)
             guarded("g1_2p24", lambda: _secondary_msm(pkg, co, torch, "g1", 24, 24, ncpu, local_rank, 3))
             guarded("g2_2p20", lambda: _secondary_msm(pkg, co, torch, "g2", 20, 4, ncpu, local_rank, 5))
             guarded("g1_2p20_precomputed_tables", lambda: _secondary_msm(pkg, co, torch, "g1", 20, 0, ncpu, local_rank, 10, precomputed=True))
@@ -851,7 +852,7 @@ def main() -> None:
                 b["valu_frac"] = round(d["roofline"]["frac"], 3)
             return b
         summary = {f"{g}_2p{log_n}" if log_n is not None else f"{g}_{headline_n}": _brief(out)}
-        for k in ("g1_2p24", "g2_2p20", "pairing_2p16", "g1_2p20_precomputed_tables", "normalize_2p20", "deserialize_2p20"):
+        for k in ("g1_2p16", "g1_2p24", "g2_2p20", "pairing_2p16", "g1_2p20_precomputed_tables", "normalize_2p20", "deserialize_2p20"):
             if k in secondary and "error" not in secondary[k]:
                 summary[k] = _brief(secondary[k])
         if "call_shapes" in secondary:

@@ -55,17 +55,35 @@ def test_g1_msm_montgomery_scalars(ctx, co, pkg):
     assert _canon(co, "g1", a) == _canon(co, "g1", b) == co.dlog_expected("g1", canon, SEED_B, n)
 
 
-@pytest.mark.parametrize("c", [7, 9, 12, 13, 16])
+@pytest.mark.parametrize("c", list(range(7, 17)))
 def test_g1_msm_all_window_sizes(ctx, co, pkg, c):
+    """every window size of the two-level sort: each has its own reduce geometry (buckets per lane L = 1, 2, 3, 5, 9, 16, ...: the reduce
+    wave takes any L and ragged last chunks since round 4)"""
     n = 3000
     bases = co.gen_bases("g1", SEED_B + 1, n, 4)
     scalars = co.gen_scalars(SEED_S + 1, n)
     ctx.set_window_bits(c)
     try:
         got = ctx.msm("g1", bases, scalars, n, pkg.SCALAR_CANONICAL)
+        assert ctx.profile()["window_bits"] == c
     finally:
         ctx.set_window_bits(0)
     assert _canon(co, "g1", got) == co.dlog_expected("g1", scalars, SEED_B + 1, n)
+
+
+@pytest.mark.parametrize("c", [8, 11, 14, 15])
+def test_g2_msm_window_sizes(ctx, co, pkg, c):
+    """the same for G2 (32 logical lanes per reduce wave: other L, other ragged chunks)"""
+    n = 700
+    bases = co.gen_bases("g2", SEED_B + 2, n, 4)
+    scalars = co.gen_scalars(SEED_S + 2, n)
+    ctx.set_window_bits(c)
+    try:
+        got = ctx.msm("g2", bases, scalars, n, pkg.SCALAR_CANONICAL)
+        assert ctx.profile()["window_bits"] == c
+    finally:
+        ctx.set_window_bits(0)
+    assert _canon(co, "g2", got) == co.dlog_expected("g2", scalars, SEED_B + 2, n)
 
 
 def test_g1_msm_edge_cases(ctx, co, o, pkg):
