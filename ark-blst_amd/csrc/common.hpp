@@ -53,6 +53,7 @@ struct Plan {
     uint32_t c, nwin;     // window bits, digit windows = ceil(255 / c)
     uint32_t bwin;        // bucket sets: nwin, or 1 when all windows share one (precomputed tables)
     uint32_t nb, coop_L, chunks_per_win, logT, lo_bits;   // coop_L: buckets per logical lane of k_reduce_coop (any value 1..64)
+    uint32_t logS;        // log2 of the item size of buckets that hold more than T = 2^logT entries (<= logT)
     uint32_t cls_shift;   // log2 of the width of a length class of the schedule (follows the typical item, not T)
     uint64_t nbuckets, nchunks;
     uint32_t chunk_buckets;   // buckets one reduce wave (or, serial form, one reduce lane) covers; the last chunk of a window may be ragged
@@ -109,11 +110,11 @@ struct DevState {
     Resident* res = nullptr;   // -> mi_ctx::residents[device][2]
     // scratch
     DevBuf raw, call_bases, call_flags, scalars, hist, offsets, woff, meta, sched, sorted, partial, order, item_bucket, pairs, pairs2;
-    DevBuf tilecnt, tileoff, bin_tot, bin_base, binA_base, coarse, coarseA, seg_cnt, seg_base, segcnt, segoff, merge_list;
+    DevBuf tilecnt, tileoff, bin_tot, bin_base, binA_base, coarse, coarseA, seg_cnt, seg_base, segcnt, segoff, merge_list, merge_list2;
     DevBuf pr_p, pr_q, pr_lvl[2], pr_raw, pr_lines;   // pairing: inputs, tree levels, top values, line coefficients
     void* h_pairs = nullptr;   // pinned host staging: window sums (D2H) and the schedule's item counts
     size_t h_pairs_cap = 0;
-    uint32_t* h_meta = nullptr;   // pinned, 16 B
+    uint32_t* h_meta = nullptr;   // pinned, 32 B
     mi_profile prof{};
 
     void ensure_host(size_t bytes) {
@@ -126,7 +127,7 @@ struct DevState {
     }
     template <class Fn> void for_each_buf(Fn fn) {
         for (DevBuf* b : {&raw, &call_bases, &call_flags, &scalars, &hist, &offsets, &woff, &meta, &sched, &sorted, &partial, &order, &item_bucket,
-                          &pairs, &pairs2, &tilecnt, &tileoff, &bin_tot, &bin_base, &binA_base, &coarse, &coarseA, &seg_cnt, &seg_base, &segcnt, &segoff, &merge_list, &pr_p, &pr_q, &pr_lvl[0],
+                          &pairs, &pairs2, &tilecnt, &tileoff, &bin_tot, &bin_base, &binA_base, &coarse, &coarseA, &seg_cnt, &seg_base, &segcnt, &segoff, &merge_list, &merge_list2, &pr_p, &pr_q, &pr_lvl[0],
                           &pr_lvl[1], &pr_raw, &pr_lines})
             fn(*b);
     }

@@ -50,6 +50,16 @@ __device__ __forceinline__ void load_point(typename C::F::E& x, typename C::F::E
 // Output: partial[i] (projective), i = natural item id.
 // Workgroups of ONE wave: a CU refills a wave slot the moment a wave retires instead of waiting for the four slots a 256-thread
 // workgroup needs (same-box A/B at 2^20 points: 2.30 vs 2.33 ms; nothing at 2^24, nothing for G2).
+// Entries [e, end) of item k of bucket b.  `packed` = log2 T | log2 S << 16 (the schedule's item geometry, sort_kernels.cuh items_of): a bucket
+// of up to T entries is one item, a fuller one is cut into items of S entries.
+__device__ __forceinline__ void item_range(const uint32_t* __restrict__ offsets, uint32_t b, uint32_t k, uint32_t packed, uint32_t& e, uint32_t& end) {
+    const uint32_t logT = packed & 0xffu, logS = (packed >> 16) & 0xffu;
+    const uint32_t beg = offsets[b], bend = offsets[b + 1];
+    const uint32_t lg = bend - beg > (1u << logT) ? logS : logT;
+    e = beg + (k << lg);
+    end = e + (1u << lg) < bend ? e + (1u << lg) : bend;
+}
+
 template <class C>
 __global__ void __launch_bounds__(64, C::OCC) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                             const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ woff,
@@ -63,8 +73,8 @@ __global__ void __launch_bounds__(64, C::OCC) k_accumulate(const uint32_t* __res
     uint32_t i = order[j];          // items are processed longest class first; partial[] keeps natural item order
     uint32_t b = item_bucket[i];
     uint32_t k = i - woff[b];
-    uint32_t e = offsets[b] + (k << logT), bend = offsets[b + 1];
-    uint32_t end = e + (1u << logT) < bend ? e + (1u << logT) : bend;
+    uint32_t e, end;
+    item_range(offsets, b, k, logT, e, end);
     // the first entry only initialises the running sum: peeled off the loop, which then has no "still empty" branch
     ec::Xyzz<FA> acc;
     const bool inf = e >= end;
@@ -145,8 +155,8 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_g2_coop(const uint32_t* __
     uint32_t i = order[j];
     uint32_t b = item_bucket[i];
     uint32_t k = i - woff[b];
-    uint32_t e = offsets[b] + (k << logT), bend = offsets[b + 1];
-    uint32_t end = e + (1u << logT) < bend ? e + (1u << logT) : bend;
+    uint32_t e, end;
+    item_range(offsets, b, k, logT, e, end);
     auto load_comp = [&](Fp& x, Fp& y, uint32_t ent) {   // this lane's component of x and y: slots x.c0 | x.c1 | y.c0 | y.c1
         const uint32_t* p = bases + (size_t)(ent & 0x7fffffffu) * G2_PT_WORDS + 16 * h;
         load_fp16(x, p);
@@ -184,25 +194,42 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_g2_coop(const uint32_t* __
     g2_coop_finish(bases, sorted, e, end, inf, fin, partial + (size_t)i * G2_BK_WORDS + 16 * h);
 }
 
-// One binary-tree level of the per-bucket merge of split buckets: partial[i] += partial[i + d] for the items whose
-// chunk index is a multiple of 2d.  After ceil(log2(max items)) levels partial[woff[b]] is bucket b.  Launched only
-// when some bucket was split (meta[1] > 1), over the items of split buckets only (merge_list, meta[3] entries).
-template <class C>
-__global__ void __launch_bounds__(256, 2) k_merge(uint32_t* __restrict__ partial, const uint32_t* __restrict__ item_bucket,
-                                                       const uint32_t* __restrict__ woff, const uint32_t* __restrict__ merge_list,
-                                                       uint32_t nlist, uint32_t d) {
-    uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= nlist) return;
-    uint32_t i = merge_list[j];
-    uint32_t b = item_bucket[i];
-    uint32_t n = woff[b + 1] - woff[b];
-    if (n <= d) return;
-    uint32_t k = i - woff[b];
-    if ((k & (2 * d - 1)) != 0 || k + d >= n) return;
-    auto a = load_bucket<C>(partial + (size_t)i * Geo<C>::BK_WORDS);
-    auto c = load_bucket<C>(partial + (size_t)(i + d) * Geo<C>::BK_WORDS);
-    add_inplace(a, c);
-    store_bucket<C>(partial + (size_t)i * Geo<C>::BK_WORDS, a);
+// One level of the per-bucket merge of split buckets, fan-in MERGE_FAN: partial[i] += partial[i + d] + partial[i + 2d] + ... for the listed
+// items i, whose index k inside their bucket is a multiple of MERGE_FAN * d.  Levels d = 1, FAN, FAN^2, .. until d >= max items; then
+// partial[woff[b]] is bucket b.  Launched only when some bucket was split (meta[1] > 1).  The list of level 0 comes from the schedule
+// (k_sched3: every FAN-th item of every split bucket); each level appends the items that accumulate again at the next one (k a
+// multiple of FAN^2 d with something left to add) to the next level's list, so every level's launch is dense whatever the bucket sizes
+// are (a level that skipped through ONE list left one active lane per wave from the second level on: 0.9 ms per level for a bucket of
+// 2^20 entries).  One LOGICAL lane of the combine's lane scheme per listed item (round 4: it was one lane per item and a binary tree —
+// 14 launches of a 25-us single-lane addition for such a bucket; a quad-lane addition takes 4-5 us).  Every lane of a wave runs the
+// same number of additions (the lane schemes exchange operands across lanes): idle ones add infinity.  grid = the host's bound of the
+// list length; the length itself is read from *count_in.
+template <class CS>
+__global__ void __launch_bounds__(64, CS::MAX_OCC) k_merge(uint32_t* __restrict__ partial, const uint32_t* __restrict__ item_bucket,
+                                                           const uint32_t* __restrict__ woff, const uint32_t* __restrict__ list_in,
+                                                           const uint32_t* __restrict__ count_in, uint32_t* __restrict__ list_out,
+                                                           uint32_t* __restrict__ count_out, uint32_t d) {
+    using Pt = typename CS::Pt;
+    constexpr int NLL = 1 << CS::LOG_LL, BK = Geo<typename CS::C>::BK_WORDS;
+    const uint32_t slot = blockIdx.x * NLL + CS::ll();
+    const bool have = slot < *count_in;
+    if (__ballot(have) == 0) return;
+    const uint32_t i = list_in[have ? slot : 0];
+    const uint32_t b = item_bucket[i];
+    const uint32_t n = woff[b + 1] - woff[b], k = i - woff[b];
+    const uint32_t room = have && n - 1 - k >= d ? (n - 1 - k) / d : 0u;            // items k + d, k + 2 d, .. that exist
+    const uint32_t m = room < MERGE_FAN - 1 ? room : MERGE_FAN - 1;                  // addends of this level
+    Pt acc = CS::load(partial + (size_t)i * BK);
+#pragma unroll 1
+    for (uint32_t t = 1; t < MERGE_FAN; t++) {
+        if (__ballot(t <= m) == 0) break;
+        Pt nb = CS::select(t <= m, CS::inf(), CS::load(partial + (size_t)(i + (t <= m ? t * d : 0u)) * BK));
+        CS::add(acc, nb);
+    }
+    if (m) CS::store(partial + (size_t)i * BK, acc);
+    // accumulates again at the next level (stride FAN d): first lane of the logical lane appends the item
+    const uint64_t fd = (uint64_t)MERGE_FAN * d;
+    if (have && (threadIdx.x & (64 / NLL - 1)) == 0 && k % (MERGE_FAN * fd) == 0 && (uint64_t)k + fd < n) list_out[atomicAdd(count_out, 1u)] = i;
 }
 
 // ---------------------------------------------------------------------------------------------- precomputed tables

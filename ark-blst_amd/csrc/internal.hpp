@@ -16,9 +16,10 @@ struct CurveCost {        // what the plan needs to know about the curve's kerne
     uint32_t max_chunks;  // reduce waves that run at once (1024 SIMDs x occupancy)
     double add_per_us;    // mixed additions per microsecond of the accumulate kernel at full occupancy
     double lane_add_us;   // one lane's time per mixed addition (latency view)
-    double step_us;       // one complete addition of the reduce chain
+    double step_us;       // one complete addition of the reduce chain, every wave slot taken
+    double lone_step_us;  // the same with at most one reduce wave per SIMD
     double comb_step_us;  // one complete addition of the combine chain
-    double merge_us;      // one level of the split-bucket merge
+    double merge_us;      // one level of the split-bucket merge (fan-in MERGE_FAN, k_merge)
     uint64_t serial_buckets;  // bucket count from which the one-lane-per-64-buckets reduce is used (0 = never)
     double serial_step_us;    // one single-lane complete addition at two waves per SIMD
 };
@@ -27,7 +28,7 @@ struct CurveCost {        // what the plan needs to know about the curve's kerne
 Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, size_t stride);
 
 struct SortOut {
-    uint32_t nitems = 0, max_items = 0, nlist = 0;
+    uint32_t nitems = 0, max_items = 0, nlist = 0, nsplit = 0;   // nlist: list length of merge level 0; nsplit: split buckets
     uint64_t entries = 0;
     size_t items_cap = 0;   // upper bound of nitems known before the schedule has run (sizes the accumulate launch and its output)
 };

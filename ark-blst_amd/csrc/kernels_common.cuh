@@ -222,6 +222,11 @@ __device__ __forceinline__ bool load_scalar(uint32_t (&s)[8], const uint32_t* sc
 }
 
 // c-bit field starting at bit `off` of a 256-bit little-endian integer (zero beyond bit 255)
+constexpr uint32_t MERGE_FAN = 4;   // fan-in of one level of the merge of split buckets (k_merge, curve_kernels.cuh; the plan counts its levels)
+// the schedule's counters in device memory (words): [0] items, [1] max items of a bucket, [2] entries, [3] merge list length of level 0,
+// [4] split buckets, [8 + l] merge list length of level l >= 1
+constexpr uint32_t MERGE_META = 32;
+
 __device__ __forceinline__ uint32_t scalar_bits(const uint32_t (&s)[8], uint32_t off, uint32_t c) {
     uint32_t w = off >> 5, sh = off & 31;
     uint32_t lo = 0, hi = 0;

@@ -14,13 +14,13 @@ template <> struct HostCurve<msmk::G1C> {
     using J = hostec::G1;
     static constexpr int IDX = 0;
     // accumulate 7.1e9 additions/s, 11 us per addition and lane; quad-lane complete addition ~6 us per step, two waves per SIMD
-    static CurveCost cost() { return CurveCost{msmk::QuadG1::LOG_LL, msmk::QuadG1::LOG_LL, 2048, 7400.0, 14.0, 9.5, 5.6, 110.0, 1ull << 21, 25.0}; }
+    static CurveCost cost() { return CurveCost{msmk::QuadG1::LOG_LL, msmk::QuadG1::LOG_LL, 2048, 7400.0, 14.0, 9.5, 5.9, 4.4, 40.0, 1ull << 21, 25.0}; }
 };
 template <> struct HostCurve<msmk::G2C> {
     using J = hostec::G2;
     static constexpr int IDX = 1;
     // lane pairs for the reduce (throughput), eight lanes per logical lane for the combine (latency)
-    static CurveCost cost() { return CurveCost{msmk::PairG2::LOG_LL, msmk::OctG2::LOG_LL, 1024, 2300.0, 36.0, 28.0, 14.0, 150.0, 0, 0.0}; }
+    static CurveCost cost() { return CurveCost{msmk::PairG2::LOG_LL, msmk::OctG2::LOG_LL, 1024, 2300.0, 36.0, 28.0, 24.5, 14.0, 80.0, 0, 0.0}; }
 };
 template <class C> constexpr size_t aff_bytes() { return (size_t)msmk::Geo<C>::RAW_AFF * 4; }
 template <class C> constexpr size_t jac_bytes() { return (size_t)msmk::Geo<C>::RAW_JAC * 4; }
@@ -176,14 +176,24 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     // the read-back's latency is hidden behind the kernel instead of idling the device between the two
     d.partial.ensure(so.items_cap * BK * 4);
     launch_accumulate<C>(s, d_bases, (const uint32_t*)d.sorted.p, (const uint32_t*)d.offsets.p, (const uint32_t*)d.woff.p,
-                         (const uint32_t*)d.order.p, (const uint32_t*)d.item_bucket.p, so.items_cap, (const uint32_t*)d.meta.p, pl.logT,
+                         (const uint32_t*)d.order.p, (const uint32_t*)d.item_bucket.p, so.items_cap, (const uint32_t*)d.meta.p, pl.logT | (pl.logS << 16),
                          (uint32_t*)d.partial.p);
     read_schedule(d, ev0, so);
     const uint32_t nitems = so.nitems, max_items = so.max_items;
-    uint32_t nlist = so.nlist;
-    for (uint32_t dd = 1; dd < max_items && nlist; dd <<= 1)
-        hipLaunchKernelGGL(msmk::k_merge<C>, dim3((nlist + 255) / 256), dim3(256), 0, s, (uint32_t*)d.partial.p,
-                           (const uint32_t*)d.item_bucket.p, (const uint32_t*)d.woff.p, (const uint32_t*)d.merge_list.p, nlist, dd);
+    if (max_items > 1 && so.nlist) {
+        // the fan-in tree over the items of split buckets: one launch per level; level l reads list l and appends list l + 1 (device
+        // counters meta[3], meta[8 + l]); the grid is the host's bound of the list length: ceil(items / FAN^(l+1)) summed over the split buckets
+        uint32_t* meta = (uint32_t*)d.meta.p;
+        uint32_t* lists[2] = {(uint32_t*)d.merge_list.p, (uint32_t*)d.merge_list2.p};
+        uint64_t dd = 1, shrink = 1;
+        for (uint32_t l = 0; dd < max_items; l++, dd *= msmk::MERGE_FAN, shrink *= msmk::MERGE_FAN) {
+            if (8 + l + 1 >= msmk::MERGE_META) throw HipFail{"merge tree deeper than its counters"};
+            const uint64_t bound = std::min<uint64_t>(so.nlist, so.nlist / shrink + so.nsplit);
+            hipLaunchKernelGGL(msmk::k_merge<CS>, dim3((uint32_t)((bound + (1u << CS::LOG_LL) - 1) >> CS::LOG_LL)), dim3(64), 0, s, (uint32_t*)d.partial.p,
+                               (const uint32_t*)d.item_bucket.p, (const uint32_t*)d.woff.p, (const uint32_t*)lists[l & 1],
+                               (const uint32_t*)(l == 0 ? meta + 3 : meta + 8 + l), lists[(l + 1) & 1], meta + 8 + l + 1, (uint32_t)dd);
+        }
+    }
     HIP_TRY(hipEventRecord(d.ev[ev0 + 4], s));
     // bucket reduction: one wave per chunk of chunk_buckets buckets -> (K S, T) pairs; then the per-window combine, 2^LOG_LL pairs per
     // wave and level, down to one Jacobian point per window

@@ -89,19 +89,34 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         const double walk = 0.2 * ((entries + 0.2 * (double)p.nbuckets) / cc.add_per_us) / cc.lane_add_us;
         while (p.logT < 20 && (double)(2u << p.logT) <= walk) p.logT++;
         const double T = (double)(1u << p.logT);
-        int merge_levels = 0;
-        for (double x = per_bucket; x > T; x *= 0.5) merge_levels++;
+        p.logS = std::max<uint32_t>(4, p.logT - 2);   // buckets beyond T entries are cut into items of S = max(16, T / 4) (sort_kernels.cuh items_of; logT >= 5)
+        // the fan-in tree over the items of the fullest expected buckets (k_merge): the short top window's 2^top_bits buckets, n / 2^top_bits
+        // entries each.  A level costs a launch, or — many items — rounds of (FAN - 1) complete additions on every wave slot's logical lanes
+        double merge_total_us = 0;
+        if (per_bucket > T) {
+            const double lanes_at_once = (double)cc.max_chunks * (double)(1u << cc.comb_log_ll);
+            double per = per_bucket / (double)(1u << p.logS), all = per * (double)(1u << top_bits);
+            for (; per > 1.0; per /= (double)msmk::MERGE_FAN, all /= (double)msmk::MERGE_FAN)
+                merge_total_us += std::max(cc.merge_us, std::ceil(all / (double)msmk::MERGE_FAN / lanes_at_once) * (msmk::MERGE_FAN - 1) * cc.step_us);
+            // ... and n entries aimed at a handful of buckets contend for the same LDS counters in every pass of the sort and make short
+            // items of the accumulate kernel's first rounds (2^23 points at c = 19, a 7-bit top window: sort + 0.6 ms, accumulate + 0.7 ms
+            // against the plain model; profiles/r04_scan_c_g1_2p21_2p24_merge_tree.jsonl)
+            merge_total_us += 1.6e-4 * (double)n;
+        }
         // entries the longest ordinary lane walks serially: bucket loads are Poisson distributed, the kernel ends with the tail
         // (round 4: the kernel ends with the LONGEST of ~10^5 items — mean + 4.5 sigma, not + 3 — and a lone lane's addition costs 14 us
         // with its dependent gather, not 11; with the old figures the plan chose c = 13 at 2^14 points, 0.86 ms where c = 16 takes 0.79:
         // profiles/r04_scan_c_g1_2p14_2p18.jsonl)
         const double tail = mean + 4.5 * std::sqrt(mean);
-        const double item_len = std::min(T, std::max(tail, std::min(per_bucket, T)));
+        // (a bucket beyond T entries is cut into items of S: the fullest expected bucket then costs S entries per lane plus its merge levels)
+        // the top window's buckets have a tail of their own; a top window of under 4 bits also has a carry-only bucket that fills to just below T
+        // (one unsplit item of ~T entries: 2^10 points at c = 9, 12, 14 measure 0.33-0.36 ms of accumulate where c = 10 takes 0.16)
+        double item_len = std::min(T, std::max(tail, per_bucket > T ? (double)(1u << p.logS) : per_bucket + 3.0 * std::sqrt(per_bucket)));
+        if (per_bucket > T && top_bits < 4) item_len = T;
         int levels = 0;
         for (uint32_t m = p.chunks_per_win; m > 1; m = (m + (1u << cc.comb_log_ll) - 1) >> cc.comb_log_ll) levels++;
         const double reduce_us = p.serial_reduce ? serial_rounds * serial_steps * cc.serial_step_us
-                                                 : coop_rounds * coop_steps *
-                                                       (p.nchunks <= 1024 ? std::min(cc.step_us, cc.comb_step_us * 1.05) : cc.step_us);   // lone waves step faster
+                                                 : coop_rounds * coop_steps * (p.nchunks <= 1000 ? cc.lone_step_us : cc.step_us);   // lone waves step faster
         // combine: one latency chain per level; the first level of a long pair list runs in several rounds of 2048 waves
         const double comb_chain = (2.0 * cc.comb_log_ll + 1.0) * cc.comb_step_us;
         const double comb_us = std::max(1, levels) * (comb_chain + 8.0) +
@@ -114,7 +129,12 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         double acc_adds = entries - nonempty + 1.2 * (double)p.nbuckets;
         const double wave_rounds = (double)p.nbuckets / 64.0 / (double)cc.max_chunks;
         if (wave_rounds < 4.0) acc_adds *= 1.0 + 0.5 * (std::ceil(wave_rounds) - wave_rounds) / std::max(wave_rounds, 0.25);
-        double cost = std::max(acc_adds / cc.add_per_us, item_len * cc.lane_add_us) + merge_levels * cc.merge_us + reduce_us + comb_us +
+        // a lane's addition takes lane_add_us with two waves per SIMD; with at most one (few items) about two thirds of it
+        const double lane_us = cc.lane_add_us * ((double)p.nbuckets / 64.0 <= 1024.0 ? 0.68 : 1.0);
+        // the kernel drains over the life of its SHORTEST items (the schedule starts the longest first): half a wave generation of
+        // mean - 3 sigma entries is lost at the end — fuller buckets, longer drain (c = 15 vs 16 at 2^20 points: 10 % fewer additions per us)
+        const double drain_us = 0.5 * std::max(0.0, mean - 3.0 * std::sqrt(mean)) * cc.lane_add_us;
+        double cost = std::max(acc_adds / cc.add_per_us + drain_us, item_len * lane_us) + merge_total_us + reduce_us + comb_us +
                       entries / 41000.0 + (double)p.nbuckets / 1e4 + (shared ? 20.0 : 100.0);
         if (cost < best_cost) {
             best_cost = cost;
@@ -174,9 +194,9 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
     d.hist.ensure(pl.nbuckets * 4);
     d.offsets.ensure((pl.nbuckets + 1) * 4);
     d.woff.ensure((pl.nbuckets + 1) * 4);
-    d.meta.ensure(16);
+    d.meta.ensure(msmk::MERGE_META * 4);
     d.sorted.ensure(entries_cap * 4);
-    if (!d.h_meta) HIP_TRY(hipHostMalloc((void**)&d.h_meta, 16, hipHostMallocDefault));
+    if (!d.h_meta) HIP_TRY(hipHostMalloc((void**)&d.h_meta, 32, hipHostMallocDefault));
 
     hipStream_t s = d.stream;
     HIP_TRY(hipEventRecord(d.ev[ev0], s));
@@ -316,27 +336,28 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
     uint32_t per_blk = 4096;
     while ((pl.nbuckets + per_blk - 1) / per_blk > 256) per_blk <<= 1;
     uint32_t nblk = (uint32_t)((pl.nbuckets + per_blk - 1) / per_blk);
-    // every bucket has at least one item (an empty bucket's item leaves infinity for the reduce), plus one per T entries
-    const size_t items_cap = pl.nbuckets + (entries_cap >> pl.logT) + 1;
+    // every bucket has at least one item (an empty bucket's item leaves infinity for the reduce), plus one per S entries of the split ones
+    const size_t items_cap = pl.nbuckets + (entries_cap >> pl.logS) + 1;
     out.items_cap = items_cap;
     d.sched.ensure((size_t)(3 + msmk::SCHED_CLASSES) * nblk * 4);
     d.order.ensure(items_cap * 4);
     d.item_bucket.ensure(items_cap * 4);
-    d.merge_list.ensure(items_cap * 4);
+    d.merge_list.ensure((items_cap / msmk::MERGE_FAN + 1) * 4);   // level 0 of the merge tree: every FAN-th item of the split buckets
+    d.merge_list2.ensure((items_cap / msmk::MERGE_FAN + 1) * 4);  // the levels ping-pong between the two lists
     uint32_t* blk_e = (uint32_t*)d.sched.p;
     uint32_t* blk_i = blk_e + nblk;
     uint32_t* blk_max = blk_i + nblk;
     uint32_t* blk_cls = blk_max + nblk;
-    hipLaunchKernelGGL(msmk::k_sched1, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT | (pl.cls_shift << 8),
+    hipLaunchKernelGGL(msmk::k_sched1, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT | (pl.cls_shift << 8) | (pl.logS << 16),
                        nblk, blk_e, blk_i, blk_cls, blk_max);
     hipLaunchKernelGGL(msmk::k_sched2, dim3(1), dim3(1024), 0, s, nblk, blk_e, blk_i, blk_cls, (const uint32_t*)blk_max,
                        (uint32_t*)d.meta.p);
-    hipLaunchKernelGGL(msmk::k_sched3, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT | (pl.cls_shift << 8),
+    hipLaunchKernelGGL(msmk::k_sched3, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT | (pl.cls_shift << 8) | (pl.logS << 16),
                        nblk, (const uint32_t*)blk_e, (const uint32_t*)blk_i, (const uint32_t*)blk_cls, (uint32_t*)d.offsets.p,
                        (uint32_t*)d.woff.p, (uint32_t*)d.order.p, (uint32_t*)d.item_bucket.p, (uint32_t*)d.merge_list.p,
                        (uint32_t*)d.meta.p);
     // the merge launches are sized by the schedule's counts: one small read-back into pinned memory, waited for by read_schedule
-    HIP_TRY(hipMemcpyAsync(d.h_meta, d.meta.p, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(d.h_meta, d.meta.p, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(d.ev[ev0 + 3], s));
 }
 
@@ -347,6 +368,7 @@ void read_schedule(DevState& d, int ev0, SortOut& out) {
     out.max_items = d.h_meta[1];
     out.entries = d.h_meta[2];
     out.nlist = d.h_meta[3];
+    out.nsplit = d.h_meta[4];
     if (out.nitems > out.items_cap) throw HipFail{"schedule produced more work items than its bound"};
 }
 

@@ -491,9 +491,15 @@ __global__ void __launch_bounds__(256) k_mid_scatter(const uint2* __restrict__ c
 // per_blk/1024 consecutive ones.  item id of (bucket b, chunk k) = woff[b] + k.
 constexpr int SCHED_CLASSES = 65;
 
-__device__ __forceinline__ uint32_t items_of(uint32_t cnt, uint32_t logT) {
-    return cnt == 0 ? 1u : (cnt + (1u << logT) - 1u) >> logT;
+// A bucket of up to T = 2^logT entries is ONE item; a fuller one is split into items of S = 2^logS entries, S = max(16, T / 4) (round 4: it
+// was T).  Skewed scalars (witness bits: half the scalars are 0 or 1) put 10^5..10^6 entries into one bucket; with items of T = 64 a lane
+// then walked 64 dependent additions (0.9 ms) while most of the machine idled; items of 16 finish in 0.2 ms and are merged by k_merge's
+// fan-in tree.  The launch packs logT | class shift << 8 | logS << 16 into one argument; item_range (curve_kernels.cuh) applies the same rule.
+__device__ __forceinline__ uint32_t items_of(uint32_t cnt, uint32_t logT, uint32_t logS) {
+    return cnt <= (1u << logT) ? 1u : (cnt + (1u << logS) - 1u) >> logS;
 }
+// entries of a bucket's LAST item (the others are full: S entries)
+__device__ __forceinline__ uint32_t last_len(uint32_t cnt, uint32_t it, uint32_t logS) { return it > 1 ? cnt - ((it - 1) << logS) : cnt; }
 // length class 0..64 of an item: len >> cls_shift, clamped.  The class width follows the TYPICAL item (twice the mean bucket load
 // spans the 64 classes), not T: when T is raised for a long kernel the ordinary buckets must still be sorted to a few entries,
 // or the lanes of a wave walk items of visibly different lengths (measured +8 % on the accumulate kernel at 2^24).
@@ -510,16 +516,16 @@ __global__ void __launch_bounds__(1024) k_sched1(const uint32_t* __restrict__ hi
     __syncthreads();
     uint32_t per_t = per_blk >> 10;
     uint32_t lo = blk * per_blk + t * per_t, hi = lo + per_t < m ? lo + per_t : m;
-    const uint32_t cls_shift = logT >> 8;   // the launch packs (class shift << 8) | log2 T
+    const uint32_t cls_shift = (logT >> 8) & 0xffu, logS = (logT >> 16) & 0xffu;   // the launch packs log2 T | class shift << 8 | log2 S << 16
     logT &= 0xffu;
-    uint32_t sum_e = 0, sum_i = 0, mx = 1, T = 1u << logT;
+    uint32_t sum_e = 0, sum_i = 0, mx = 1;
     for (uint32_t k = lo; k < hi; k++) {
-        uint32_t h = hist[k], it = items_of(h, logT);
+        uint32_t h = hist[k], it = items_of(h, logT, logS);
         sum_e += h;
         sum_i += it;
         mx = it > mx ? it : mx;
         if (it > 1) atomicAdd(&cls[64], it - 1);
-        atomicAdd(&cls[class_of(h - (it - 1) * T, cls_shift)], 1u);
+        atomicAdd(&cls[class_of(last_len(h, it, logS), cls_shift)], 1u);
     }
     atomicAdd(&se, sum_e);
     atomicAdd(&si, sum_i);
@@ -581,7 +587,9 @@ __global__ void __launch_bounds__(1024) k_sched2(uint32_t nblk, uint32_t* __rest
         meta[0] = b[255];  // total items   (a[], b[] are inclusive scans; entries past nblk are zero)
         meta[1] = mx;      // max items of any bucket
         meta[2] = a[255];  // total entries
-        meta[3] = 0;       // merge-list length, filled by k_sched3
+        meta[3] = 0;       // merge-list length (level 0 of the merge tree), filled by k_sched3
+        meta[4] = 0;       // number of split buckets, filled by k_sched3
+        for (uint32_t k = 5; k < MERGE_META; k++) meta[k] = 0;   // [8 + l]: list length of merge level l >= 1 (k_merge appends)
     }
 }
 
@@ -595,20 +603,20 @@ __global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hi
     __shared__ uint32_t pe[1024], pi[1024], cur[SCHED_CLASSES];
     // buckets split into many items (skewed scalars: one bucket can hold all N entries) are written out by the whole
     // workgroup after the per-lane pass; one lane doing it alone cost 0.65 ms for a bucket of 2^20 entries
-    constexpr uint32_t HV_CAP = 64, HV_MIN = 64;
+    constexpr uint32_t HV_CAP = 512, HV_MIN = 64;   // (64 slots until round 4: the 128 buckets of a 7-bit top window overflowed them, and a lone lane wrote 4096 items each — 1.2 ms)
     __shared__ uint32_t hv_k[HV_CAP], hv_run[HV_CAP], hv_it[HV_CAP], hv_pos[HV_CAP], hv_mp[HV_CAP], hv_n;
     uint32_t t = threadIdx.x, blk = blockIdx.x;
     if (t == 0) hv_n = 0;
     if (t < SCHED_CLASSES) cur[t] = blk_cls[t * nblk + blk];
     uint32_t per_t = per_blk >> 10;
     uint32_t lo = blk * per_blk + t * per_t, hi = lo + per_t < m ? lo + per_t : m;
-    const uint32_t cls_shift = logT >> 8;
+    const uint32_t cls_shift = (logT >> 8) & 0xffu, logS = (logT >> 16) & 0xffu;
     logT &= 0xffu;
-    uint32_t sum_e = 0, sum_i = 0, T = 1u << logT;
+    uint32_t sum_e = 0, sum_i = 0;
     for (uint32_t k = lo; k < hi; k++) {
         uint32_t h = hist[k];
         sum_e += h;
-        sum_i += items_of(h, logT);
+        sum_i += items_of(h, logT, logS);
     }
     pe[t] = sum_e;
     pi[t] = sum_i;
@@ -622,22 +630,24 @@ __global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hi
     }
     uint32_t run_e = blk_e[blk] + pe[t] - sum_e, run_i = blk_i[blk] + pi[t] - sum_i;
     for (uint32_t k = lo; k < hi; k++) {
-        uint32_t h = hist[k], it = items_of(h, logT);
+        uint32_t h = hist[k], it = items_of(h, logT, logS);
         offsets[k] = run_e;
         woff[k] = run_i;
         if (it > 1) {  // full-length chunks of a split bucket: one reservation in the longest class
             uint32_t pos = atomicAdd(&cur[64], it - 1);
-            uint32_t mp = atomicAdd(&meta[3], it);     // the merge passes only visit the items of split buckets
+            // the merge tree only visits the items of split buckets: level 0 lists every MERGE_FAN-th item of the bucket
+            uint32_t mp = atomicAdd(&meta[3], (it + MERGE_FAN - 1) / MERGE_FAN);
+            atomicAdd(&meta[4], 1u);
             uint32_t slot = it >= HV_MIN ? atomicAdd(&hv_n, 1u) : HV_CAP;
             if (slot < HV_CAP) {
                 hv_k[slot] = k; hv_run[slot] = run_i; hv_it[slot] = it; hv_pos[slot] = pos; hv_mp[slot] = mp;
             } else {
                 for (uint32_t j = 0; j + 1 < it; j++) { order[pos + j] = run_i + j; item_bucket[run_i + j] = k; }
-                for (uint32_t j = 0; j < it; j++) merge_list[mp + j] = run_i + j;
+                for (uint32_t j = 0; j < it; j += MERGE_FAN) merge_list[mp + j / MERGE_FAN] = run_i + j;
             }
         }
         uint32_t last = run_i + it - 1;
-        uint32_t pos = atomicAdd(&cur[class_of(h - (it - 1) * T, cls_shift)], 1u);
+        uint32_t pos = atomicAdd(&cur[class_of(last_len(h, it, logS), cls_shift)], 1u);
         order[pos] = last;
         item_bucket[last] = k;
         run_e += h;
@@ -650,7 +660,7 @@ __global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hi
         const uint32_t k = hv_k[s], r0 = hv_run[s], it = hv_it[s], pos = hv_pos[s], mp = hv_mp[s];
         for (uint32_t j = t; j < it; j += 1024) {
             if (j + 1 < it) { order[pos + j] = r0 + j; item_bucket[r0 + j] = k; }
-            merge_list[mp + j] = r0 + j;
+            if (j % MERGE_FAN == 0) merge_list[mp + j / MERGE_FAN] = r0 + j;
         }
     }
 }

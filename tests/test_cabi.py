@@ -218,7 +218,7 @@ def test_plan_geometry_invariants(pkg):
     assert pkg.test_plan(100_000_000, 0, "g1", True, 100_000_000)["c"] == 0
     # the sizes the benchmark configs use keep their measured choices
     # (round 4: with the scalar's sign folded into the digits c = 17 needs 15 windows, not 16, and wins from 2^22 up: 21.5 vs 22.1 ms at 2^23)
-    assert pkg.test_plan(1 << 20)["c"] == 16 and pkg.test_plan(1 << 21)["c"] == 16 and pkg.test_plan(1 << 23)["c"] == 17
+    assert pkg.test_plan(1 << 20)["c"] == 16 and pkg.test_plan(1 << 21)["c"] == 17 and pkg.test_plan(1 << 23)["c"] == 17   # 2^21: 5.71 (17) vs 6.02 ms (16)
     assert pkg.test_plan(1 << 23)["nwin"] == 15 and pkg.test_plan(1 << 16)["c"] == 15
     assert pkg.test_plan(1 << 24)["c"] == 20 and pkg.test_plan(1 << 24)["serial"] == 1 and pkg.test_plan(1 << 24)["serial_L"] == 53
     assert pkg.test_plan(1 << 20, 0, "g2")["c"] == 16
