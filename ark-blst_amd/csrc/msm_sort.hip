@@ -342,8 +342,10 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
     d.sched.ensure((size_t)(3 + msmk::SCHED_CLASSES) * nblk * 4);
     d.order.ensure(items_cap * 4);
     d.item_bucket.ensure(items_cap * 4);
-    d.merge_list.ensure((items_cap / msmk::MERGE_FAN + 1) * 4);   // level 0 of the merge tree: every FAN-th item of the split buckets
-    d.merge_list2.ensure((items_cap / msmk::MERGE_FAN + 1) * 4);  // the levels ping-pong between the two lists
+    // level 0 of the merge tree lists every FAN-th item of the split buckets: sum ceil(items_b / FAN) <= items / FAN + 3/4 per split bucket; a split
+    // bucket has at least 3 items (more than T >= 2 S entries), so the list never exceeds items / 2.  The levels ping-pong between two lists.
+    d.merge_list.ensure((items_cap / 2 + 1) * 4);
+    d.merge_list2.ensure((items_cap / 2 + 1) * 4);
     uint32_t* blk_e = (uint32_t*)d.sched.p;
     uint32_t* blk_i = blk_e + nblk;
     uint32_t* blk_max = blk_i + nblk;
@@ -369,6 +371,7 @@ void read_schedule(DevState& d, int ev0, SortOut& out) {
     out.entries = d.h_meta[2];
     out.nlist = d.h_meta[3];
     out.nsplit = d.h_meta[4];
+    if ((uint64_t)out.nlist > out.items_cap / 2 + 1) throw HipFail{"schedule produced a longer merge list than its bound"};
     if (out.nitems > out.items_cap) throw HipFail{"schedule produced more work items than its bound"};
 }
 

@@ -133,6 +133,35 @@ def test_g1_msm_skewed_scalars(ctx, co, o, pkg, kind):
         assert prof["max_items_per_bucket"] > 1  # the split/merge path really ran
 
 
+@pytest.mark.parametrize("group,n,c,vals", [("g1", 8192, 10, 240), ("g1", 40000, 12, 500), ("g2", 4096, 9, 100)])
+def test_many_slightly_overfull_buckets(ctx, co, pkg, group, n, c, vals):
+    """Every window's digit drawn from `vals` of the 2^(c-1) values: the used buckets hold about twice the mean the plan expects —
+    just over its item size T — so that HUNDREDS of buckets are each cut into three or four short items.  That is the dense-list
+    path of the merge tree with many small split buckets (the skewed tests above have a few giant ones) and the case that decides
+    how long the schedule's merge list can get."""
+    rnd = random.Random(77)
+    W = -(-255 // c)
+    top_bits = 254 - c * (W - 1)
+    sc = []
+    for _ in range(n):
+        s = 0
+        for w in range(W - 1):
+            s |= rnd.randrange(1, vals + 1) << (c * w)       # raw window value <= 2^(c-1): no negative digit, no carry
+        s |= rnd.randrange(1, min(vals, (1 << max(top_bits - 1, 1)) - 1) + 1) << (c * (W - 1))
+        sc.append(s)
+    ss = b"".join(x.to_bytes(32, "little") for x in sc)
+    bases = co.gen_bases(group, SEED_B + 9, n, 4)
+    ctx.set_window_bits(c)
+    try:
+        got = ctx.msm(group, bases, ss, n, pkg.SCALAR_CANONICAL)
+        prof = ctx.profile()
+    finally:
+        ctx.set_window_bits(0)
+    assert _canon(co, group, got) == co.dlog_expected(group, ss, SEED_B + 9, n)
+    assert prof["window_bits"] == c and prof["max_items_per_bucket"] >= 3   # buckets were split, into few items each
+    assert prof["work_items"] > 2 * vals * (W - 1)                          # ... and many of them were
+
+
 def test_g1_resident_bases_and_prefix(ctx, co, pkg):
     n = 4096
     bases = co.gen_bases("g1", SEED_B, n, 4)
