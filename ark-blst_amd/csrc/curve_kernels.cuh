@@ -55,7 +55,7 @@ __device__ __forceinline__ void load_point(typename C::F::E& x, typename C::F::E
 __device__ __forceinline__ void item_range(const uint32_t* __restrict__ offsets, uint32_t b, uint32_t k, uint32_t packed, uint32_t& e, uint32_t& end) {
     const uint32_t logT = packed & 0xffu, logS = (packed >> 16) & 0xffu;
     const uint32_t beg = offsets[b], bend = offsets[b + 1];
-    const uint32_t lg = bend - beg > (1u << logT) ? logS : logT;
+    const uint32_t lg = item_size_log(bend - beg, logT, logS);
     e = beg + (k << lg);
     end = e + (1u << lg) < bend ? e + (1u << lg) : bend;
 }

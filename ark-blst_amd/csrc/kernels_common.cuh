@@ -227,6 +227,11 @@ constexpr uint32_t MERGE_FAN = 4;   // fan-in of one level of the merge of split
 // [4] split buckets, [8 + l] merge list length of level l >= 1
 constexpr uint32_t MERGE_META = 32;
 
+// Item geometry of the schedule, ONE definition for the kernels that build the items (sort_kernels.cuh) and the ones that walk them
+// (curve_kernels.cuh): a bucket of up to T = 2^logT entries is one item, a fuller one is cut into items of S = 2^logS entries.
+// Launches pack logT | (class shift << 8) | (logS << 16) into one argument.
+__device__ __forceinline__ uint32_t item_size_log(uint32_t cnt, uint32_t logT, uint32_t logS) { return cnt > (1u << logT) ? logS : logT; }
+
 __device__ __forceinline__ uint32_t scalar_bits(const uint32_t (&s)[8], uint32_t off, uint32_t c) {
     uint32_t w = off >> 5, sh = off & 31;
     uint32_t lo = 0, hi = 0;

@@ -496,7 +496,8 @@ constexpr int SCHED_CLASSES = 65;
 // then walked 64 dependent additions (0.9 ms) while most of the machine idled; items of 16 finish in 0.2 ms and are merged by k_merge's
 // fan-in tree.  The launch packs logT | class shift << 8 | logS << 16 into one argument; item_range (curve_kernels.cuh) applies the same rule.
 __device__ __forceinline__ uint32_t items_of(uint32_t cnt, uint32_t logT, uint32_t logS) {
-    return cnt <= (1u << logT) ? 1u : (cnt + (1u << logS) - 1u) >> logS;
+    const uint32_t lg = item_size_log(cnt, logT, logS);
+    return cnt == 0 ? 1u : (cnt + (1u << lg) - 1u) >> lg;   // an empty bucket keeps one (empty) item: it leaves infinity for the reduce
 }
 // entries of a bucket's LAST item (the others are full: S entries)
 __device__ __forceinline__ uint32_t last_len(uint32_t cnt, uint32_t it, uint32_t logS) { return it > 1 ? cnt - ((it - 1) << logS) : cnt; }
