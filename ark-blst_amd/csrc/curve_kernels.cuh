@@ -501,7 +501,8 @@ template <> struct CoopOf<G2C> { using RS = PairG2; using CS = OctG2; };   // th
 // LP_0 = L * S there, LOG_LL times, which gives K * S without a single extra step ("rider").
 template <class CS>
 __global__ void __launch_bounds__(64, CS::MAX_OCC) k_reduce_coop(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ woff,
-                                                                 uint32_t* __restrict__ pairs, uint32_t L, uint32_t nb, uint32_t cpw) {
+                                                                 const uint32_t* __restrict__ offsets, uint32_t* __restrict__ pairs, uint32_t L,
+                                                                 uint32_t nb, uint32_t cpw) {
     using Pt = typename CS::Pt;
     constexpr int NLL = 1 << CS::LOG_LL, BK = Geo<typename CS::C>::BK_WORDS;
     const uint32_t chunk = blockIdx.x, ll = CS::ll();
@@ -510,6 +511,18 @@ __global__ void __launch_bounds__(64, CS::MAX_OCC) k_reduce_coop(const uint32_t*
     const uint32_t cnt = first >= nb ? 0u : (nb - first < L ? nb - first : L);
     const uint32_t* wp = woff + (size_t)w * nb + (cnt ? first : 0u);            // bucket b lives at partial[woff[b]]; only rel < cnt is dereferenced as such
     Pt run = CS::inf(), acc = CS::inf(), LP = CS::inf();
+    // A chunk without a single entry (offsets[] are the buckets' entry prefix sums) is done: both sums are infinity.  Scalars of a few
+    // dozen bits leave most windows empty (64-bit values: 11 of 16 windows at c = 16; witness bits: 15), and their chunks' waves would
+    // otherwise walk the whole latency chain next to the few that have work.
+    {
+        const uint32_t* op = offsets + (size_t)w * nb + (cnt ? first : 0u);
+        const uint32_t mine = cnt ? op[cnt] - op[0] : 0u;
+        if (__ballot(mine != 0) == 0) {
+            if (ll == NLL - 1) CS::store(pairs + (size_t)(2 * chunk) * BK, acc);
+            if (ll == 0) CS::store(pairs + (size_t)(2 * chunk + 1) * BK, acc);
+            return;
+        }
+    }
     int top = 0;                                                                 // index of L's top bit
     while ((L >> top) > 1u) top++;
     uint32_t chain = 0;
@@ -592,7 +605,8 @@ __global__ void __launch_bounds__(64, CS::MAX_OCC) k_reduce_coop(const uint32_t*
 // pairs of a level.  L S comes from S by the double-and-add chain of L's bits (S parked in LDS once T has been written out).
 template <class C>
 __global__ void __launch_bounds__(64, 2) k_reduce_serial(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ woff,
-                                                        uint32_t nlanes, uint32_t L, uint32_t nb, uint32_t lpw, uint32_t* __restrict__ pairs) {
+                                                        const uint32_t* __restrict__ offsets, uint32_t nlanes, uint32_t L, uint32_t nb,
+                                                        uint32_t lpw, uint32_t* __restrict__ pairs) {
     using F = typename C::F;
     using FR = typename C::FR;
     using E = typename F::E;
@@ -606,6 +620,16 @@ __global__ void __launch_bounds__(64, 2) k_reduce_serial(const uint32_t* __restr
     const uint32_t w = g / lpw, j = g - w * lpw;
     const uint32_t first = j * L, cnt = nb - first < L ? nb - first : L;   // this lane's buckets: first .. first + cnt - 1 of window w
     const uint32_t* wp = woff + (size_t)w * nb + first;
+    {   // a wave whose lanes' buckets hold no entry at all (empty windows of short scalars) writes infinity pairs and leaves (cf. k_reduce_coop)
+        const uint32_t* op = offsets + (size_t)w * nb + first;
+        if (__ballot(op[cnt] != op[0]) == 0) {
+            if (live) {
+                store_bucket<C>(pairs + (size_t)(2 * g) * BK, ec::proj_inf<F>());
+                store_bucket<C>(pairs + (size_t)(2 * g + 1) * BK, ec::proj_inf<F>());
+            }
+            return;
+        }
+    }
     auto park_store = [&](const PJ& p) {
         ElemIO<E>::store(park + (0 * 64 + lane) * SLOT, p.x);
         ElemIO<E>::store(park + (1 * 64 + lane) * SLOT, p.y);

@@ -201,14 +201,15 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     if constexpr (std::is_same<C, msmk::G1C>::value) {   // the throughput form exists for G1 only (HostCurve<G2C>::cost() never asks for it)
         if (pl.serial_reduce) {
             hipLaunchKernelGGL(msmk::k_reduce_serial<C>, dim3((uint32_t)((pl.nchunks + 63) / 64)), dim3(64), 0, s, (const uint32_t*)d.partial.p,
-                               (const uint32_t*)d.woff.p, (uint32_t)pl.nchunks, pl.serial_L, pl.nb, pl.chunks_per_win, (uint32_t*)d.pairs.p);
+                               (const uint32_t*)d.woff.p, (const uint32_t*)d.offsets.p, (uint32_t)pl.nchunks, pl.serial_L, pl.nb, pl.chunks_per_win,
+                               (uint32_t*)d.pairs.p);
             reduced = true;
         }
     }
     if (!reduced) {
         if (pl.serial_reduce) throw HipFail{"serial reduce requested for a curve without it"};
         hipLaunchKernelGGL(msmk::k_reduce_coop<RS>, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
-                           (const uint32_t*)d.woff.p, (uint32_t*)d.pairs.p, pl.coop_L, pl.nb, pl.chunks_per_win);
+                           (const uint32_t*)d.woff.p, (const uint32_t*)d.offsets.p, (uint32_t*)d.pairs.p, pl.coop_L, pl.nb, pl.chunks_per_win);
     }
     HIP_TRY(hipEventRecord(d.ev[ev0 + 5], s));
     uint32_t* jac_dev = (uint32_t*)((char*)d.pairs2.p + d.pairs2.cap - (size_t)pl.bwin * jac_bytes<C>());
