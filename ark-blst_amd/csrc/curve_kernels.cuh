@@ -536,23 +536,35 @@ __global__ void __launch_bounds__(64, CS::MAX_OCC) k_reduce_coop(const uint32_t*
     // lane loads bucket 0 of its range in place of the missing ones and replaces the value by infinity.
     auto index_of = [&](uint32_t rel) { return wp[rel < cnt ? rel : 0u]; };
     auto bucket_of = [&](uint32_t idx, uint32_t rel) { return CS::select(rel < cnt, CS::inf(), CS::load(partial + (size_t)idx * BK)); };
+    // Steps of the running sums whose second operand is infinity in EVERY logical lane of the wave are skipped (the sum is unchanged):
+    // "bucket t holds an entry" comes from the entry offsets, "run may be non-zero" follows from it.  Dense chunks never skip; a window
+    // with a handful of occupied buckets (witness bits: one) runs the 13 + LOG_LL closing steps and little else instead of all 2 L + ...
+    const uint32_t* opw = offsets + (size_t)w * nb + (cnt ? first : 0u);
+    auto full_of = [&](uint32_t rel) { return rel < cnt && opw[rel + 1] != opw[rel]; };
     Pt nbk = bucket_of(index_of(L - 1), L - 1);
+    bool nbf = full_of(L - 1);
     uint32_t idx2 = L > 1 ? index_of(L - 2) : 0u;
+    bool f2 = L > 1 && full_of(L - 2);
+    bool fr = false;   // this lane's `run` may be non-zero
 #pragma unroll 1
     for (uint32_t s = 0; s < s_end; s++) {
         Pt A, B;
         uint32_t dst;  // 0 run, 1 acc, 2 LP
         if (s < s_scan) {
+            bool fB;
             if ((s & 1u) == 0) {
                 const uint32_t p = s >> 1;
-                A = run; B = nbk; dst = 0;
+                A = run; B = nbk; dst = 0; fB = nbf;
                 if (p + 1 < L) {
                     nbk = bucket_of(idx2, L - 2 - p);
-                    if (p + 2 < L) idx2 = index_of(L - 3 - p);
+                    nbf = f2;
+                    if (p + 2 < L) { idx2 = index_of(L - 3 - p); f2 = full_of(L - 3 - p); }
                 }
+                fr = fr || fB;
             } else {
-                A = acc; B = run; dst = 1;
+                A = acc; B = run; dst = 1; fB = fr;
             }
+            if (__ballot(fB) == 0) continue;
         } else if (s < s_dbl) {
             int d = 1 << (s - s_scan);
             A = run;
