@@ -22,5 +22,6 @@ from .binding import (  # noqa: F401
     g2_sum,
     lib_path,
     load_library,
+    profile_dict,
 )
 from .msm import G1Projective, G2Projective  # noqa: F401

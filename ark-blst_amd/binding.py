@@ -28,6 +28,10 @@ class Profile(C.Structure):
         ("work_items", C.c_uint32), ("max_items_per_bucket", C.c_uint32)]
 
 
+def profile_dict(p: Profile) -> dict:
+    return {f: getattr(p, f) for f, _ in Profile._fields_}
+
+
 class PairingProfile(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("h2d_ms", "lines_ms", "accumulate_ms", "miller_ms", "tree_ms", "host_ms", "total_ms")] + [
         ("n", C.c_uint64), ("pairs_per_accumulator", C.c_uint32), ("reserved", C.c_uint32)]
@@ -245,9 +249,13 @@ class Context:
         return out.raw
 
     def profile(self) -> dict:
+        return profile_dict(self.profile_raw())
+
+    def profile_raw(self) -> Profile:
+        """The last call's profile as the C struct (a few microseconds: for timed loops; profile_dict() turns it into a dict later)."""
         p = Profile()
         self._check(self._L.mi_msm_last_profile(self._h, C.byref(p)), "mi_msm_last_profile")
-        return {f: getattr(p, f) for f, _ in Profile._fields_}
+        return p
 
     def pairing_profile(self) -> dict:
         p = PairingProfile()
