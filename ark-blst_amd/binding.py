@@ -77,6 +77,7 @@ def load_library(test_hooks: bool = False):
         L.mi_multi_pairing.argtypes = [vp, vp, vp, sz, vp]
         L.mi_final_exponentiation.argtypes = [vp, vp]
         L.mi_msm_set_window_bits.argtypes = [vp, u]
+        L.mi_msm_set_profile_level.argtypes = [vp, i]
         L.mi_msm_last_profile.argtypes = [vp, C.POINTER(Profile)]
         if hasattr(L, "mi_pairing_last_profile"):
             L.mi_pairing_last_profile.argtypes = [vp, C.POINTER(PairingProfile)]
@@ -149,6 +150,10 @@ class Context:
 
     def set_window_bits(self, c: int):
         self._check(self._L.mi_msm_set_window_bits(self._h, c), "mi_msm_set_window_bits")
+
+    def set_profile_level(self, level: int):
+        """0: no timing events, 1 (default): the accumulate kernel's interval only, 2: every phase of mi_profile."""
+        self._check(self._L.mi_msm_set_profile_level(self._h, level), "mi_msm_set_profile_level")
 
     def set_bases(self, group: str, bases, n: int):
         p, keep = _buf(bases)

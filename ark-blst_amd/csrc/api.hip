@@ -239,6 +239,13 @@ int mi_msm_set_window_bits(mi_ctx* ctx, unsigned window_bits) {
     return MI_OK;
 }
 
+int mi_msm_set_profile_level(mi_ctx* ctx, int level) {
+    if (!ctx || level < 0 || level > 2) return fail(ctx, MI_E_INVALID, "profile level must be 0, 1 or 2");
+    LaneLock lk(ctx, true);
+    ctx->profile_level = level;
+    return MI_OK;
+}
+
 int mi_msm_last_profile(const mi_ctx* ctx, mi_profile* out) {
     if (!ctx || !out) return MI_E_INVALID;
     std::lock_guard<std::mutex> lk(ctx->info_mu);

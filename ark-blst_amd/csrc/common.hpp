@@ -116,6 +116,7 @@ struct DevState {
     size_t h_pairs_cap = 0;
     uint32_t* h_meta = nullptr;   // pinned, 32 B
     mi_profile prof{};
+    int prof_level = 1;   // copied from the context at the start of a call (mi_msm_set_profile_level): which events the pipeline records
 
     void ensure_host(size_t bytes) {
         if (bytes <= h_pairs_cap) return;
@@ -206,6 +207,7 @@ struct mi_ctx {
     bool lane_busy[mi::NLANES] = {false, false};
     mutable std::mutex info_mu;                                  // prof / err
     unsigned forced_c = 0;
+    int profile_level = 1;   // 0: no timing events beyond the one the pipeline waits on; 1: + the accumulate kernel's interval; 2: every phase
     mi_profile prof{};
     mi_pairing_profile pprof{};
     std::string err;

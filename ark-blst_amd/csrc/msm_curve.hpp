@@ -194,7 +194,8 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
                                (const uint32_t*)(l == 0 ? meta + 3 : meta + 8 + l), lists[(l + 1) & 1], meta + 8 + l + 1, (uint32_t)dd);
         }
     }
-    HIP_TRY(hipEventRecord(d.ev[ev0 + 4], s));
+    const bool phases = d.prof_level >= 2;   // see sort_and_schedule
+    if (d.prof_level >= 1) HIP_TRY(hipEventRecord(d.ev[ev0 + 4], s));
     // bucket reduction: one wave per chunk of chunk_buckets buckets -> (K S, T) pairs; then the per-window combine, 2^LOG_LL pairs per
     // wave and level, down to one Jacobian point per window
     bool reduced = false;
@@ -211,7 +212,7 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
         hipLaunchKernelGGL(msmk::k_reduce_coop<RS>, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
                            (const uint32_t*)d.woff.p, (const uint32_t*)d.offsets.p, (uint32_t*)d.pairs.p, pl.coop_L, pl.nb, pl.chunks_per_win);
     }
-    HIP_TRY(hipEventRecord(d.ev[ev0 + 5], s));
+    if (phases) HIP_TRY(hipEventRecord(d.ev[ev0 + 5], s));
     uint32_t* jac_dev = (uint32_t*)((char*)d.pairs2.p + d.pairs2.cap - (size_t)pl.bwin * jac_bytes<C>());
     {
         uint32_t cpw = pl.chunks_per_win;
@@ -227,7 +228,7 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
             cpw = cpw_out;
         }
     }
-    HIP_TRY(hipEventRecord(d.ev[ev0 + 6], s));
+    if (phases) HIP_TRY(hipEventRecord(d.ev[ev0 + 6], s));
     if (wo) {   // the window sums stay on the device (the caller exchanges them: mi_msm_g1_device_windows); no fold here
         HIP_TRY(hipMemcpyAsync(wo->d_out, jac_dev, (size_t)pl.bwin * jac_bytes<C>(), hipMemcpyDeviceToDevice, s));
         wo->info.window_bits = pl.c;
@@ -235,17 +236,19 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     } else {
         HIP_TRY(hipMemcpyAsync(d.h_pairs, jac_dev, (size_t)pl.bwin * jac_bytes<C>(), hipMemcpyDeviceToHost, s));
     }
-    HIP_TRY(hipEventRecord(d.ev[ev0 + 7], s));
+    if (phases) HIP_TRY(hipEventRecord(d.ev[ev0 + 7], s));
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipGetLastError());
 
-    d.prof.digits_ms += ev_ms(d.ev[ev0], d.ev[ev0 + 1]);      // digits + coarse partition (4 kernels)
-    d.prof.scatter_ms += ev_ms(d.ev[ev0 + 1], d.ev[ev0 + 2]);  // fine sort in LDS
-    d.prof.scan_ms += ev_ms(d.ev[ev0 + 2], d.ev[ev0 + 3]);     // schedule (3 kernels)
-    d.prof.accumulate_ms += ev_ms(d.ev[ev0 + 3], d.ev[ev0 + 4]);
-    d.prof.reduce_ms += ev_ms(d.ev[ev0 + 4], d.ev[ev0 + 5]);
-    d.prof.combine_ms += ev_ms(d.ev[ev0 + 5], d.ev[ev0 + 6]);
-    d.prof.d2h_ms += ev_ms(d.ev[ev0 + 6], d.ev[ev0 + 7]);
+    if (phases) {
+        d.prof.digits_ms += ev_ms(d.ev[ev0], d.ev[ev0 + 1]);      // digits + coarse partition (4 kernels)
+        d.prof.scatter_ms += ev_ms(d.ev[ev0 + 1], d.ev[ev0 + 2]);  // fine sort in LDS
+        d.prof.scan_ms += ev_ms(d.ev[ev0 + 2], d.ev[ev0 + 3]);     // schedule (3 kernels)
+        d.prof.reduce_ms += ev_ms(d.ev[ev0 + 4], d.ev[ev0 + 5]);
+        d.prof.combine_ms += ev_ms(d.ev[ev0 + 5], d.ev[ev0 + 6]);
+        d.prof.d2h_ms += ev_ms(d.ev[ev0 + 6], d.ev[ev0 + 7]);
+    }
+    if (d.prof_level >= 1) d.prof.accumulate_ms += ev_ms(d.ev[ev0 + 3], d.ev[ev0 + 4]);   // the accumulate kernel and the merges of split buckets
     d.prof.accumulate_adds += so.entries;
     d.prof.work_items = nitems;
     d.prof.max_items_per_bucket = max_items;
@@ -264,6 +267,7 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
     using J = typename HostCurve<C>::J;
     HIP_TRY(hipSetDevice(d.dev));
     d.prof = mi_profile{};
+    d.prof_level = ctx->profile_level;
     auto t0 = std::chrono::steady_clock::now();
     J total = J::inf();
     if (n == 0) return total;
@@ -287,7 +291,7 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
     } drain{d};
     for (size_t lo = 0; lo < n; lo += part_max) {   // one pass unless n exceeds the per-pass limit
         const size_t m = std::min(part_max, n - lo);
-        HIP_TRY(hipEventRecord(d.ev[0], s));
+        if (d.prof_level >= 2) HIP_TRY(hipEventRecord(d.ev[0], s));
         // Host slices (the trait's call shape) cross PCIe in chunks on the lane's copy stream, each consumed as it lands: bases first
         // (k_ingest per chunk), then the scalars (count pass of the sort per chunk, inside sort_and_schedule).
         const uint32_t* d_scalars;
@@ -320,11 +324,11 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
                     ingest<C>(d, (const char*)d.raw.p + p0 * aff_bytes<C>(), true, p1 - p0, (uint32_t*)d.call_bases.p + p0 * msmk::Geo<C>::PT_WORDS,
                               (uint8_t*)d.call_flags.p + p0);
             }
-            HIP_TRY(hipEventRecord(d.ev[1], s));
+            if (d.prof_level >= 2) HIP_TRY(hipEventRecord(d.ev[1], s));
             d_bases = reinterpret_cast<const uint32_t*>(d.call_bases.p);
             d_flags = reinterpret_cast<const uint8_t*>(d.call_flags.p);
         } else {
-            HIP_TRY(hipEventRecord(d.ev[1], s));
+            if (d.prof_level >= 2) HIP_TRY(hipEventRecord(d.ev[1], s));
             d_bases = reinterpret_cast<const uint32_t*>(res.buf.p) + (r0 + lo) * msmk::Geo<C>::PT_WORDS;
             d_flags = reinterpret_cast<const uint8_t*>(res.flags.p) + r0 + lo;
         }
@@ -332,7 +336,7 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
         total = lo == 0 ? r : total.add(r);
         // h2d_ms: bases (their chunks interleave with k_ingest on the main stream) + scalars (copy stream, first to last chunk; the
         // sort's count pass runs underneath, so digits_ms of a host-scalar call includes waiting for the chunks)
-        d.prof.h2d_ms += ev_ms(d.ev[0], d.ev[1]) + (host_scalars ? ev_ms(d.cev[0], d.cev[9]) : 0.0);
+        if (d.prof_level >= 2) d.prof.h2d_ms += ev_ms(d.ev[0], d.ev[1]) + (host_scalars ? ev_ms(d.cev[0], d.cev[9]) : 0.0);
     }
     d.prof.n = n;
     d.prof.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

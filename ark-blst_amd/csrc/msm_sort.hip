@@ -199,7 +199,9 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
     if (!d.h_meta) HIP_TRY(hipHostMalloc((void**)&d.h_meta, 32, hipHostMallocDefault));
 
     hipStream_t s = d.stream;
-    HIP_TRY(hipEventRecord(d.ev[ev0], s));
+    // phase events only on request (profile level 2): each record leaves the device idle for ~6 us between two kernels
+    const bool phases = d.prof_level >= 2;
+    if (phases) HIP_TRY(hipEventRecord(d.ev[ev0], s));
     // ---- two-level LDS-staged bucket sort (geometry in msmk::SortGeom)
     // The count pass, per chunk of tiles: with host scalars chunk j is copied on the copy stream and counted as soon as it has
     // landed, while chunk j + 1 is still crossing PCIe; device-resident scalars are one chunk.
@@ -320,7 +322,7 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
         launch_coarse<true>(pl.c, dim3(g.tiles, g.ngroups), dim3(coarse_block), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
                             (const uint32_t*)d.tileoff.p, (const uint32_t*)d.bin_base.p, (uint32_t*)d.coarse.p);
     }
-    HIP_TRY(hipEventRecord(d.ev[ev0 + 1], s));
+    if (phases) HIP_TRY(hipEventRecord(d.ev[ev0 + 1], s));
     // fine sort over bin segments
     hipLaunchKernelGGL(msmk::k_seg_count, dim3((g.nbins + 255) / 256), dim3(256), 0, s, (const uint32_t*)d.bin_base.p, g.nbins,
                        (uint32_t*)d.seg_cnt.p);
@@ -331,7 +333,7 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
                        (uint32_t*)d.segoff.p, (uint32_t*)d.hist.p);
     hipLaunchKernelGGL(msmk::k_fine_scatter, dim3(segs_cap), dim3(256), 0, s, (const uint32_t*)d.coarse.p, (const uint32_t*)d.bin_base.p,
                        (const uint32_t*)d.seg_base.p, g, (const uint32_t*)d.segcnt.p, (const uint32_t*)d.segoff.p, (uint32_t*)d.sorted.p);
-    HIP_TRY(hipEventRecord(d.ev[ev0 + 2], s));
+    if (phases) HIP_TRY(hipEventRecord(d.ev[ev0 + 2], s));
     // ---- schedule: <= 256 blocks of 1024 lanes, each lane owning per_blk/1024 consecutive buckets
     uint32_t per_blk = 4096;
     while ((pl.nbuckets + per_blk - 1) / per_blk > 256) per_blk <<= 1;

@@ -214,6 +214,11 @@ int mi_g2_fold_windows(const mi_g2 *windows, size_t n_ranks, size_t rank_stride,
 
 /* Tuning / introspection. window_bits = 0 restores the built-in heuristic (cf. calc_window_size, src/gpu.rs:218-223). */
 int mi_msm_set_window_bits(mi_ctx *ctx, unsigned window_bits);
+/* Which timing events an MSM call records (every record leaves the device idle for ~6 us between two kernels — 5 % of a 2^16-point call):
+ * 0 = none beyond the one the pipeline itself waits on; 1 (default) = the accumulate kernel's interval (mi_profile.accumulate_ms, total_ms,
+ * host_fold_ms and the counters are filled, the other phase times are 0); 2 = every phase (digits, scatter, scan, reduce, combine, d2h, h2d).
+ * No counterpart in the reference (its driver has no instrumentation, src/gpu.rs:101-241). */
+int mi_msm_set_profile_level(mi_ctx *ctx, int level);
 int mi_msm_last_profile(const mi_ctx *ctx, mi_profile *out);
 /* Text of the CALLING THREAD's most recent failure (thread-local storage: the pointer stays valid until the same thread
  * fails again, whatever other threads do on the context). */

@@ -14,6 +14,7 @@ bases = co.gen_bases("g1", 5, N, 16)
 scalars = co.gen_scalars(6, N)
 res = {}
 with pkg.Context([0]) as ctx:
+    ctx.set_profile_level(2)   # every phase's events (the default records the accumulate kernel's interval only)
     def run(name, b, s, n, check=True):
         ctx.set_bases("g1", b, n)
         d = torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda(); torch.cuda.synchronize()

@@ -23,6 +23,7 @@ scalars = co.gen_scalars(78, nmax)
 d = torch.frombuffer(bytearray(scalars), dtype=torch.uint8).cuda()
 torch.cuda.synchronize()
 with pkg.Context([0]) as ctx:
+    ctx.set_profile_level(2)   # every phase's events (the default records the accumulate kernel's interval only)
     ctx.set_bases(g, bases, nmax)
     for ln in range(lo, hi + 1):
         n = 1 << ln
