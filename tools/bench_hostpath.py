@@ -16,6 +16,7 @@ scalars = co.gen_scalars(6, n)
 want = co.dlog_expected("g1", scalars, 5, n)
 out = {"n": n}
 with pkg.Context([0]) as ctx:
+    ctx.set_profile_level(2)   # every phase's events
     def timeit(fn, reps=5):
         fn(); best = 1e9
         for _ in range(reps):
