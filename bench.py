@@ -531,6 +531,23 @@ def _in_process_leg(pkg, co, torch, ncpu, slots: int, log_n: int, steps: int) ->
     return out
 
 
+def _in_process_isolated(pkg, co, torch, ncpu, slots: int) -> dict:
+    """The in-library multi-device leg.  With ONE visible GPU it runs here (device 0 listed twice: the plumbing every round has
+    tested).  With several it sees distinct physical devices — peer access, one resident shard and one host thread per GPU — for the first
+    time on whatever node runs this, so it runs in a child process (started, not exec'ed): a fault there costs this leg, not the line."""
+    if torch.cuda.device_count() <= 1:
+        return _in_process_leg(pkg, co, torch, ncpu, slots, 20, 5)
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--in-process-child", "--in-process", str(slots)],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"child process rc={r.returncode}", "stderr_tail": r.stderr[-600:]}
+    out = json.loads(lines[-1])
+    out["isolated_in_child_process"] = True
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -551,6 +568,7 @@ def main() -> None:
     ap.add_argument("--in-process", type=int, default=0, metavar="SLOTS",
                     help="N = 1 only: device slots of the in-library multi-GPU leg of the secondary set (default: every visible GPU, at most 8; "
                          "device 0 twice on a one-GPU box)")
+    ap.add_argument("--in-process-child", action="store_true", help=argparse.SUPPRESS)   # runs ONLY the in-library multi-device leg (see _in_process_isolated)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device rehearses the N>1 path on a single-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (rehearsal only)")
@@ -608,6 +626,9 @@ def main() -> None:
     pkg = ge.load_package()
     g = args.group
     ncpu = _host_threads()
+    if args.in_process_child:   # child of _in_process_isolated: this leg only, one JSON line
+        print(json.dumps(_in_process_leg(pkg, co, torch, ncpu, args.in_process, 20, 5)), flush=True)
+        return
     if world > 1:
         ncpu = max(1, min(ncpu, (os.cpu_count() or world) // world))   # the ranks share the node's cores
     aff = 96 if g == "g1" else 192
@@ -715,6 +736,8 @@ def main() -> None:
             xchg["barrier"] = False
             xchg["headline_steps"] = headline_steps
 
+    breakdown = leg.phase_breakdown(3 if n <= (1 << 22) else 1)   # right after the timed region (warm clocks): every phase's events
+
     # ---- parity: closed form over ALL ranks' inputs
     mine_expected = leg.expected_affine()          # affine bytes of this rank's shard
     if exchange:
@@ -793,7 +816,6 @@ def main() -> None:
     headline_n, gen_s = n, leg.gen_s
     p0 = prof_acc[-1]
     acc_ms = sum(p["accumulate_ms"] for p in prof_acc) / len(prof_acc)
-    breakdown = leg.phase_breakdown(3 if n <= (1 << 22) else 1)   # after the timed region: every phase's events
     leg.close()
     del leg
 
@@ -813,7 +835,7 @@ def main() -> None:
         if g == "g1" and log_n == 20 and not args.precomputed and args.dist == "uniform":
             guarded("normalize_2p20", lambda: _normalize_leg(pkg, co, ncpu, local_rank))
             guarded("deserialize_2p20", lambda: _deserialize_leg(pkg, co, ncpu, local_rank))
-        guarded("in_process_multi_device", lambda: _in_process_leg(pkg, co, torch, ncpu, args.in_process, 20, 5))
+        guarded("in_process_multi_device", lambda: _in_process_isolated(pkg, co, torch, ncpu, args.in_process))
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3

@@ -648,6 +648,25 @@ def test_bench_json_contract():
     assert list(d)[-1] == "summary" and d["summary"]["g1_2p14"]["bit_exact"] is True   # the recap closes the line (log tails keep it)
 
 
+def test_bench_in_process_leg_as_child_process():
+    """bench.py runs its in-library multi-device leg in a child process when several GPUs are visible (the first run on distinct
+    physical devices happens on the driver's node: a fault there must not cost the headline line).  The child's entry, on this box's
+    one GPU: device 0 listed twice."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--in-process-child", "--in-process", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["device_scalars"]["bit_exact"] is True and d["host_scalars"]["bit_exact"] is True
+    assert d["device_slots"] == [0, 0] and d["plumbing_only"] is True
+
+
 def test_bench_two_ranks_exchange_from_device_memory():
     """The N > 1 path of bench.py end to end on ONE GPU (2 ranks share device 0, gloo collective): every rank leaves its window
     sums in device memory (mi_msm_g1_device_windows), they are all-gathered and folded (mi_g1_fold_windows); the line carries
