@@ -15,7 +15,9 @@ struct CurveCost {        // what the plan needs to know about the curve's kerne
     int comb_log_ll;      // log2 logical lanes per combine wave (k_combine may use a narrower, lower-latency scheme)
     uint32_t max_chunks;  // reduce waves that run at once (1024 SIMDs x occupancy)
     double add_per_us;    // mixed additions per microsecond of the accumulate kernel at full occupancy
-    double lane_add_us;   // one lane's time per mixed addition (latency view)
+    double lane_add_us;   // one lane's time per mixed addition (latency view), every wave slot taken
+    double lone_lane;     // ... as a fraction of it when at most one accumulate wave runs per SIMD (few items)
+    double acc_wave_items; // work items per accumulate wave (64 lanes; G2: a lane pair per item)
     double step_us;       // one complete addition of the reduce chain, every wave slot taken
     double lone_step_us;  // the same with at most one reduce wave per SIMD
     double comb_step_us;  // one complete addition of the combine chain

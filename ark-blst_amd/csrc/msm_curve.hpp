@@ -14,13 +14,13 @@ template <> struct HostCurve<msmk::G1C> {
     using J = hostec::G1;
     static constexpr int IDX = 0;
     // accumulate 7.1e9 additions/s, 11 us per addition and lane; quad-lane complete addition ~6 us per step, two waves per SIMD
-    static CurveCost cost() { return CurveCost{msmk::QuadG1::LOG_LL, msmk::QuadG1::LOG_LL, 2048, 7400.0, 14.0, 9.5, 5.9, 4.4, 40.0, 1ull << 21, 25.0}; }
+    static CurveCost cost() { return CurveCost{msmk::QuadG1::LOG_LL, msmk::QuadG1::LOG_LL, 2048, 7400.0, 14.0, 0.68, 64.0, 9.5, 5.9, 4.4, 40.0, 1ull << 21, 25.0}; }
 };
 template <> struct HostCurve<msmk::G2C> {
     using J = hostec::G2;
     static constexpr int IDX = 1;
     // lane pairs for the reduce (throughput), eight lanes per logical lane for the combine (latency)
-    static CurveCost cost() { return CurveCost{msmk::PairG2::LOG_LL, msmk::OctG2::LOG_LL, 1024, 2300.0, 36.0, 28.0, 24.5, 14.0, 80.0, 0, 0.0}; }
+    static CurveCost cost() { return CurveCost{msmk::PairG2::LOG_LL, msmk::OctG2::LOG_LL, 1024, 2300.0, 36.0, 0.45, 32.0, 28.0, 24.5, 14.0, 80.0, 0, 0.0}; }
 };
 template <class C> constexpr size_t aff_bytes() { return (size_t)msmk::Geo<C>::RAW_AFF * 4; }
 template <class C> constexpr size_t jac_bytes() { return (size_t)msmk::Geo<C>::RAW_JAC * 4; }

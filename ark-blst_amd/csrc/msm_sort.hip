@@ -129,8 +129,8 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         double acc_adds = entries - nonempty + 1.2 * (double)p.nbuckets;
         const double wave_rounds = (double)p.nbuckets / 64.0 / (double)cc.max_chunks;
         if (wave_rounds < 4.0) acc_adds *= 1.0 + 0.5 * (std::ceil(wave_rounds) - wave_rounds) / std::max(wave_rounds, 0.25);
-        // a lane's addition takes lane_add_us with two waves per SIMD; with at most one (few items) about two thirds of it
-        const double lane_us = cc.lane_add_us * ((double)p.nbuckets / 64.0 <= 1024.0 ? 0.68 : 1.0);
+        // a lane's addition takes lane_add_us with every wave slot taken; with at most one wave per SIMD (few items) two thirds of it (G1) / under half (G2's lane pairs)
+        const double lane_us = cc.lane_add_us * ((double)p.nbuckets / cc.acc_wave_items <= 1024.0 ? cc.lone_lane : 1.0);
         // the kernel drains over the life of its SHORTEST items (the schedule starts the longest first): half a wave generation of
         // mean - 3 sigma entries is lost at the end — fuller buckets, longer drain (c = 15 vs 16 at 2^20 points: 10 % fewer additions per us)
         const double drain_us = 0.5 * std::max(0.0, mean - 3.0 * std::sqrt(mean)) * cc.lane_add_us;
