@@ -538,8 +538,11 @@ def _in_process_isolated(pkg, co, torch, ncpu, slots: int) -> dict:
     if torch.cuda.device_count() <= 1:
         return _in_process_leg(pkg, co, torch, ncpu, slots, 20, 5)
     import subprocess
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--in-process-child", "--in-process", str(slots)],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--in-process-child", "--in-process", str(slots)],
+                           capture_output=True, text=True, timeout=300, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": "child process exceeded 300 s (a normal run takes under 30 s)"}
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if r.returncode != 0 or not lines:
         return {"error": f"child process rc={r.returncode}", "stderr_tail": r.stderr[-600:]}
