@@ -664,20 +664,29 @@ __global__ void __launch_bounds__(64, 2) k_reduce_serial(const uint32_t* __restr
     uint32_t idx = wp[L - 1 < cnt ? L - 1 : 0];   // bucket of step pair t = 0 is rel = L - 1 (beyond a ragged lane's buckets: infinity)
     int bit = top - 1;                     // wave-uniform state of the chain
     bool pend_add = false;
+    // as in k_reduce_coop: a running-sum step whose second operand is infinity in every lane of the wave is skipped ("bucket holds an
+    // entry" from the entry offsets; `fr`: this lane's run may be non-zero)
+    const uint32_t* opw = offsets + (size_t)w * nb + first;
+    bool fr = false;
 #pragma unroll 1
     for (uint32_t s = 0; s < nsteps; s++) {
         PJ A, B;
         const bool phase1 = s < 2 * L, even = (s & 1u) == 0;
         if (phase1 && even) {              // run += B_rel, rel = L - 1 - t
             const uint32_t t = s >> 1, rel = L - 1 - t;
+            const bool full = rel < cnt && opw[rel + 1] != opw[rel];
+            const uint32_t idx_now = idx;
+            if (t + 1 < L) idx = wp[rel - 1 < cnt ? rel - 1 : 0];
+            fr = fr || full;
+            if (__ballot(full) == 0) continue;
             A = run;
-            B = load_bucket<C>(partial + (size_t)idx * BK);
+            B = load_bucket<C>(partial + (size_t)idx_now * BK);
             // beyond a ragged lane's buckets: infinity = (0 : Y : 0) for ANY Y != 0 — clearing X and Z of whatever was loaded costs
             // two selects against the inline constant 0 (a select against (0 : 1 : 0) parked the 14 limbs of one in registers)
             B.x = F::select(rel < cnt, F::zero(), B.x);
             B.z = F::select(rel < cnt, F::zero(), B.z);
-            if (t + 1 < L) idx = wp[rel - 1 < cnt ? rel - 1 : 0];
         } else if (phase1) {               // acc += run
+            if (__ballot(fr) == 0) continue;
             A = park_load();
             B = run;
         } else {
