@@ -61,6 +61,7 @@ def load_library(test_hooks: bool = False):
         for g in ("g1", "g2"):
             getattr(L, f"mi_msm_{g}_set_bases").argtypes = [vp, vp, sz]
             getattr(L, f"mi_msm_{g}_set_bases_precomputed").argtypes = [vp, vp, sz, u]
+            getattr(L, f"mi_msm_{g}_validate_bases").argtypes = [vp, C.POINTER(sz)]
             getattr(L, f"mi_msm_{g}").argtypes = [vp, vp, vp, sz, u, vp]
             getattr(L, f"mi_msm_{g}_device").argtypes = [vp, vp, sz, u, vp]
             getattr(L, f"mi_{g}_sum").argtypes = [vp, sz, vp]
@@ -164,6 +165,12 @@ class Context:
         p, keep = _buf(bases)
         self._check(getattr(self._L, f"mi_msm_{group}_set_bases_precomputed")(self._h, p, n, window_bits),
                     f"mi_msm_{group}_set_bases_precomputed")
+
+    def validate_bases(self, group: str) -> int:
+        """Valid::check of the resident base set on the GPU; returns the number of points that fail (0 = the set is recorded as valid)"""
+        bad = C.c_size_t(0)
+        self._check(getattr(self._L, f"mi_msm_{group}_validate_bases")(self._h, C.byref(bad)), "mi_msm_validate_bases")
+        return bad.value
 
     def msm(self, group: str, bases, scalars, n: int, scalar_fmt: int = SCALAR_CANONICAL) -> bytes:
         """bases=None uses the resident set. Returns the Jacobian result bytes (blst_p1 / blst_p2)."""
@@ -287,10 +294,10 @@ class Context:
         self._check(self._L.mi_test_set_no_peer(self._h, int(no_peer)), "mi_test_set_no_peer")
 
 
-def test_plan(n: int, forced_c: int = 0, group: str = "g1", shared: bool = False, stride: int = 0) -> dict:
-    """The window-size plan of an n-point call (test build; host only, needs no device)."""
+def test_plan(n: int, forced_c: int = 0, group: str = "g1", shared: bool = False, stride: int = 0, fold: bool = False) -> dict:
+    """The window-size plan of an n-point call (test build; host only, needs no device).  fold: the plan of a validated resident set."""
     out = (C.c_uint32 * 13)()
-    rc = load_library(True).mi_test_plan(n, forced_c, 0 if group == "g1" else 1, int(shared), stride, out)
+    rc = load_library(True).mi_test_plan(n, forced_c, 0 if group == "g1" else 1, int(shared) | (2 if fold else 0), stride, out)
     if rc != 0:
         raise MsmError(rc, "mi_test_plan")
     keys = ("c", "nwin", "bwin", "coop_L", "chunk_buckets", "logT", "lo_bits", "serial", "chunks_per_win")

@@ -141,6 +141,9 @@ int mi_msm_g2_set_bases_precomputed(mi_ctx* ctx, const mi_g2_affine* bases, size
     return g2_set_bases(ctx, bases, n, window_bits ? window_bits : 1);
 }
 
+int mi_msm_g1_validate_bases(mi_ctx* ctx, size_t* n_invalid) { return g1_validate_bases(ctx, n_invalid); }
+int mi_msm_g2_validate_bases(mi_ctx* ctx, size_t* n_invalid) { return g2_validate_bases(ctx, n_invalid); }
+
 int mi_msm_g1(mi_ctx* ctx, const mi_g1_affine* bases, const uint8_t* scalars, size_t n, unsigned scalar_fmt, mi_g1* out) {
     return g1_msm(ctx, bases, scalars, false, n, scalar_fmt, out);
 }
@@ -304,7 +307,7 @@ int mi_test_set_no_peer(mi_ctx* ctx, int no_peer) {
 }
 int mi_test_plan(size_t n, unsigned forced_c, int group, int shared, size_t stride, uint32_t* out) {
     if (!out || n == 0) return MI_E_INVALID;
-    Plan p = make_plan(n, forced_c, group == 0 ? g1_cost() : g2_cost(), shared != 0, stride);
+    Plan p = make_plan(n, forced_c, group == 0 ? g1_cost() : g2_cost(), (shared & 1) != 0, stride, (shared & 2) != 0);
     out[0] = p.c; out[1] = p.nwin; out[2] = p.bwin; out[3] = p.coop_L; out[4] = p.chunk_buckets; out[5] = p.logT; out[6] = p.lo_bits;
     out[7] = p.serial_reduce ? 1u : 0u; out[8] = p.chunks_per_win; out[9] = (uint32_t)(p.nbuckets >> 32); out[10] = (uint32_t)p.nbuckets;
     out[11] = (uint32_t)p.nchunks; out[12] = p.serial_reduce ? p.serial_L : 0u;

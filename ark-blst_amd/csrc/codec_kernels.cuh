@@ -50,9 +50,25 @@ __device__ __noinline__ void g1_mul_z(ec::Proj<ec::FpOps>& r, const ec::Proj<ec:
     }
 }
 
+// is_torsion_free of an affine point in the internal form: (beta x, y) == -[z^2] P, i.e. X == beta x Z, Y == -y Z, Z != 0
+__device__ __forceinline__ bool g1_in_subgroup(const Fp& x, const Fp& y) {
+    using F = ec::FpOps;
+    ec::Proj<F> p1 = ec::proj_from_affine<F>(x, y), q, q2;
+    g1_mul_z(q, p1);
+    g1_mul_z(q2, q);                                                     // [z^2] P
+    Fp bx = fp28::fp_mul_call(x, fp28::fp_const(fp28c::BETA));
+    bool ok = !fp28::fp_is_zero_any(q2.z);
+    ok = ok && fp_equal(q2.x, fp28::fp_mul_call(bx, q2.z));
+    ok = ok && fp28::fp_is_zero_any(fp28::fp_add(q2.y, fp28::fp_mul_call(y, q2.z)));
+    return ok;
+}
+__device__ __forceinline__ bool g1_on_curve(const Fp& x, const Fp& y) {   // y^2 == x^3 + 4
+    Fp rhs = fp28::fp_add(fp28::fp_mul_call(fp28::fp_sqr_call(x), x), fp28::fp_const(fp28c::FOUR));
+    return fp_equal(fp28::fp_sqr_call(y), rhs);
+}
+
 __global__ void __launch_bounds__(256, 2) k_deserialize_g1(const uint8_t* __restrict__ bytes, uint32_t n, int compressed, int validate,
                                                         uint32_t* __restrict__ out_aff, uint8_t* __restrict__ status) {
-    using F = ec::FpOps;
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t size = compressed ? 48u : 96u;
@@ -108,17 +124,7 @@ __global__ void __launch_bounds__(256, 2) k_deserialize_g1(const uint8_t* __rest
             on_curve = !validate || fp_equal(fp28::fp_sqr_call(y), rhs);
             if (!on_curve) st = 2;
         }
-        if (st == 0 && validate) {
-            ec::Proj<F> p1 = ec::proj_from_affine<F>(x, y), q, q2;
-            g1_mul_z(q, p1);
-            g1_mul_z(q2, q);                                                     // [z^2] P
-            // membership: (beta x, y) == -[z^2] P, i.e. X == beta x Z, Y == -y Z, Z != 0
-            Fp bx = fp28::fp_mul_call(x, fp28::fp_const(fp28c::BETA));
-            bool ok = !fp28::fp_is_zero_any(q2.z);
-            ok = ok && fp_equal(q2.x, fp28::fp_mul_call(bx, q2.z));
-            ok = ok && fp28::fp_is_zero_any(fp28::fp_add(q2.y, fp28::fp_mul_call(y, q2.z)));
-            if (!ok) st = 3;
-        }
+        if (st == 0 && validate && !g1_in_subgroup(x, y)) st = 3;
     }
     uint32_t w[12];
     bool keep = st == 0 && !is_inf;
@@ -214,6 +220,26 @@ __device__ __forceinline__ bool fp2_lex_largest(const ec::Fp2& y) {  // c1 first
     return canon_gt_half(fp_to_canonical(y.c0));
 }
 
+// is_torsion_free of an affine point in the internal form: psi(P) == [z] P = -[|z|] P, i.e. X_q == px Z_q, Y_q == -py Z_q, Z_q != 0
+__device__ __noinline__ bool g2_in_subgroup(const ec::Fp2& x, const ec::Fp2& y) {
+    ec::Proj<G2F> p1 = ec::proj_from_affine<G2F>(x, y), q;
+    g2_mul_z(q, p1);                                                          // [|z|] P
+    ec::Fp2 px = G2F::mul(fp2_conj(x), ec::Fp2{fp28::fp_zero(), fp28::fp_const(fp28c::PSI_X1)});
+    ec::Fp2 py = G2F::mul(fp2_conj(y), ec::Fp2{fp28::fp_const(fp28c::PSI_Y0), fp28::fp_const(fp28c::PSI_Y1)});
+    bool ok = !fp2_is_zero(q.z);
+    ok = ok && fp2_equal(q.x, G2F::mul(px, q.z));
+    ok = ok && fp2_is_zero(G2F::add(q.y, G2F::mul(py, q.z)));
+    return ok;
+}
+__device__ __forceinline__ bool g2_on_curve(const ec::Fp2& x, const ec::Fp2& y) {   // y^2 == x^3 + 4 (1 + u)
+    const Fp four = fp28::fp_const(fp28c::FOUR);
+    ec::Fp2 rhs = G2F::add(G2F::mul(G2F::sqr(x), x), ec::Fp2{four, four});
+    return fp2_equal(G2F::sqr(y), rhs);
+}
+
+// The decoder proper: encoding checks, decompression (square root in Fp2) and, for uncompressed input with `validate`, the curve equation.  The
+// subgroup test of Valid::check is the SECOND kernel of mi_g2_deserialize_batch (k_validate<G2C, true> below): fused, the straight-line
+// code between the two out-of-line loops (fp2_pow, g2_mul_z) kept 86 registers in scratch (round 4's finding); apart, neither kernel spills.
 __global__ void __launch_bounds__(256, 2) k_deserialize_g2(const uint8_t* __restrict__ bytes, uint32_t n, int compressed, int validate,
                                                         uint32_t* __restrict__ out_aff, uint8_t* __restrict__ status) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -271,22 +297,59 @@ __global__ void __launch_bounds__(256, 2) k_deserialize_g2(const uint8_t* __rest
             y.c1 = fp28::fp_mul_call(fp28::fp_unpack384(y1w), r2);
             if (validate && !fp2_equal(G2F::sqr(y), rhs)) st = 2;
         }
-        if (st == 0 && validate) {
-            ec::Proj<G2F> p1 = ec::proj_from_affine<G2F>(x, y), q;
-            g2_mul_z(q, p1);                                                          // [|z|] P
-            ec::Fp2 px = G2F::mul(fp2_conj(x), ec::Fp2{fp28::fp_zero(), fp28::fp_const(fp28c::PSI_X1)});
-            ec::Fp2 py = G2F::mul(fp2_conj(y), ec::Fp2{fp28::fp_const(fp28c::PSI_Y0), fp28::fp_const(fp28c::PSI_Y1)});
-            // psi(P) == [z] P = -[|z|] P :  X_q == px Z_q,  Y_q == -py Z_q,  Z_q != 0
-            bool ok = !fp2_is_zero(q.z);
-            ok = ok && fp2_equal(q.x, G2F::mul(px, q.z));
-            ok = ok && fp2_is_zero(G2F::add(q.y, G2F::mul(py, q.z)));
-            if (!ok) st = 3;
-        }
     }
     bool keep = st == 0 && !is_inf;
     ElemIO<ec::Fp2>::to_raw(o, x, keep);
     ElemIO<ec::Fp2>::to_raw(o + 24, y, keep);
     status[i] = st;
+}
+
+template <class C> struct PointCheck;
+template <> struct PointCheck<G1C> {
+    static __device__ __forceinline__ bool on_curve(const Fp& x, const Fp& y) { return g1_on_curve(x, y); }
+    static __device__ __forceinline__ bool in_subgroup(const Fp& x, const Fp& y) { return g1_in_subgroup(x, y); }
+};
+template <> struct PointCheck<G2C> {
+    static __device__ __forceinline__ bool on_curve(const ec::Fp2& x, const ec::Fp2& y) { return g2_on_curve(x, y); }
+    static __device__ __forceinline__ bool in_subgroup(const ec::Fp2& x, const ec::Fp2& y) { return g2_in_subgroup(x, y); }
+};
+
+// Valid::check (is_on_curve && is_torsion_free, /root/reference/src/g1.rs:419-431, src/g2.rs:399-411) of n affine points in device memory.
+//   RAW = true   second pass of mi_g2_deserialize_batch: points in the reference's form as the decoder wrote them (all-zero = infinity or
+//                rejected: skipped), already known to be on the curve; a point outside the subgroup gets status 3 and is zeroed.
+//   RAW = false  mi_msm_g{1,2}_validate_bases: the RESIDENT base set in the device form (infinity flag in the point's last word);
+//                both halves of the check; *n_bad counts the points that fail.
+template <class C, bool RAW>
+__global__ void __launch_bounds__(256, 2) k_validate(uint32_t* __restrict__ pts, uint32_t n, uint8_t* __restrict__ status, uint32_t* __restrict__ n_bad) {
+    using E = typename C::F::E;
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    E x, y;
+    if constexpr (RAW) {
+        if (status[i] != 0) return;
+        uint32_t* q = pts + (size_t)i * Geo<C>::RAW_AFF;
+        uint32_t any = 0;
+#pragma unroll 4
+        for (int k = 0; k < Geo<C>::RAW_AFF; k++) any |= q[k];
+        if (any == 0) return;   // infinity
+        ElemIO<E>::from_raw(x, q);
+        ElemIO<E>::from_raw(y, q + ElemIO<E>::RAW);
+        if (!PointCheck<C>::in_subgroup(x, y)) {
+            status[i] = 3;
+#pragma unroll 4
+            for (int k = 0; k < Geo<C>::RAW_AFF; k++) q[k] = 0u;
+        }
+    } else {
+        const uint32_t* q = pts + (size_t)i * Geo<C>::PT_WORDS;
+        if (q[Geo<C>::PT_WORDS - 1] != 0) return;   // infinity: a member of every subgroup
+        ElemIO<E>::load(x, q);
+        ElemIO<E>::load(y, q + Geo<C>::SLOT);
+        uint8_t st = 0;
+        if (!PointCheck<C>::on_curve(x, y)) st = 2;
+        else if (!PointCheck<C>::in_subgroup(x, y)) st = 3;
+        if (status) status[i] = st;
+        if (st) atomicAdd(n_bad, 1u);
+    }
 }
 
 __device__ __forceinline__ void words_to_be48(uint8_t* d, const uint32_t (&w)[12]) {

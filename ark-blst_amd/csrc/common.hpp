@@ -49,8 +49,15 @@ struct HipFail {
 extern std::atomic<int> g_fail_allocs;   // > 0: that many upcoming DevBuf::ensure calls that need to grow will throw
 #endif
 
+// Digit windows of a scalar below r < 2^255 recoded into signed c-bit digits.  fold = the digit kernels recode min(s, r - s) < 2^254 with
+// the sign folded into the digits (exact only on the prime-order subgroup: resident bases that passed mi_msm_g{1,2}_validate_bases):
+// ceil(255 / c) windows always suffice.  Otherwise the integer s itself is recoded and a top window of a full c bits can carry out:
+// one more window when c divides 255 (c = 15, 17).
+inline uint32_t num_windows(unsigned c, bool fold) { return (255 + c - 1) / c + ((!fold && 255 % c == 0) ? 1u : 0u); }
+
 struct Plan {
-    uint32_t c, nwin;     // window bits, digit windows = ceil(255 / c)
+    uint32_t c, nwin;     // window bits, digit windows = num_windows(c, fold)
+    bool fold;            // sign fold (see num_windows): travels to the digit kernels as bit 1 of their fmt argument
     uint32_t bwin;        // bucket sets: nwin, or 1 when all windows share one (precomputed tables)
     uint32_t nb, coop_L, chunks_per_win, logT, lo_bits;   // coop_L: buckets per logical lane of k_reduce_coop (any value 1..64)
     uint32_t logS;        // log2 of the item size of buckets that hold more than T = 2^logT entries (<= logT)
@@ -95,6 +102,7 @@ struct Resident {
     size_t lo = 0;       // global index of the first resident point
     uint32_t tables = 1; // 1 = plain bases; W > 1 = precomputed 2^(c j) P_i tables, j < W (see mi_msm_g1_set_bases_precomputed)
     uint32_t table_c = 0;// window size the tables were built for
+    bool validated = false;   // every point passed Valid::check on the GPU (mi_msm_g{1,2}_validate_bases): MSMs over this set may fold signs
 };
 
 // Per-device state of ONE LANE of a context: stream, events and scratch.  A context has two lanes per device so that two

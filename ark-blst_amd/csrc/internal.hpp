@@ -27,7 +27,8 @@ struct CurveCost {        // what the plan needs to know about the curve's kerne
 };
 // shared = false: one bucket set per window (plain bases).  shared = true: resident 2^(c j) P tables — every window feeds ONE
 // bucket set; `stride` = points per table (entry index = w * stride + i).  forced_c = 0 lets the time model choose.
-Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, size_t stride);
+// fold: see num_windows (common.hpp).
+Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, size_t stride, bool fold = false);
 
 struct SortOut {
     uint32_t nitems = 0, max_items = 0, nlist = 0, nsplit = 0;   // nlist: list length of merge level 0; nsplit: split buckets
@@ -64,6 +65,8 @@ int g1_deserialize(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, 
 int g1_serialize(mi_ctx* ctx, const mi_g1_affine* points, size_t n, int compressed, uint8_t* bytes);
 int g2_deserialize(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int validate, mi_g2_affine* out, uint8_t* status);
 int g2_serialize(mi_ctx* ctx, const mi_g2_affine* points, size_t n, int compressed, uint8_t* bytes);
+int g1_validate_bases(mi_ctx* ctx, size_t* n_invalid);
+int g2_validate_bases(mi_ctx* ctx, size_t* n_invalid);
 #if defined(MI_TEST_HOOKS)
 int test_fp_op(mi_ctx* ctx, int op, const mi_fp* a, const mi_fp* b, mi_fp* out, size_t n);
 #endif

@@ -169,16 +169,19 @@ __device__ __forceinline__ void fr_from_mont(uint32_t (&s)[8]) {
     for (int k = 0; k < 8; k++) s[k] = ge ? d[k] : t[k];
 }
 
-// Returns `flip`: the canonical scalar was above (r - 1) / 2 and has been replaced by r - s — the caller inverts the sign of every
-// digit (s P = (r - s)(-P) on the prime-order subgroup, and negating a point is free: NEGATION_IS_CHEAP, src/g1.rs:595).  Round 4:
-// the scalars the recoding sees are then below 2^254, so ceil(255 / c) windows always suffice and the signed recoding never carries
-// out of the top window — for c = 15 and c = 17 (the divisors of 255) that removes the extra window whose single bucket collected
-// a carry from 45 % of the points (a heavy bucket, one merge launch per tree level).
+// fmt bit 0: the scalars are blst_fr Montgomery values (converted here); bit 1: sign fold (Plan::fold, host side).
+// Without the fold the canonical integer s < r is recoded as it is — s P for ANY point P, the reference's semantics
+// (blst's Pippenger, src/g1.rs:614-617, also for points that skipped Valid::check: Validate::No, src/g1.rs:425) — and `false` is returned.
+// With the fold — only for resident bases that passed mi_msm_g{1,2}_validate_bases — a scalar above (r - 1) / 2 is replaced by
+// r - s and `true` is returned: the caller inverts the sign of every digit (s P = (r - s)(-P) on the prime-order subgroup, and
+// negating a point is free: NEGATION_IS_CHEAP, src/g1.rs:595).  The recoded values are then below 2^254, ceil(255 / c) windows
+// always suffice and the signed recoding never carries out of the top window — for c = 15 and c = 17 (the divisors of 255) that
+// removes the extra window whose single bucket collects a carry from 45 % of the points.
 __device__ __forceinline__ bool load_scalar(uint32_t (&s)[8], const uint32_t* scalars, uint32_t i, unsigned fmt) {
     const uint4* q = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
     uint4 a = q[0], b = q[1];
     s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
-    if (fmt == 1) {
+    if (fmt & 1u) {
         fr_from_mont(s);
     } else {
         // canonical integers are expected below r, but any 256-bit value is accepted: subtract r up to twice
@@ -197,6 +200,7 @@ __device__ __forceinline__ bool load_scalar(uint32_t (&s)[8], const uint32_t* sc
             for (int k = 0; k < 8; k++) s[k] = borrow ? s[k] : d[k];
         }
     }
+    if (!(fmt & 2u)) return false;
     // s > (r - 1) / 2  <=>  2 s > r - 1  <=>  r - s < s ... decided on d = r - s: flip when d < s
     uint32_t d[8];
     uint64_t borrow = 0;
@@ -221,7 +225,6 @@ __device__ __forceinline__ bool load_scalar(uint32_t (&s)[8], const uint32_t* sc
     return flip;
 }
 
-// c-bit field starting at bit `off` of a 256-bit little-endian integer (zero beyond bit 255)
 constexpr uint32_t MERGE_FAN = 4;   // fan-in of one level of the merge of split buckets (k_merge, curve_kernels.cuh; the plan counts its levels)
 // the schedule's counters in device memory (words): [0] items, [1] max items of a bucket, [2] entries, [3] merge list length of level 0,
 // [4] split buckets, [8 + l] merge list length of level l >= 1
@@ -232,6 +235,7 @@ constexpr uint32_t MERGE_META = 32;
 // Launches pack logT | (class shift << 8) | (logS << 16) into one argument.
 __device__ __forceinline__ uint32_t item_size_log(uint32_t cnt, uint32_t logT, uint32_t logS) { return cnt > (1u << logT) ? logS : logT; }
 
+// c-bit field starting at bit `off` of a 256-bit little-endian integer (zero beyond bit 255)
 __device__ __forceinline__ uint32_t scalar_bits(const uint32_t (&s)[8], uint32_t off, uint32_t c) {
     uint32_t w = off >> 5, sh = off & 31;
     uint32_t lo = 0, hi = 0;
@@ -263,7 +267,9 @@ __device__ __forceinline__ void for_each_digit(const uint32_t (&s)[8], bool flip
 // windows outside [w0, w1) cost only their carry.  k_coarse is instantiated for c = 7..22.
 template <int CB, class Fn>
 __device__ __forceinline__ void for_each_digit_static(const uint32_t (&s)[8], bool flip, uint32_t w0, uint32_t w1, Fn f) {
-    constexpr uint32_t NW = (255 + CB - 1) / CB, HALF = 1u << (CB - 1), MASKC = (1u << CB) - 1u;   // s < 2^254 (load_scalar): no carry out of window NW - 1
+    // NW = the windows of the unfolded recoding (num_windows(CB, false), common.hpp); with the fold the value is below 2^254, the last
+    // of them (CB = 15, 17) sees no bits and no carry and lies beyond w1
+    constexpr uint32_t NW = (255 + CB - 1) / CB + (255 % CB == 0 ? 1 : 0), HALF = 1u << (CB - 1), MASKC = (1u << CB) - 1u;
     uint32_t carry = 0;
 #pragma unroll
     for (uint32_t w = 0; w < NW; w++) {

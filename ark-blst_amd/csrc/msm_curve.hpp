@@ -153,13 +153,13 @@ void launch_accumulate(hipStream_t s, const uint32_t* bases, const uint32_t* sor
 // The pipeline on one device.  d_bases: device-form points (tables of `stride` points when shared); d_scalars: n x 32 B on device.
 template <class C>
 typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint8_t* d_flags, const uint32_t* d_scalars,
-                                 size_t n, unsigned fmt, bool shared, unsigned table_c, size_t stride, int ev0, WinOut* wo = nullptr,
+                                 size_t n, unsigned fmt, bool shared, unsigned table_c, size_t stride, int ev0, bool fold, WinOut* wo = nullptr,
                                  const uint8_t* host_scalars = nullptr) {
     using J = typename HostCurve<C>::J;
     using RS = typename msmk::CoopOf<C>::RS;   // lane scheme of the reduce kernel
     using CS = typename msmk::CoopOf<C>::CS;   // lane scheme of the combine levels
     constexpr int BK = msmk::Geo<C>::BK_WORDS;
-    Plan pl = make_plan(n, shared ? table_c : ctx->forced_c, HostCurve<C>::cost(), shared, stride);
+    Plan pl = make_plan(n, shared ? table_c : ctx->forced_c, HostCurve<C>::cost(), shared, stride, fold);
     if (pl.c == 0) throw HipFail{"window_bits not usable for this n (sort geometry)"};
     d.prof.window_bits = pl.c;
     d.prof.num_windows = pl.nwin;
@@ -332,7 +332,9 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
             d_bases = reinterpret_cast<const uint32_t*>(res.buf.p) + (r0 + lo) * msmk::Geo<C>::PT_WORDS;
             d_flags = reinterpret_cast<const uint8_t*>(res.flags.p) + r0 + lo;
         }
-        J r = run_msm<C>(ctx, d, d_bases, d_flags, d_scalars, m, fmt, shared, res.table_c, res.n, 2, wo, host_scalars);
+        // sign fold (one window fewer at c = 15 / 17) only over a resident set whose every point passed the subgroup check on this
+        // context; bases handed over with the call are multiplied by the integer s, as the reference does (src/g1.rs:614-617)
+        J r = run_msm<C>(ctx, d, d_bases, d_flags, d_scalars, m, fmt, shared, res.table_c, res.n, 2, !bases && res.validated, wo, host_scalars);
         total = lo == 0 ? r : total.add(r);
         // h2d_ms: bases (their chunks interleave with k_ingest on the main stream) + scalars (copy stream, first to last chunk; the
         // sort's count pass runs underneath, so digits_ms of a host-scalar call includes waiting for the chunks)
@@ -343,7 +345,7 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
     return total;
 }
 
-// Resident base set.  precompute_c == 0: plain bases.  Otherwise W = ceil(255 / c) tables T_j[i] = 2^(c j) P_i (affine, device
+// Resident base set.  precompute_c == 0: plain bases.  Otherwise W = num_windows(c, false) tables T_j[i] = 2^(c j) P_i (affine, device
 // form): every window of a later MSM then shares ONE bucket set (no per-window reduce, no Horner doublings) and c can be larger.
 template <class C>
 void build_resident(mi_ctx* ctx, DevState& d, Resident& res, const uint8_t* bases, size_t n, unsigned precompute_c) {
@@ -357,12 +359,13 @@ void build_resident(mi_ctx* ctx, DevState& d, Resident& res, const uint8_t* base
         // c == 0: no window size fits the entry encoding (n x windows > 2^30 entries, i.e. more than ~9e7 points per device)
         if (c < 7 || c > 22 || make_plan(n, c, HostCurve<C>::cost(), true, n).c == 0)
             throw HipFail{"window_bits not usable for precomputed tables of this size", false, true};
-        W = (255 + c - 1) / c;
+        W = num_windows(c, false);   // one more than a validated set's calls use at c = 15 / 17
     }
     res.buf.ensure_fit(n * W * PTB);
     res.flags.ensure(n);
     res.tables = 1;
     res.table_c = 0;
+    res.validated = false;
     ingest<C>(d, bases, false, n, (uint32_t*)res.buf.p, (uint8_t*)res.flags.p);
     if (W > 1) {
         InvTree t(n);
@@ -409,6 +412,7 @@ int set_bases_impl(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute
                 res.n = hi - lo;
                 res.tables = 1;
                 res.table_c = 0;
+                res.validated = false;
                 if (hi > lo) build_resident<C>(ctx, d, res, (const uint8_t*)bases + lo * aff_bytes<C>(), hi - lo, precompute_c);
             });
         });

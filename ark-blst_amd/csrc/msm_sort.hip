@@ -11,14 +11,15 @@ namespace mi {
 //   merge       one launch per binary-tree level when the short top window overfills its buckets
 //   reduce      a latency chain of 2L + 2 LOG_LL + chain(L) + 1 complete additions per wave, max_chunks waves per round
 //   combine     2 LOG_LL + 1 additions per level;  sort  N W entries at 4.1e10 /s;  schedule ~ buckets / 1e4;  host Horner ~ 100 us
-Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, size_t stride) {
+Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, size_t stride, bool fold) {
     Plan best{};
     double best_cost = 1e300;
     for (unsigned c = 7; c <= 22; c++) {
         if (forced_c && c != forced_c) continue;
         Plan p{};
         p.c = c;
-        p.nwin = (255 + c - 1) / c;   // the digit kernels recode min(s, r - s) < 2^254 (load_scalar): ceil(255 / c) windows, no carry out of the top one
+        p.fold = fold;
+        p.nwin = num_windows(c, fold);
         // sort geometry: lo bits share a 32-bit entry with the point index and the sign; the coarse bins of one
         // window must fit the LDS counter array
         uint32_t idx_bits = 1;
@@ -71,11 +72,11 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
             p.chunks_per_win = (p.nb + p.serial_L - 1) / p.serial_L;
         }
         p.nchunks = (uint64_t)p.chunks_per_win * p.bwin;
-        // The top window holds only 254 - c (nwin - 1) significant bits: its n entries share 2^top_bits buckets (on top of the
+        // The top window holds only 254 (fold) or 255 - c (nwin - 1) significant bits (0: the carry-only window of c = 15 / 17 without the fold): its n entries share 2^top_bits buckets (on top of the
         // others' entries when all windows share one bucket set)
         const double entries = (double)n * p.nwin;
         double mean = entries / (double)p.nbuckets;
-        int top_bits = std::max(0, std::min<int>(254 - (int)c * ((int)p.nwin - 1), (int)c - 1));
+        int top_bits = std::max(0, std::min<int>((fold ? 254 : 255) - (int)c * ((int)p.nwin - 1), (int)c - 1));
         double per_bucket = (double)n / (double)(1u << top_bits) + (shared ? mean : 0.0);
         // work-item size: twice the mean bucket load (uniform scalars then never split), at least 32 entries; the fuller buckets
         // of the top window count as the mean while they are within 4x of it (splitting them would cost a merge launch for
@@ -227,7 +228,7 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
         }
     };
     msmk::SortGeom g{};
-    g.n = (uint32_t)n; g.fmt = fmt; g.c = pl.c; g.nwin = pl.nwin;
+    g.n = (uint32_t)n; g.fmt = fmt | (pl.fold ? 2u : 0u); g.c = pl.c; g.nwin = pl.nwin;
     g.shared = shared_buckets ? 1u : 0u;
     g.stride = (uint32_t)stride;
     g.lo_bits = pl.lo_bits;

@@ -19,8 +19,9 @@ void mi_test_fail_allocs(int count);
 /* treat every device slot as remote from the scalar vector's device: device-resident scalars of a multi-device context are then
  * staged by peer copies even on one GPU (the path every slot but the owner's takes on a real multi-GPU node) */
 int mi_test_set_no_peer(mi_ctx *ctx, int no_peer);
-/* the window-size plan of an n-point call (host only, no device): out[13] = c, windows, bucket sets, logL, chunk_log, logT, lo_bits,
- * serial reduce, chunks per window, buckets (hi, lo), chunks, buckets per lane of the serial reduce.  group 0 = G1, 1 = G2; c = 0 in out[0]: no usable plan */
+/* the window-size plan of an n-point call (host only, no device): out[13] = c, windows, bucket sets, buckets per logical lane of the cooperative
+ * reduce (coop_L), buckets per reduce chunk, logT, lo_bits, serial reduce, chunks per window, buckets (hi, lo), chunks, buckets per lane of the
+ * serial reduce.  group 0 = G1, 1 = G2; shared bit 0 = precomputed tables, bit 1 = sign fold (a validated resident set); c = 0 in out[0]: no usable plan */
 int mi_test_plan(size_t n, unsigned forced_c, int group, int shared, size_t stride, uint32_t *out);
 #ifdef __cplusplus
 }

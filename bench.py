@@ -229,6 +229,17 @@ def _valu_roofline(kernel: str, model: str, mads_per_launch: float, kernel_ms: f
     return r
 
 
+MAX_LINE_BYTES = 8000   # the headline JSON line (a 40 KB line left BENCH_r04.json unparsed)
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_stale", "algorithmic_bytes_per_launch",
+              "kernel_ms", "model", "model_mads_per_point", "shader_clock_ghz", "frac_at_measured_clock", "instruction_cost_sum_cycles",
+              "cycles_per_wave_addition", "frac_of_instruction_cost_bound")
+_HBM_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel_ms")
+
+
+def _compact(d: dict, keys) -> dict:
+    return {k: d[k] for k in keys if k in d}
+
+
 def _rooflines(g: str, n: int, log_n, acc_ms: float, nwin: int, precomputed: bool) -> dict:
     alg_bytes = ALG_BYTES_PER_POINT[g] * n
     gbs = alg_bytes / (acc_ms * 1e-3) / 1e9
@@ -262,7 +273,6 @@ def _rooflines(g: str, n: int, log_n, acc_ms: float, nwin: int, precomputed: boo
                          "kernel_ms": acc_ms,
                          "note": "reported because the north star asks for it; low by construction (the bucket method re-reads each "
                                  "device point once per window: traffic ~ windows x algorithmic bytes, still far below 8 TB/s)"},
-        "valu_roofline": valu,   # alias of `roofline` (the key of rounds 1-3), kept for one more round
     }
 
 
@@ -399,7 +409,7 @@ def _pairing_leg(pkg, co, ncpu, device) -> dict:
             "host_tail_ms": pp["host_ms"],
             "product_cancels_to_one": gt == pr_oracle.fp12_to_bytes(pr_oracle.FP12_ONE), f"bit_exact_{m}_pairs_vs_c_oracle": sample_ok,
             "bit_exact": sample_ok,
-            "roofline": valu, "valu_roofline": valu,
+            "roofline": valu,
             "hbm_roofline": {"bound": "hbm", "kernel": "k_miller_lines2 + k_miller_accumulate", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": 288 * n, "kernel_ms": miller_ms,
                              "note": "288 B per pair in (96 B G1 + 192 B G2 affine); the 26 KB of line coefficients per pair written and "
@@ -568,6 +578,9 @@ def main() -> None:
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zero_one", "small64", "all_equal", "all_ones", "r1cs_mix"],
                     help="scalar distribution (secondary robustness figures; the headline is uniform)")
     ap.add_argument("--no-secondary", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--secondary-out", default=None, metavar="FILE",
+                    help="where the full records of the secondary legs go (default: bench_secondary.json beside bench.py); the stdout "
+                         "line carries a one-line recap of each under `summary` and this file's name under `secondary_file`")
     ap.add_argument("--in-process", type=int, default=0, metavar="SLOTS",
                     help="N = 1 only: device slots of the in-library multi-GPU leg of the secondary set (default: every visible GPU, at most 8; "
                          "device 0 twice on a one-GPU box)")
@@ -662,7 +675,8 @@ def main() -> None:
     # mi_g1_fold_windows adds the ranks per window in rank order and runs the Horner fold — identical result on every rank.
     win_dev = torch.empty(pkg.MAX_WINDOWS * jac_bytes, dtype=torch.uint8, device="cuda") if exchange else None
     xchg = {"info": None, "gather": None, "gather_host": None, "msm_s": 0.0, "wait_s": 0.0, "exchange_s": 0.0, "steps": 0,
-            "barrier": bool(args.timing_breakdown)}
+            "barrier": bool(args.timing_breakdown), "backend": args.backend,
+            "path": "window sums in device memory -> all_gather_into_tensor -> one D2H of the gathered block -> mi_%s_fold_windows" % g}
 
     def setup_exchange():
         """one untimed call: learn the window geometry, make every rank agree on it, size the gather buffers"""
@@ -843,6 +857,11 @@ def main() -> None:
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = total / (elapsed / args.steps)
+        full = _rooflines(g, headline_n, log_n, acc_ms, p0["num_windows"], args.precomputed)
+        roof = full["roofline"]
+        # whole-step fraction of the same roof: the model's multiply-adds of ALL ranks' points over the step time (sort, bucket reduction,
+        # combine, host fold and exchange included) against the peak of the GPUs used; `roofline.frac` is the dominant kernel alone
+        step_frac = roof["model_mads_per_point"] * total / (ms_step * 1e-3) / 1e12 / (MAD_PEAK_T * world)
         out = {
             "metric": f"{g.upper()} MSM points/sec",
             "value": value,
@@ -859,56 +878,70 @@ def main() -> None:
             "bit_exact": bit_exact,
             "config": {"workload": wl, "points_per_gpu": headline_n, "total_points": total, "window_bits": p0["window_bits"],
                        "num_windows": p0["num_windows"], "parallelism": f"base-set sharded x{world}", "scalar_dist": args.dist,
-                       "precomputed_tables": bool(args.precomputed),
-                       "field_repr": "14 x 28-bit limbs in u32, products accumulated with v_mad_u64_u32"},
-            "phases_ms": _phases(prof_acc, breakdown),
-            "input_gen_s": gen_s,
+                       "precomputed_tables": bool(args.precomputed), "field_repr": "14 x 28-bit limbs in u32 (v_mad_u64_u32)"},
+            "roofline": _compact(roof, _ROOF_KEYS),
+            "hbm_roofline": _compact(full["hbm_roofline"], _HBM_KEYS),
+            "step_frac": step_frac,
+            "phases_ms": {k: round(v, 4) for k, v in _phases(prof_acc, breakdown).items()},
         }
-        out.update(_rooflines(g, headline_n, log_n, acc_ms, p0["num_windows"], args.precomputed))
+        detail = {"headline_roofline": roof, "headline_hbm_roofline": full["hbm_roofline"], "input_gen_s": gen_s}
         if exchange:
             exp_ms, exp_src = _expected_ms(g, log_n) if log_n is not None else (None, None)
             out["config"]["expected_ms_per_rank"] = exp_ms
-            out["config"]["expected_ms_source"] = exp_src
             ks = max(1, xchg["steps"])
             out["msm_ms"] = xchg["msm_s"] / ks * 1e3            # rank 0: the library call up to the window sums in device memory
             out["wait_ms"] = xchg["wait_s"] / ks * 1e3          # rank 0: barrier until the slowest rank has its window sums (load imbalance)
-            out["exchange_ms"] = xchg["exchange_s"] / ks * 1e3  # rank 0: all-gather + one D2H + host fold (mi_g1_fold_windows)
-            out["exchange"] = {"backend": args.backend, "world_size": world, "bytes_per_rank": xchg["info"][1] * jac_bytes,
-                               "windows": xchg["info"][1], "window_bits": xchg["info"][0],
-                               "breakdown_from": "the timed steps (--timing-breakdown: a barrier inside every step)" if args.timing_breakdown
-                               else f"{ks} extra steps with a barrier, run after the timed region (the timed steps carry none)",
-                               "path": "window sums in device memory -> all_gather_into_tensor -> one D2H of the gathered block -> mi_%s_fold_windows" % g}
+            out["exchange_ms"] = xchg["exchange_s"] / ks * 1e3  # rank 0: all-gather + one D2H + host fold, inside the library
+            out["exchange"] = {"backend": xchg["backend"], "world_size": world, "bytes_per_rank": xchg["info"][1] * jac_bytes,
+                               "windows": xchg["info"][1], "window_bits": xchg["info"][0], "path": xchg["path"]}
+            detail["exchange"] = {"expected_ms_source": exp_src,
+                                  "breakdown_from": "the timed steps (--timing-breakdown: a barrier inside every step)" if args.timing_breakdown
+                                  else f"{ks} extra steps with a barrier, run after the timed region (the timed steps carry none)"}
             if "headline_steps" in xchg:
                 hs = xchg["headline_steps"]
                 out["exchange"]["timed_steps_msm_ms"] = hs["msm_s"] / max(1, hs["steps"]) * 1e3
                 out["exchange"]["timed_steps_exchange_incl_wait_ms"] = hs["exchange_s"] / max(1, hs["steps"]) * 1e3
         if cpu_baseline:
             out["cpu_baseline"] = cpu_baseline
-        if secondary:
-            out["secondary"] = secondary
-            for k in ("pairing_2p16", "two_host_threads", "call_shapes"):   # top-level names of rounds 1-2, kept as aliases for one more round
-                if k in secondary:
-                    out[k] = secondary[k]
-        # compact recap LAST: a log tail always shows the north-star figures (the driver keeps the last 2000 characters)
+        # compact recap: the north-star figures of every leg (the full records of the legs go to the sidecar file)
         def _brief(d):
-            b = {"value": d.get("value"), "ms_per_step": d.get("ms_per_step", d.get("ms", d.get("kernel_ms", d.get("kernels_ms")))), "bit_exact": d.get("bit_exact")}
+            b = {"value": d.get("value"), "ms": d.get("ms_per_step", d.get("ms", d.get("kernel_ms", d.get("kernels_ms")))), "bit_exact": d.get("bit_exact")}
             if "roofline" in d and d["roofline"].get("bound") == "valu_int_mad":
                 b["valu_frac"] = round(d["roofline"]["frac"], 3)
-            return b
+            if "step_frac" in d:
+                b["step_frac"] = round(d["step_frac"], 3)
+            if "cpu_baseline" in d and d is not out:
+                b["cpu"] = d["cpu_baseline"]["value"]
+            return {k: (float("%.4g" % v) if isinstance(v, float) else v) for k, v in b.items()}
         summary = {f"{g}_2p{log_n}" if log_n is not None else f"{g}_{headline_n}": _brief(out)}
-        for k in ("g1_2p16", "g1_2p24", "g2_2p20", "pairing_2p16", "g1_2p20_precomputed_tables", "normalize_2p20", "deserialize_2p20"):
-            if k in secondary and "error" not in secondary[k]:
-                summary[k] = _brief(secondary[k])
+        for k, v in secondary.items():
+            if isinstance(v, dict) and "error" in v:
+                summary[k] = {"error": str(v["error"])[:120]}
+            elif isinstance(v, dict) and "value" in v:
+                summary[k] = _brief(v)
         if "call_shapes" in secondary:
             summary["call_shapes_ms"] = {k: round(v, 3) for k, v in secondary["call_shapes"].items() if isinstance(v, float)}
-        if exchange:
-            summary["n_gpus"] = world
-            summary["exchange_ms"] = round(out["exchange_ms"], 4)
-            summary["wait_ms"] = round(out["wait_ms"], 4)
-        if cpu_baseline:
-            summary["cpu_points_per_s"] = cpu_baseline["value"]
         out["summary"] = summary
-        print(json.dumps(out), flush=True)
+        # ---- the sidecar: every secondary leg in full (rooflines with their notes, cpu baselines, phase tables).  The line below
+        # stays a few KB: a record the driver can parse whole (round 4's 40 KB line was not)
+        if secondary or args.secondary_out:
+            path = args.secondary_out or os.path.join(ROOT, "bench_secondary.json")
+            try:
+                with open(path, "w") as f:
+                    json.dump({"headline": out, "detail": detail, "secondary": secondary}, f, indent=1)
+                out["secondary_file"] = os.path.relpath(path, ROOT)
+            except OSError as e:
+                out["secondary_file"] = None
+                out["secondary_file_error"] = repr(e)[:200]
+        line = json.dumps(out)
+        if len(line) > MAX_LINE_BYTES:   # never again a line the driver cannot parse: drop the optional blocks, largest first
+            for k in ("phases_ms", "summary", "exchange", "hbm_roofline"):
+                out.pop(k, None)
+                line = json.dumps(out)
+                if len(line) <= MAX_LINE_BYTES:
+                    break
+        sys.stdout.flush()
+        print(line, flush=True)
     if exchange:
         dist.barrier()
         dist.destroy_process_group()

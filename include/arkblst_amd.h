@@ -77,7 +77,7 @@ typedef struct {
     double host_fold_ms;    /* CPU tail: Horner fold over the window sums, one thread */
     double total_ms;        /* wall time of the call */
     uint32_t window_bits;   /* c */
-    uint32_t num_windows;   /* ceil(255 / c): the digit kernels recode min(s, r - s) < 2^254 with the sign folded into the digits */
+    uint32_t num_windows;   /* ceil(255 / c), one more when c divides 255 (c = 15, 17) unless the base set passed mi_msm_g{1,2}_validate_bases */
     uint64_t n;             /* points in the call */
     uint64_t accumulate_adds; /* mixed additions executed by the accumulate kernel */
     uint32_t work_items;      /* lanes of the accumulate kernel: buckets, heavy ones split into chunks */
@@ -105,12 +105,20 @@ int mi_msm_g2_set_bases(mi_ctx *ctx, const mi_g2_affine *bases, size_t n);
 int mi_msm_g1_set_bases_precomputed(mi_ctx *ctx, const mi_g1_affine *bases, size_t n, unsigned window_bits);
 int mi_msm_g2_set_bases_precomputed(mi_ctx *ctx, const mi_g2_affine *bases, size_t n, unsigned window_bits);
 
+/* Valid::check (is_on_curve && is_torsion_free, src/g1.rs:419-431, src/g2.rs:399-411) of the RESIDENT base set, on the GPU, every device
+ * over its shard (the endomorphism tests of the bulk decoders below; ~30 ms per 2^20 G1 points, once per SRS).  *n_invalid = points that
+ * are not on the curve or not in the prime-order subgroup (infinity passes).  When it is 0 the context records it, and later MSMs over the
+ * resident set may recode a scalar above (r - 1) / 2 as -(r - s) — identical results on the subgroup, one digit window fewer at
+ * c = 15 and c = 17.  A new set_bases clears the record.  No counterpart in the reference (its MSM takes whatever G1Affine it is given). */
+int mi_msm_g1_validate_bases(mi_ctx *ctx, size_t *n_invalid);
+int mi_msm_g2_validate_bases(mi_ctx *ctx, size_t *n_invalid);
+
 /* out = sum_i scalars[i] * bases[i], i < n.   Replaces gpu::msm::<G1Affine> (src/gpu.rs:226-241) and the CPU
  * multi_exp (src/g1.rs:614-617).  bases == NULL uses the first n resident bases.  Infinity bases contribute
  * nothing (the reference's blst path fails on them, src/g1.rs:682-688).  n == 0 returns infinity.  Blocking.
- * Bases are expected in the prime-order subgroup, as every G1Affine / G2Affine the reference's deserialisers accept is
- * (Valid::check, src/g1.rs:419-431): scalars are taken modulo r (a canonical value >= r is reduced) and a scalar above (r - 1) / 2
- * is processed as -(r - s), so for a point outside the subgroup the result is s P only up to a multiple of r P.
+ * Integer semantics, as blst's Pippenger: every base — also a curve point OUTSIDE the prime-order subgroup, which the reference hands
+ * out under Validate::No (src/g1.rs:425) — is multiplied by the integer s_i (0 <= s_i < r; a canonical value >= r is reduced modulo r
+ * first).  The one exception is a resident set that passed mi_msm_g{1,2}_validate_bases (above), where it makes no difference.
  * Any n: more than 2^26 points per device are processed in several passes whose sums are added (the reference's
  * calc_chunk_size path, src/gpu.rs:64-85,238-239, is unfinished). */
 int mi_msm_g1(mi_ctx *ctx, const mi_g1_affine *bases, const uint8_t *scalars, size_t n, unsigned scalar_fmt,

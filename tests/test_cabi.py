@@ -188,16 +188,18 @@ def test_plan_geometry_invariants(pkg):
             [rnd.randrange(1, 1 << 26) for _ in range(40)]
     for group in ("g1", "g2"):
         for n in sizes:
-            for shared in (False, True):
+            for shared, fold in ((False, False), (True, False), (False, True), (True, True)):
                 for c in [0] + list(range(7, 23)):
                     stride = n if shared else 0
-                    p = pkg.test_plan(n, c, group, shared, stride)
+                    p = pkg.test_plan(n, c, group, shared, stride, fold)
                     if p["c"] == 0:
                         assert c != 0 or shared, (group, n, "the free plan must exist for every size")   # a forced c may not fit the geometry
                         continue
                     cc = p["c"]
                     assert 7 <= cc <= 22 and (c == 0 or cc == c)
-                    assert p["nwin"] == (255 + cc - 1) // cc and p["bwin"] == (1 if shared else p["nwin"])   # min(s, r - s) < 2^254 is recoded
+                    # the integer s < r < 2^255 is recoded: a full top window (c | 255) can carry into one more; a validated set recodes min(s, r - s) < 2^254
+                    assert p["nwin"] == (255 + cc - 1) // cc + (1 if 255 % cc == 0 and not fold else 0) and p["bwin"] == (1 if shared else p["nwin"])
+                    assert p["nwin"] <= 37                                                     # MI_MAX_WINDOWS
                     assert n * p["nwin"] < 1 << 32                                            # entry offsets are 32-bit
                     nb = 1 << (cc - 1)
                     assert p["nbuckets"] == nb * p["bwin"]
@@ -217,13 +219,16 @@ def test_plan_geometry_invariants(pkg):
     # says so (c = 0) and mi_msm_g1_set_bases_precomputed turns that into MI_E_INVALID before it divides by c
     assert pkg.test_plan(100_000_000, 0, "g1", True, 100_000_000)["c"] == 0
     # the sizes the benchmark configs use keep their measured choices
-    # (round 4: with the scalar's sign folded into the digits c = 17 needs 15 windows, not 16, and wins from 2^22 up: 21.5 vs 22.1 ms at 2^23)
-    assert pkg.test_plan(1 << 20)["c"] == 16 and pkg.test_plan(1 << 21)["c"] == 17 and pkg.test_plan(1 << 23)["c"] == 17   # 2^21: 5.71 (17) vs 6.02 ms (16)
-    assert pkg.test_plan(1 << 23)["nwin"] == 15 and pkg.test_plan(1 << 16)["c"] == 15
+    # (round 4: with the scalar's sign folded into the digits c = 17 needs 15 windows, not 16, and wins from 2^22 up: 21.5 vs 22.1 ms at 2^23;
+    #  round 5: the fold is the plan of a VALIDATED resident set only — the plain plan recodes the integer and c = 15 / 17 carry an extra window)
+    vp = lambda n, *a: pkg.test_plan(n, *a, fold=True)
+    assert vp(1 << 20)["c"] == 16 and vp(1 << 21)["c"] == 17 and vp(1 << 23)["c"] == 17   # 2^21: 5.71 (17) vs 6.02 ms (16)
+    assert vp(1 << 23)["nwin"] == 15 and vp(1 << 16)["c"] == 15
+    assert pkg.test_plan(1 << 21)["c"] == 16 and pkg.test_plan(1 << 16, 15)["nwin"] == 18 and pkg.test_plan(1 << 21, 17)["nwin"] == 16
     assert pkg.test_plan(1 << 24)["c"] == 20 and pkg.test_plan(1 << 24)["serial"] == 1 and pkg.test_plan(1 << 24)["serial_L"] == 53
     assert pkg.test_plan(1 << 20, 0, "g2")["c"] == 16
     # the reduce wave's L is not tied to powers of two: 17 windows of 2^14 buckets fit one round of wave slots at L = 9
-    assert pkg.test_plan(1 << 16, 15)["coop_L"] == 9 and pkg.test_plan(1 << 16, 15)["nchunks"] == 17 * 114
+    assert vp(1 << 16, 15)["coop_L"] == 9 and vp(1 << 16, 15)["nchunks"] == 17 * 114
     assert pkg.test_plan(1 << 20)["coop_L"] == 16 and pkg.test_plan(1 << 20)["nchunks"] == 2048
 
 
@@ -248,7 +253,7 @@ def test_plan_picks_against_the_committed_scans(pkg):
                 t[r["forced_c"]] = min(t.get(r["forced_c"], 1e9), r["ms"])
     checked = 0
     for (group, log_n), t in sorted(tab.items()):
-        c = pkg.test_plan(1 << log_n, 0, group)["c"]
+        c = pkg.test_plan(1 << log_n, 0, group, fold=True)["c"]   # the round-4 scans ran with the sign fold
         if c not in t:
             continue   # the scan did not force this window size
         assert t[c] <= 1.15 * min(t.values()), (group, log_n, c, t)

@@ -582,19 +582,83 @@ def test_cofactor_clearing_through_the_hip_path(ctx, co, o, group):
         got = _canon(co, group, ctx.msm(group, bases, sc, n, 0))
         assert got == want and got != bytes(len(want))
         assert got == co.to_affine(group, co.msm(group, bases, sc, n, 0, 1))
-        # r = (r-1)/2 + (r-1)/2 + 1: every scalar at most (r-1)/2, so the library multiplies by the INTEGER (above that it works with
-        # -(r - s), which is the same thing only on the subgroup: include/arkblst_amd.h)
-        half = ((o.R_ORDER - 1) // 2).to_bytes(32, "little")
-        three = half + half + (1).to_bytes(32, "little")
-        rq = ctx.msm(group, got * 3, three, 3, 0)
+        # r = (r - 1) + 1: a single scalar ABOVE (r - 1) / 2 on a point outside the subgroup — the library multiplies by the integer, as blst does
+        two = (o.R_ORDER - 1).to_bytes(32, "little") + (1).to_bytes(32, "little")
+        rq = ctx.msm(group, got + got, two, 2, 0)
         assert _canon(co, group, rq) == bytes(len(want))               # r * (h P) = infinity
         # ... and r * P itself is NOT: the point really was outside the subgroup (so the property above is not vacuous)
-        rp = ctx.msm(group, o.affine_to_bytes(F, pt) * 3, three, 3, 0)
+        raw = o.affine_to_bytes(F, pt)
+        rp = ctx.msm(group, raw + raw, two, 2, 0)
         assert _canon(co, group, rp) == o.affine_to_bytes(F, o.scalar_mul(F, pt, o.R_ORDER))
         assert _canon(co, group, rp) != bytes(len(want))
-        # on the subgroup a scalar above (r-1)/2 is exact too: (r - 1) Q = -Q
-        neg = ctx.msm(group, got, (o.R_ORDER - 1).to_bytes(32, "little"), 1, 0)
-        assert _canon(co, group, neg) == o.affine_to_bytes(F, o.aff_neg(F, o.affine_from_bytes(F, got)))
+        # (r - 1) P and (h k) P for a 254-bit k, each ONE scalar on the off-subgroup point, against the big-int oracle
+        k254 = (1 << 253) + 0x1234567 * (1 << 100) + 12345
+        for s in (o.R_ORDER - 1, (o.R_ORDER + 1) // 2, k254 | 1):
+            one = ctx.msm(group, raw, s.to_bytes(32, "little"), 1, 0)
+            assert _canon(co, group, one) == o.affine_to_bytes(F, o.scalar_mul(F, pt, s)), hex(s)
+        hk = ctx.msm(group, got, (k254).to_bytes(32, "little"), 1, 0)   # (h P) is in the subgroup: k (h P) has order r
+        assert _canon(co, group, hk) == o.affine_to_bytes(F, o.scalar_mul(F, o.affine_from_bytes(F, got), k254))
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_unvalidated_resident_bases_keep_integer_semantics(pkg, co, o, group):
+    """the reference multiplies whatever G1Affine it holds by the integer s (blst's Pippenger, src/g1.rs:614-617; points
+    that skipped Valid::check exist: Validate::No, src/g1.rs:425).  A resident set with off-subgroup points in it: validate_bases counts
+    them and leaves the sign fold OFF, the MSM over it equals the big-int oracle's sum for scalars above (r - 1) / 2, at a window size
+    where the fold would change the window count (c = 15) and one where it would not (c = 16)."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cofactor_util import off_subgroup_points
+
+    F = o.F1 if group == "g1" else o.F2
+    aff = 96 if group == "g1" else 192
+    n = 64
+    good = co.gen_bases(group, 4242, n - 3, 2)
+    offp = off_subgroup_points(o, group, 3)
+    bases = good[:aff * 20] + o.affine_to_bytes(F, offp[0]) + good[aff * 20:aff * 40] + o.affine_to_bytes(F, offp[1]) + good[aff * 40:] + o.affine_to_bytes(F, offp[2])
+    rng = random.Random(77)
+    sc = [rng.getrandbits(256) % o.R_ORDER for _ in range(n)]
+    sc[20], sc[41], sc[63] = o.R_ORDER - 1, o.R_ORDER - 5, (o.R_ORDER + 3) // 2     # the off-subgroup points get scalars above (r - 1) / 2
+    scb = b"".join(x.to_bytes(32, "little") for x in sc)
+    want = o.INF
+    for i in range(n):
+        want = o.aff_add(F, want, o.scalar_mul(F, o.affine_from_bytes(F, bases[aff * i:aff * (i + 1)]), sc[i]))
+    want = o.affine_to_bytes(F, want)
+    with pkg.Context([0]) as c:
+        c.set_bases(group, bases, n)
+        assert c.validate_bases(group) == 3
+        for cb, windows in ((15, 18), (16, 16), (17, 16), (0, None)):
+            c.set_window_bits(cb)
+            assert _canon(co, group, c.msm(group, None, scb, n, 0)) == want, cb
+            assert windows is None or c.profile()["num_windows"] == windows
+        assert _canon(co, group, c.msm(group, bases, scb, n, 0)) == want             # bases passed with the call: never folded
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_validated_bases_fold_signs_with_identical_results(pkg, co, group):
+    """A resident set that passes validate_bases: the MSM recodes min(s, r - s) (one window fewer at c = 15 / 17) and returns the same
+    point as the unvalidated context and as the C oracle; a new set_bases clears the record."""
+    n = 3000
+    bases = co.gen_bases(group, 991, n, 2)
+    sc = co.gen_scalars(992, n)
+    want = co.to_affine(group, co.msm(group, bases, sc, n, 0, 2))
+    with pkg.Context([0]) as c:
+        c.set_bases(group, bases, n)
+        for cb, w_plain, w_fold in ((15, 18, 17), (17, 16, 15), (16, 16, 16), (13, 20, 20)):
+            c.set_window_bits(cb)
+            assert _canon(co, group, c.msm(group, None, sc, n, 0)) == want
+            assert c.profile()["num_windows"] == w_plain
+        assert c.validate_bases(group) == 0
+        for cb, w_plain, w_fold in ((15, 18, 17), (17, 16, 15), (16, 16, 16), (13, 20, 20)):
+            c.set_window_bits(cb)
+            assert _canon(co, group, c.msm(group, None, sc, n, 0)) == want
+            assert c.profile()["num_windows"] == w_fold
+            assert _canon(co, group, c.msm(group, None, sc, n, 1)) == co.to_affine(group, co.msm(group, bases, sc, n, 1, 2))   # Montgomery scalars too
+        c.set_bases(group, bases, n)            # a new set: the record is gone
+        c.set_window_bits(15)
+        assert _canon(co, group, c.msm(group, None, sc, n, 0)) == want
+        assert c.profile()["num_windows"] == 18
 
 
 def test_call_abi_reproducer():
