@@ -23,5 +23,9 @@ from .binding import (  # noqa: F401
     lib_path,
     load_library,
     profile_dict,
+    RcclComm,
+    rccl_unique_id,
+    rccl_lib_path,
+    load_rccl_library,
 )
 from .msm import G1Projective, G2Projective  # noqa: F401

@@ -350,3 +350,97 @@ def g1_sum(partials) -> bytes:
 
 def g2_sum(partials) -> bytes:
     return _sum("g2", partials)
+
+
+# ---------------------------------------------------------------------------------------------- multi-process exchange
+class RcclTiming(C.Structure):
+    _fields_ = [("msm_ms", C.c_double), ("exchange_ms", C.c_double), ("window_bits", C.c_uint32), ("num_windows", C.c_uint32),
+                ("repeats", C.c_uint32), ("bytes_per_rank", C.c_uint32)]
+
+
+RCCL_UNIQUE_ID_BYTES = 128
+_RCCL = []
+
+
+def rccl_lib_path() -> str:
+    return os.path.join(_HERE, "lib", "libarkblst_amd_rccl.so")
+
+
+def load_rccl_library():
+    """libarkblst_amd_rccl.so (include/arkblst_amd_rccl.h): the exchange step of a one-process-per-GPU deployment.  Loaded on demand:
+    it pulls in librccl.so.1, which a single-GPU user never needs."""
+    if not _RCCL:
+        load_library(False)   # the product library first: the exchange library's NEEDED entry resolves to the same object
+        path = rccl_lib_path()
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(path)
+        vp, sz, u, i = C.c_void_p, C.c_size_t, C.c_uint, C.c_int
+        L.mi_rccl_get_unique_id.argtypes = [vp]
+        L.mi_rccl_comm_create.argtypes = [C.POINTER(vp), vp, vp, i, i]
+        L.mi_rccl_comm_attach.argtypes = [C.POINTER(vp), vp, vp]
+        L.mi_rccl_comm_destroy.argtypes = [vp]
+        L.mi_rccl_comm_destroy.restype = None
+        L.mi_rccl_comm_size.argtypes = [vp]
+        L.mi_rccl_comm_rank.argtypes = [vp]
+        for g in ("g1", "g2"):
+            getattr(L, f"mi_msm_{g}_allgather_fold").argtypes = [vp, vp, sz, u, vp]
+        L.mi_rccl_last_timing.argtypes = [vp, C.POINTER(RcclTiming)]
+        L.mi_rccl_last_error.restype = C.c_char_p
+        _RCCL.append(L)
+    return _RCCL[0]
+
+
+def rccl_unique_id() -> bytes:
+    """ncclGetUniqueId through the library: ONE rank calls it and hands the 128 bytes to the others."""
+    L = load_rccl_library()
+    buf = C.create_string_buffer(RCCL_UNIQUE_ID_BYTES)
+    rc = L.mi_rccl_get_unique_id(buf)
+    if rc != 0:
+        raise MsmError(rc, "mi_rccl_get_unique_id", (L.mi_rccl_last_error() or b"").decode())
+    return buf.raw
+
+
+class RcclComm:
+    """One rank's end of the exchange (mi_rccl_comm): collective construction, collective allgather_fold."""
+
+    def __init__(self, ctx: Context, unique_id: bytes, n_ranks: int, rank: int):
+        self._L = load_rccl_library()
+        self._h = C.c_void_p()
+        self._ctx = ctx   # the context must outlive the communicator
+        rc = self._L.mi_rccl_comm_create(C.byref(self._h), ctx._h, unique_id, n_ranks, rank)
+        if rc != 0:
+            raise MsmError(rc, "mi_rccl_comm_create", (self._L.mi_rccl_last_error() or b"").decode())
+
+    def close(self):
+        if self._h:
+            self._L.mi_rccl_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def size(self) -> int:
+        return self._L.mi_rccl_comm_size(self._h)
+
+    def rank(self) -> int:
+        return self._L.mi_rccl_comm_rank(self._h)
+
+    def allgather_fold(self, group: str, d_scalars_ptr: int, n: int, scalar_fmt: int = SCALAR_CANONICAL) -> bytes:
+        out = C.create_string_buffer(G1_JAC if group == "g1" else G2_JAC)
+        rc = getattr(self._L, f"mi_msm_{group}_allgather_fold")(self._h, C.c_void_p(d_scalars_ptr), n, scalar_fmt, out)
+        if rc != 0:
+            raise MsmError(rc, f"mi_msm_{group}_allgather_fold", (self._L.mi_rccl_last_error() or b"").decode())
+        return out.raw
+
+    def timing_raw(self) -> RcclTiming:
+        t = RcclTiming()
+        self._L.mi_rccl_last_timing(self._h, C.byref(t))
+        return t
+
+    def timing(self) -> dict:
+        t = self.timing_raw()
+        return {f: getattr(t, f) for f, _ in RcclTiming._fields_}

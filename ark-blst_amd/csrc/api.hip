@@ -131,6 +131,7 @@ void mi_msm_destroy(mi_ctx* ctx) {
 }
 
 int mi_msm_num_devices(const mi_ctx* ctx) { return ctx ? (int)ctx->devs.size() : 0; }
+int mi_msm_device_id(const mi_ctx* ctx, int slot) { return ctx && slot >= 0 && (size_t)slot < ctx->devs.size() ? ctx->devs[(size_t)slot].dev : -1; }
 
 int mi_msm_g1_set_bases(mi_ctx* ctx, const mi_g1_affine* bases, size_t n) { return g1_set_bases(ctx, bases, n, 0); }
 int mi_msm_g2_set_bases(mi_ctx* ctx, const mi_g2_affine* bases, size_t n) { return g2_set_bases(ctx, bases, n, 0); }
@@ -278,6 +279,7 @@ const char* mi_msm_strerror(int code) {
         case MI_E_NOMEM: return "out of memory";
         case MI_E_NO_BASES: return "no resident base set";
         case MI_E_UNSUPPORTED: return "not supported on this host (the library needs an x86-64 CPU with BMI2 and ADX)";
+        case MI_E_COMM: return "RCCL communication error";
         default: return "unknown error";
     }
 }

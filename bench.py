@@ -66,6 +66,13 @@ def _free_port() -> int:
         return sk.getsockname()[1]
 
 
+def _under_profiler() -> bool:
+    """rocprofv3 preloads its tool library into the process (and with --pmc initialises the GPU before main() runs): such a process
+    must not start child processes that use the GPU.  Profiling is single-process: tools/profile_bench.sh passes --no-secondary."""
+    env = os.environ
+    return any(k.startswith("ROCPROF") for k in env) or "rocprof" in env.get("LD_PRELOAD", "") or "rocprofiler" in env.get("HSA_TOOLS_LIB", "")
+
+
 def _self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as ONE child process tree (`python -m
     torch.distributed.run`, one rank per GPU) and relay its output and exit code.  The parent has not imported torch and never
@@ -423,44 +430,84 @@ NORM_FP_MULS_PER_POINT = 12          # product tree up + down (fan-out 32): ~5, 
 DESER_FP_MULS_PER_POINT = 570 + 1650  # y = (x^3 + 4)^((p+1)/4): 378 squarings + ~190 products; subgroup test: two 64-bit ladders on complete formulas
 
 
-def _normalize_leg(pkg, co, ncpu, device, log_n=20) -> dict:
-    """Row (f)-2 of SURVEY.md 8: CurveGroup::normalize_batch (src/g1.rs:537-543) for 2^20 G1 points with non-trivial Z through
-    mi_g1_normalize_batch (host buffers in and out; the kernels are timed on the library's stream), a sample checked against the C
-    oracle, which is also the timed CPU baseline."""
+# G2 decoder: two Fp2 exponentiations ((p-3)/4 and (p-1)/2: ~379 squarings at 2 Fp-mul + ~190 products at 3 each) = 2656; subgroup test:
+# one 64-bit ladder, 63 doublings at 22 Fp-mul + 5 complete additions at 36 = 1566
+DESER_G2_FP_MULS_PER_POINT = 2656 + 1566
+
+
+def _normalize_leg(pkg, co, ncpu, device, g="g1", log_n=20) -> dict:
+    """Row (f)-2 of SURVEY.md 8: CurveGroup::normalize_batch (src/g1.rs:537-543, src/g2.rs:517-523) for 2^20 points with non-trivial Z
+    through mi_g{1,2}_normalize_batch (host buffers in and out; the kernels are timed on the library's stream), all of them checked against
+    the C oracle, which is also the timed CPU baseline."""
     n = 1 << log_n
     m = 1 << 12
-    bases = co.gen_bases("g1", SEED_B + 201, m + 1, ncpu)
-    one = _mont_one()
-    jac = b"".join(co.sum_jac("g1", bases[96 * i:96 * i + 96] + one + bases[96 * (i + 1):96 * (i + 2)] + one, 2) for i in range(m))
+    aff, jb, G = (96, 144, "G1") if g == "g1" else (192, 288, "G2")
+    bases = co.gen_bases(g, SEED_B + 201, m + 1, ncpu)
+    one = _mont_one() if g == "g1" else _mont_one() + bytes(48)
+    jac = b"".join(co.sum_jac(g, bases[aff * i:aff * (i + 1)] + one + bases[aff * (i + 1):aff * (i + 2)] + one, 2) for i in range(m))
     blob = jac * (n // m)
     with pkg.Context([device]) as ctx:
-        ctx.normalize_batch("g1", blob[:144 * 1024])
+        ctx.normalize_batch(g, blob[:jb * 1024])
         best, kms, out = 1e30, None, b""
         for _ in range(3):
             t1 = time.perf_counter()
-            out = ctx.normalize_batch("g1", blob)
+            out = ctx.normalize_batch(g, blob)
             dt = time.perf_counter() - t1
             if dt < best:
                 best, kms = dt, ctx.profile()["accumulate_ms"]
     t1 = time.perf_counter()
-    cpu = co.normalize_batch("g1", blob, ncpu)
+    cpu = co.normalize_batch(g, blob, ncpu)
     cpu_s = time.perf_counter() - t1
     ok = out == cpu
-    mads = NORM_FP_MULS_PER_POINT * MADS_PER_FP_MUL
+    muls = NORM_FP_MULS_PER_POINT * (1 if g == "g1" else 3)
+    mads = muls * MADS_PER_FP_MUL
     clock, clock_src = _measured_clock("k_accumulate<msmk::G1C>")
-    gbs = (144 + 96) * n / (kms * 1e-3) / 1e9
-    return {"metric": "G1 points/s, normalize_batch (Jacobian -> affine, one inversion)", "value": n / (kms * 1e-3), "unit": "points/s", "n": n,
+    gbs = (jb + aff) * n / (kms * 1e-3) / 1e9
+    return {"metric": f"{G} points/s, normalize_batch (Jacobian -> affine, one inversion)", "value": n / (kms * 1e-3), "unit": "points/s", "n": n,
             "kernels_ms": kms, "call_ms_host_buffers": best * 1e3, "bit_exact": ok,
-            "workload": f"2^{log_n} G1 Jacobian points with non-trivial Z, host buffers in and out (PCIe-inclusive figure: call_ms_host_buffers)",
+            "workload": f"2^{log_n} {G} Jacobian points with non-trivial Z, host buffers in and out (PCIe-inclusive figure: call_ms_host_buffers)",
             "roofline": {"bound": "hbm", "kernel": "k_norm_load + k_norm_up/down x levels + k_norm_final", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": (144 + 96) * n, "kernel_ms": kms,
-                         "note": "algorithmic bytes = 144 B Jacobian in + 96 B affine out per point; the product tree adds ~3 x 64 B of "
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": (jb + aff) * n, "kernel_ms": kms,
+                         "note": f"algorithmic bytes = {jb} B Jacobian in + {aff} B affine out per point; the product tree adds ~3 slots of "
                                  "intermediate values per point and level-0 element; arithmetic is 12 field multiplications per point, "
                                  "so neither roof is close: the row is bound by its five dependent passes over the data"},
-            "valu_roofline": _valu_roofline("normalize kernels", f"{NORM_FP_MULS_PER_POINT} Fp-mul x {MADS_PER_FP_MUL} MAD per point", mads * n, kms, clock, clock_src, {}),
+            "valu_roofline": _valu_roofline("normalize kernels", f"{muls} Fp-mul x {MADS_PER_FP_MUL} MAD per point", mads * n, kms, clock, clock_src, {}),
             "cpu_baseline": {"value": n / cpu_s, "unit": "points/s", "cores": ncpu, "kind": "port", "cpu_model": _cpu_model(), "seconds": cpu_s,
                              "sample": f"the same 2^{log_n} points: Montgomery's simultaneous inversion per thread slice (oracle/msm_oracle.c "
-                                       "orc_g1_normalize_batch), what blstrs batch_normalize does"}}
+                                       "normalize_batch), what blstrs batch_normalize does"}}
+
+
+def _deserialize_g2_leg(pkg, co, ncpu, device, log_n=18) -> dict:
+    """Row (f)-4 for G2 (src/g2.rs:366-411): 2^18 compressed 96-byte encodings with Valid::check on through mi_g2_deserialize_batch (two
+    kernels: decoder, then the subgroup test).  Parity: every decoded point equals the point it was serialised from, and a 48-point sample
+    is decoded by the big-int oracle (oracle/bls12_381.py g2_deserialize — the C oracle has no G2 decoder, so this leg carries no
+    timed CPU baseline)."""
+    from oracle import bls12_381 as o
+    n = 1 << log_n
+    bases = co.gen_bases("g2", SEED_B + 203, n, ncpu)
+    with pkg.Context([device]) as ctx:
+        enc = ctx.serialize_batch("g2", bases, True)
+        ctx.deserialize_batch("g2", enc[:96 * 1024], True, True)
+        t1 = time.perf_counter()
+        dec, st = ctx.deserialize_batch("g2", enc, True, True)
+        wall = time.perf_counter() - t1
+        kms = ctx.profile()["accumulate_ms"]
+        ctx.deserialize_batch("g2", enc, True, False)
+        kms_novalidate = ctx.profile()["accumulate_ms"]
+    m = 48
+    sample_ok = True
+    for i in range(m):
+        pt, status = o.g2_deserialize(enc[96 * i:96 * (i + 1)], True, True)
+        sample_ok = sample_ok and status == 0 and o.affine_to_bytes(o.F2, pt) == dec[192 * i:192 * (i + 1)]
+    ok = dec == bases and st == bytes(n) and sample_ok
+    fp_muls = DESER_G2_FP_MULS_PER_POINT
+    clock, clock_src = _measured_clock("k_accumulate<msmk::G1C>")
+    return {"metric": "G2 points/s, deserialize_batch (compressed, validate on)", "value": n / (kms * 1e-3), "unit": "points/s", "n": n,
+            "kernel_ms": kms, "kernel_ms_validate_off": kms_novalidate, "call_ms_host_buffers": wall * 1e3, "bit_exact": ok,
+            "workload": f"2^{log_n} compressed G2 encodings (96 B), decompression (Fp2 square root) + on-curve + subgroup check, host buffers in and out",
+            "roofline": _valu_roofline("k_deserialize_g2 + k_validate<G2C>", f"~{fp_muls} Fp-mul x {MADS_PER_FP_MUL} MAD per point",
+                                       fp_muls * MADS_PER_FP_MUL * n, kms, clock, clock_src, {"traffic": None, "algorithmic_bytes_per_launch": (96 + 192) * n}),
+            "cpu_baseline": None}
 
 
 def _deserialize_leg(pkg, co, ncpu, device, log_n=20) -> dict:
@@ -547,6 +594,8 @@ def _in_process_isolated(pkg, co, torch, ncpu, slots: int) -> dict:
     time on whatever node runs this, so it runs in a child process (started, not exec'ed): a fault there costs this leg, not the line."""
     if torch.cuda.device_count() <= 1:
         return _in_process_leg(pkg, co, torch, ncpu, slots, 20, 5)
+    if _under_profiler():
+        return {"skipped": "under rocprofv3 this process must not start GPU child processes; run the leg unprofiled"}
     import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--in-process-child", "--in-process", str(slots)],
@@ -589,15 +638,18 @@ def main() -> None:
                     help="gloo + --share-device rehearses the N>1 path on a single-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (rehearsal only)")
     ap.add_argument("--force-exchange", action="store_true",
-                    help="run the N > 1 exchange path (device_windows -> all_gather_into_tensor -> one D2H -> fold_windows) at any world "
-                         "size, including 1: a one-GPU box then executes the RCCL branch under a one-rank nccl group")
-    ap.add_argument("--timing-breakdown", action="store_true",
-                    help="N > 1: put a barrier between the library call and the exchange INSIDE the timed steps (msm / wait / exchange "
-                         "per step; costs one more collective per step).  Default: the timed steps carry no extra barrier and the "
-                         "breakdown is taken from a few extra steps after the timed region")
+                    help="run the N > 1 exchange path (mi_msm_g1_allgather_fold: device_windows -> ncclAllGather -> one D2H -> fold_windows, all "
+                         "inside libarkblst_amd_rccl.so) at any world size, including 1: a one-GPU box then executes the RCCL calls under a "
+                         "one-rank communicator")
     args = ap.parse_args()
 
+    # dmabuf IPC: RCCL across processes needs it on this pool (the host driver has no legacy IPC).  Set before torch / HIP / RCCL load, for
+    # ranks started by an external launcher as much as for the ones _self_launch starts.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if _under_profiler():
+            raise SystemExit("bench.py --gpus N under rocprofv3 must be started through the launcher form (python -m torch.distributed.run ... "
+                             "bench.py): the profiler's preload has initialised the GPU in this process, which must then not start children")
         sys.exit(_self_launch(args.gpus))   # nothing below has run: this process never initialises the GPU
 
     import torch  # plumbing only: device buffers, synchronize, torch.distributed (RCCL)
@@ -670,16 +722,28 @@ def main() -> None:
 
     jac_bytes = 144 if g == "g1" else 288
     cdev = "cuda" if on_gpu else "cpu"
-    # ---- exchange step at N > 1: the library leaves this rank's per-window sums in DEVICE memory
-    # (mi_msm_g1_device_windows: no D2H, no host fold), RCCL all-gathers them over xGMI, ONE D2H copy of the gathered block,
-    # mi_g1_fold_windows adds the ranks per window in rank order and runs the Horner fold — identical result on every rank.
-    win_dev = torch.empty(pkg.MAX_WINDOWS * jac_bytes, dtype=torch.uint8, device="cuda") if exchange else None
-    xchg = {"info": None, "gather": None, "gather_host": None, "msm_s": 0.0, "wait_s": 0.0, "exchange_s": 0.0, "steps": 0,
-            "barrier": bool(args.timing_breakdown), "backend": args.backend,
-            "path": "window sums in device memory -> all_gather_into_tensor -> one D2H of the gathered block -> mi_%s_fold_windows" % g}
+    # ---- exchange step at N > 1, INSIDE the product: mi_msm_g{1,2}_allgather_fold (libarkblst_amd_rccl.so) leaves this
+    # rank's per-window sums in device memory, all-gathers them with ncclAllGather over xGMI, copies the gathered block to the host ONCE
+    # and folds — identical result on every rank.  torch only starts the ranks, carries the 128-byte ncclUniqueId to them and
+    # brackets the timed region (barrier, max over ranks).  `--backend gloo --share-device` (several ranks on ONE GPU, where RCCL
+    # refuses to form a communicator) rehearses the same steps with a host collective instead.
+    xchg = {"info": None, "gather_host": None, "msm_s": 0.0, "exchange_s": 0.0, "steps": 0, "backend": "rccl (in-library)" if on_gpu else "gloo",
+            "comm": None, "repeats": 0,
+            "path": ("mi_msm_%s_allgather_fold: window sums in device memory -> ncclAllGather -> one D2H of the gathered block -> mi_%s_fold_windows" % (g, g))
+            if on_gpu else ("rehearsal: mi_msm_%s_device_windows -> host all_gather (gloo) -> mi_%s_fold_windows" % (g, g))}
+    win_dev = torch.empty(pkg.MAX_WINDOWS * jac_bytes, dtype=torch.uint8, device="cuda") if exchange and not on_gpu else None
 
     def setup_exchange():
-        """one untimed call: learn the window geometry, make every rank agree on it, size the gather buffers"""
+        if on_gpu:
+            uid = [pkg.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            xchg["comm"] = pkg.RcclComm(leg.ctx, uid[0], world, rank)   # collective: ncclCommInitRank
+            xchg["comm"].allgather_fold(g, leg.d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)   # untimed: ragged shards agree on a window size here
+            t = xchg["comm"].timing()
+            xchg["info"] = (t["window_bits"], t["num_windows"])
+            xchg["bytes_per_rank"] = t["bytes_per_rank"]
+            return
+        # gloo rehearsal: learn the window geometry, make every rank agree on it, size the gather buffer
         info = leg.ctx.msm_device_windows(g, leg.d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL, win_dev.data_ptr())
         infos = [None] * world
         dist.all_gather_object(infos, info)
@@ -689,32 +753,29 @@ def main() -> None:
             dist.all_gather_object(infos, info)
             assert len(set(infos)) == 1, infos
         xchg["info"] = info
-        nb = info[1] * jac_bytes
-        xchg["gather"] = torch.empty(world * nb, dtype=torch.uint8, device=cdev)
-        gh = torch.empty(world * nb, dtype=torch.uint8)
-        xchg["gather_host"] = gh.pin_memory() if on_gpu else gh
+        xchg["bytes_per_rank"] = info[1] * jac_bytes
+        xchg["gather_host"] = torch.empty(world * info[1] * jac_bytes, dtype=torch.uint8)
 
     def step() -> bytes:
         if not exchange:
             return leg.call()
+        if on_gpu:
+            out = xchg["comm"].allgather_fold(g, leg.d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)
+            t = xchg["comm"].timing_raw()
+            xchg["msm_s"] += t.msm_ms * 1e-3
+            xchg["exchange_s"] += t.exchange_ms * 1e-3
+            xchg["repeats"] += t.repeats
+            xchg["steps"] += 1
+            return out
         t_a = time.perf_counter()
         info = leg.ctx.msm_device_windows(g, leg.d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL, win_dev.data_ptr())
         t_b = time.perf_counter()
-        if xchg["barrier"]:
-            dist.barrier()   # separates waiting for the slowest rank (wait_ms) from the exchange proper (exchange_ms)
-        t_w = time.perf_counter()
         nb = info[1] * jac_bytes
-        if on_gpu:
-            dist.all_gather_into_tensor(xchg["gather"], win_dev[:nb])      # RCCL over xGMI: N x W x 144 B, from device memory
-            xchg["gather_host"].copy_(xchg["gather"], non_blocking=True)    # the one D2H copy of the step
-            torch.cuda.current_stream().synchronize()
-        else:                                                               # gloo rehearsal: host collective
-            dist.all_gather_into_tensor(xchg["gather_host"], win_dev[:nb].cpu())
+        dist.all_gather_into_tensor(xchg["gather_host"], win_dev[:nb].cpu())
         out = pkg.fold_windows(g, xchg["gather_host"].numpy(), world, info[1], *info)
         t_c = time.perf_counter()
         xchg["msm_s"] += t_b - t_a
-        xchg["wait_s"] += t_w - t_b
-        xchg["exchange_s"] += t_c - t_w
+        xchg["exchange_s"] += t_c - t_b
         xchg["steps"] += 1
         return out
 
@@ -728,7 +789,7 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     prof_acc = []
-    xchg.update(msm_s=0.0, wait_s=0.0, exchange_s=0.0, steps=0)
+    xchg.update(msm_s=0.0, exchange_s=0.0, steps=0, repeats=0)
     fence()
     t0 = time.perf_counter()
     result = b""
@@ -742,16 +803,14 @@ def main() -> None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        if not xchg["barrier"]:
-            # breakdown pass OUTSIDE the timed region: the timed steps carry no barrier (one collective less per step); a few more
-            # steps with one tell how a step splits into library call / waiting for the slowest rank / exchange proper
-            headline_steps = {k: xchg[k] for k in ("msm_s", "exchange_s", "steps")}
-            xchg.update(msm_s=0.0, wait_s=0.0, exchange_s=0.0, steps=0, barrier=True)
-            for _ in range(min(5, max(2, args.steps))):
-                step()
-            fence()
-            xchg["barrier"] = False
-            xchg["headline_steps"] = headline_steps
+        # how a step splits: every rank's local part (up to its window sums in device memory) — the slowest rank sets the pace, the
+        # others wait for it inside the all-gather: wait_ms = slowest local part - rank 0's; what remains of rank 0's exchange time
+        # is the collective proper + the one D2H + the host fold.  No barrier inside the timed steps.
+        ks = max(1, xchg["steps"])
+        mine = torch.tensor([xchg["msm_s"] / ks * 1e3], dtype=torch.float64, device=cdev)
+        allm = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allm, mine)
+        xchg["rank_msm_ms"] = [float(t.item()) for t in allm]
 
     breakdown = leg.phase_breakdown(3 if n <= (1 << 22) else 1)   # right after the timed region (warm clocks): every phase's events
 
@@ -833,6 +892,10 @@ def main() -> None:
     headline_n, gen_s = n, leg.gen_s
     p0 = prof_acc[-1]
     acc_ms = sum(p["accumulate_ms"] for p in prof_acc) / len(prof_acc)
+    if xchg.get("comm") is not None:
+        if world > 1:
+            dist.barrier()       # ncclCommDestroy is collective-ish: nobody tears down while a peer is still inside a step
+        xchg["comm"].close()     # before the context it sits on
     leg.close()
     del leg
 
@@ -852,6 +915,8 @@ def main() -> None:
         if g == "g1" and log_n == 20 and not args.precomputed and args.dist == "uniform":
             guarded("normalize_2p20", lambda: _normalize_leg(pkg, co, ncpu, local_rank))
             guarded("deserialize_2p20", lambda: _deserialize_leg(pkg, co, ncpu, local_rank))
+            guarded("normalize_g2_2p20", lambda: _normalize_leg(pkg, co, ncpu, local_rank, "g2"))
+            guarded("deserialize_g2_2p18", lambda: _deserialize_g2_leg(pkg, co, ncpu, local_rank))
         guarded("in_process_multi_device", lambda: _in_process_isolated(pkg, co, torch, ncpu, args.in_process))
 
     if rank == 0:
@@ -889,18 +954,15 @@ def main() -> None:
             exp_ms, exp_src = _expected_ms(g, log_n) if log_n is not None else (None, None)
             out["config"]["expected_ms_per_rank"] = exp_ms
             ks = max(1, xchg["steps"])
-            out["msm_ms"] = xchg["msm_s"] / ks * 1e3            # rank 0: the library call up to the window sums in device memory
-            out["wait_ms"] = xchg["wait_s"] / ks * 1e3          # rank 0: barrier until the slowest rank has its window sums (load imbalance)
-            out["exchange_ms"] = xchg["exchange_s"] / ks * 1e3  # rank 0: all-gather + one D2H + host fold, inside the library
-            out["exchange"] = {"backend": xchg["backend"], "world_size": world, "bytes_per_rank": xchg["info"][1] * jac_bytes,
-                               "windows": xchg["info"][1], "window_bits": xchg["info"][0], "path": xchg["path"]}
-            detail["exchange"] = {"expected_ms_source": exp_src,
-                                  "breakdown_from": "the timed steps (--timing-breakdown: a barrier inside every step)" if args.timing_breakdown
-                                  else f"{ks} extra steps with a barrier, run after the timed region (the timed steps carry none)"}
-            if "headline_steps" in xchg:
-                hs = xchg["headline_steps"]
-                out["exchange"]["timed_steps_msm_ms"] = hs["msm_s"] / max(1, hs["steps"]) * 1e3
-                out["exchange"]["timed_steps_exchange_incl_wait_ms"] = hs["exchange_s"] / max(1, hs["steps"]) * 1e3
+            rm = xchg["rank_msm_ms"]
+            out["msm_ms"] = rm[0]                                             # rank 0: the local pipeline up to its window sums in device memory
+            out["wait_ms"] = max(0.0, max(rm) - rm[0])                        # rank 0 inside the all-gather until the slowest rank arrives (load imbalance)
+            out["exchange_ms"] = max(0.0, xchg["exchange_s"] / ks * 1e3 - out["wait_ms"])   # header + all-gather + one D2H + host fold
+            out["exchange"] = {"backend": xchg["backend"], "world_size": world, "bytes_per_rank": xchg["bytes_per_rank"],
+                               "windows": xchg["info"][1], "window_bits": xchg["info"][0], "path": xchg["path"],
+                               "rank_msm_ms": [round(x, 4) for x in rm], "exchange_incl_wait_ms": xchg["exchange_s"] / ks * 1e3,
+                               "window_size_repeats_in_timed_steps": xchg["repeats"]}
+            detail["exchange"] = {"expected_ms_source": exp_src}
         if cpu_baseline:
             out["cpu_baseline"] = cpu_baseline
         # compact recap: the north-star figures of every leg (the full records of the legs go to the sidecar file)
@@ -910,7 +972,7 @@ def main() -> None:
                 b["valu_frac"] = round(d["roofline"]["frac"], 3)
             if "step_frac" in d:
                 b["step_frac"] = round(d["step_frac"], 3)
-            if "cpu_baseline" in d and d is not out:
+            if d.get("cpu_baseline") and d is not out:
                 b["cpu"] = d["cpu_baseline"]["value"]
             return {k: (float("%.4g" % v) if isinstance(v, float) else v) for k, v in b.items()}
         summary = {f"{g}_2p{log_n}" if log_n is not None else f"{g}_{headline_n}": _brief(out)}

@@ -58,7 +58,8 @@ enum {
     MI_E_HIP = -3,          /* a HIP runtime call failed; mi_msm_last_error() has the text */
     MI_E_NOMEM = -4,        /* device or host allocation failed */
     MI_E_NO_BASES = -5,     /* bases == NULL but no resident base set was uploaded */
-    MI_E_UNSUPPORTED = -6   /* host CPU lacks BMI2 / ADX (the host tail is built for them) */
+    MI_E_UNSUPPORTED = -6,  /* host CPU lacks BMI2 / ADX (the host tail is built for them) */
+    MI_E_COMM = -7          /* an RCCL call of the multi-process exchange failed (libarkblst_amd_rccl.so, arkblst_amd_rccl.h) */
 };
 
 /* Per-call timing of the last MSM on this context, milliseconds, measured with HIP events on the
@@ -91,6 +92,8 @@ typedef struct {
 int mi_msm_init(mi_ctx **out, const int *device_ids, int n_devices);
 void mi_msm_destroy(mi_ctx *ctx);
 int mi_msm_num_devices(const mi_ctx *ctx);
+/* HIP device ordinal of device slot `slot` of the context (0 <= slot < mi_msm_num_devices), -1 otherwise. */
+int mi_msm_device_id(const mi_ctx *ctx, int slot);
 
 /* Optional: keep a base set resident in HBM across calls (an SRS).  The reference re-uploads the bases on
  * every call (src/gpu.rs:149).  Copies; no pointer is retained. */

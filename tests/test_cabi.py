@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "arkblst_amd.h")).read()
+def _declared_symbols(header="arkblst_amd.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", text)))
 
@@ -21,6 +21,24 @@ def test_header_symbols_are_exported(pkg):
     assert len(syms) >= 16
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/arkblst_amd.h but not exported"
+
+
+def test_rccl_header_symbols_are_exported(pkg):
+    """include/arkblst_amd_rccl.h against libarkblst_amd_rccl.so: every declared entry point is exported, the RCCL calls are IMPORTED
+    (the library, not a Python host, issues the collective), and the product library itself does not pull RCCL in."""
+    import subprocess
+
+    L = pkg.load_rccl_library()
+    syms = _declared_symbols("arkblst_amd_rccl.h")
+    assert len(syms) >= 9 and "mi_msm_g1_allgather_fold" in syms and "mi_msm_g2_allgather_fold" in syms
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/arkblst_amd_rccl.h but not exported"
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", pkg.rccl_lib_path()]).decode()
+    for s in ("ncclAllGather", "ncclCommInitRank", "ncclGetUniqueId", "mi_msm_g1_device_windows", "mi_g1_fold_windows"):
+        assert s in und, s
+    needed = subprocess.check_output(["readelf", "-d", pkg.rccl_lib_path()]).decode()
+    assert "librccl.so.1" in needed and "libarkblst_amd.so" in needed
+    assert "rccl" not in subprocess.check_output(["readelf", "-d", pkg.lib_path()]).decode()
 
 
 def _exported(path):

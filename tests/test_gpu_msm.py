@@ -673,7 +673,13 @@ def test_call_abi_reproducer():
     lib = os.path.join(root, "ark-blst_amd", "lib")
     good = subprocess.run([os.path.join(lib, "repro_call_abi")], capture_output=True, text=True, timeout=300)
     assert good.returncode == 0 and "miller loop, 63 rounds: 0 of 64" in good.stdout, good.stdout[-1500:] + good.stderr[-500:]
-    dflt = subprocess.run([os.path.join(lib, "repro_call_abi_compiler_default")], capture_output=True, text=True, timeout=300)
+    # The expected-to-FAIL half (the same source with the compiler's default flags) is opt-in: a miscompiled 512-register kernel has only
+    # ever corrupted data values, but nothing says the next compiler will not clobber an address register on a shared box.
+    # `make -C ark-blst_amd/csrc repro-default` builds it into tools/call_abi/; ARKBLST_RUN_BROKEN_REPRO=1 runs it.
+    broken = os.path.join(root, "tools", "call_abi", "repro_call_abi_compiler_default")
+    if os.environ.get("ARKBLST_RUN_BROKEN_REPRO") != "1" or not os.path.exists(broken):
+        return
+    dflt = subprocess.run([broken], capture_output=True, text=True, timeout=300)
     # the isolated tower functions are right either way; only the loop kernel is affected
     for piece in ("conj12", "sqr12", "mul_by_014", "chain"):
         assert f"{piece}: 0 of 64" in dflt.stdout, dflt.stdout[-1500:]
@@ -705,11 +711,45 @@ def test_bench_json_contract():
         assert k in d["roofline"], k
     # the roofline key names the BINDING bound of this path (integer multiply-add issue); the HBM line the north star asks for sits beside it
     assert d["roofline"]["bound"] == "valu_int_mad" and d["roofline"]["unit"] == "T MAD/s" and 0.05 < d["roofline"]["frac"] < 1.0
-    assert d["hbm_roofline"]["bound"] == "hbm" and d["hbm_roofline"]["unit"] == "GB/s" and d["valu_roofline"] == d["roofline"]
+    assert d["hbm_roofline"]["bound"] == "hbm" and d["hbm_roofline"]["unit"] == "GB/s" and "valu_roofline" not in d
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port"
-    assert list(d)[-1] == "summary" and d["summary"]["g1_2p14"]["bit_exact"] is True   # the recap closes the line (log tails keep it)
+    assert d["summary"]["g1_2p14"]["bit_exact"] is True and 0.0 < d["step_frac"] < d["roofline"]["frac"]
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 8192   # the record is the LAST stdout line and small
+
+
+def test_bench_default_invocation_is_one_small_line(tmp_path):
+    """the DEFAULT invocation — every secondary leg on, the form the driver runs — prints exactly one JSON line, the last
+    line of stdout, under 8 KB, with `roofline`, `cpu_baseline` and `step_frac` in it; the legs' full records are in the sidecar file."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    side = str(tmp_path / "secondary.json")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--secondary-out", side],
+                       capture_output=True, text=True, timeout=1500, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and r.stdout.rstrip().splitlines()[-1] == lines[0]
+    assert len(lines[0]) < 8192, len(lines[0])
+    d = json.loads(lines[0])
+    assert d["bit_exact"] is True and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["config"]["workload"].startswith("G1 MSM, 2^20") and d["dtype"] == "u32" and d["vs_baseline"] is None
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms"):
+        assert k in d["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert 0.0 < d["step_frac"] <= d["roofline"]["frac"] < 1.0
+    assert "secondary" not in d and "pairing_2p16" not in d and "valu_roofline" not in d
+    sec = json.load(open(side))["secondary"]
+    for leg in ("g1_2p16", "g1_2p24", "g2_2p20", "pairing_2p16", "normalize_2p20", "deserialize_2p20", "normalize_g2_2p20", "deserialize_g2_2p18",
+                "call_shapes", "two_host_threads"):
+        assert leg in sec and "error" not in sec[leg], (leg, sec.get(leg))
+    for leg in ("g1_2p16", "g1_2p24", "g2_2p20", "pairing_2p16", "normalize_2p20", "deserialize_2p20", "normalize_g2_2p20", "deserialize_g2_2p18"):
+        assert sec[leg]["bit_exact"] is True, leg
+        assert d["summary"][leg]["bit_exact"] is True
 
 
 def test_bench_in_process_leg_as_child_process():
@@ -749,8 +789,8 @@ def test_bench_two_ranks_exchange_from_device_memory():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["bit_exact"] is True and d["scaling"] == "strong" and d["config"]["total_points"] == 1 << 15
-    assert d["exchange_ms"] > 0 and d["msm_ms"] > 0 and d["exchange"]["windows"] == d["config"]["num_windows"]
-    assert d["summary"]["n_gpus"] == 2 and "expected_ms_per_rank" in d["config"]
+    assert d["exchange_ms"] >= 0 and d["msm_ms"] > 0 and d["exchange"]["windows"] == d["config"]["num_windows"]
+    assert d["exchange"]["backend"] == "gloo" and len(d["exchange"]["rank_msm_ms"]) == 2 and "expected_ms_per_rank" in d["config"]
 
 
 def test_bench_self_launch_two_ranks():
@@ -769,30 +809,60 @@ def test_bench_self_launch_two_ranks():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["bit_exact"] is True and d["scaling"] == "strong" and d["exchange"]["world_size"] == 2
-    assert d["exchange"]["timed_steps_msm_ms"] > 0 and d["wait_ms"] >= 0   # breakdown from the extra steps, none inside the timed ones
+    assert d["exchange"]["exchange_incl_wait_ms"] > 0 and d["wait_ms"] >= 0   # split from the ranks' local times: no barrier inside the timed steps
 
 
-def test_bench_exchange_runs_under_one_rank_rccl():
-    """The RCCL branch of bench.py's exchange on a one-GPU box: --force-exchange runs the N > 1 step at world size 1 under an `nccl`
-    process group — mi_msm_g1_device_windows leaves the window sums in device memory, all_gather_into_tensor on the DEVICE buffer
-    (RCCL), the pinned D2H copy, mi_g1_fold_windows — and the result is bit-exact.  (The gloo rehearsals never execute this branch.)"""
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_bench_exchange_runs_under_one_rank_rccl(group):
+    """The exchange of bench.py's N > 1 path on a one-GPU box: --force-exchange runs it at world size 1 — mi_msm_g{1,2}_allgather_fold of
+    libarkblst_amd_rccl.so (window sums in device memory, ncclAllGather on the device buffer, the pinned D2H copy, the fold), under a
+    one-rank RCCL communicator created from an ncclUniqueId — and the result is bit-exact.  (The gloo rehearsals never execute it.)"""
     import json
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-exchange", "--log-n", "16", "--steps", "3", "--warmup", "1", "--no-secondary",
-           "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-exchange", "--group", group, "--log-n", "16", "--steps", "3", "--warmup", "1",
+           "--no-secondary", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["bit_exact"] is True
-    assert d["exchange"]["backend"] == "nccl" and d["exchange"]["world_size"] == 1 and d["exchange"]["windows"] == d["config"]["num_windows"]
-    assert d["exchange_ms"] > 0 and d["msm_ms"] > 0
+    assert d["n_gpus"] == 1 and d["bit_exact"] is True and d["metric"].startswith(group.upper())
+    assert d["exchange"]["backend"].startswith("rccl") and d["exchange"]["world_size"] == 1 and d["exchange"]["windows"] == d["config"]["num_windows"]
+    assert d["exchange_ms"] > 0 and d["msm_ms"] > 0 and d["exchange"]["window_size_repeats_in_timed_steps"] == 0
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_rccl_allgather_fold_world_size_one(pkg, co, group):
+    """libarkblst_amd_rccl.so through its C ABI at world size 1: the collective result equals mi_msm_{g}_device on the same inputs and the
+    C oracle; n = 0 gives infinity; a shorter call after a longer one (stale window slots) is right; the timing record is filled."""
+    import torch
+
+    n = 5000
+    jac = 144 if group == "g1" else 288
+    bases = co.gen_bases(group, 31337, n, 4)
+    sc = co.gen_scalars(31338, n)
+    d_sc = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    with pkg.Context([0]) as c:
+        c.set_bases(group, bases, n)
+        with pkg.RcclComm(c, pkg.rccl_unique_id(), 1, 0) as comm:
+            assert comm.size() == 1 and comm.rank() == 0
+            got = comm.allgather_fold(group, d_sc.data_ptr(), n, pkg.SCALAR_CANONICAL)
+            assert _canon(co, group, got) == _canon(co, group, c.msm_device(group, d_sc.data_ptr(), n, pkg.SCALAR_CANONICAL))
+            assert _canon(co, group, got) == _canon(co, group, co.msm(group, bases, sc, n, 0, 4))
+            t = comm.timing()
+            assert t["msm_ms"] > 0 and t["exchange_ms"] > 0 and t["repeats"] == 0 and t["num_windows"] > 0 and t["bytes_per_rank"] == 38 * jac
+            assert comm.allgather_fold(group, 0, 0, pkg.SCALAR_CANONICAL) == bytes(jac)      # nobody has a point: infinity
+            short = comm.allgather_fold(group, d_sc.data_ptr(), 100, pkg.SCALAR_CANONICAL)
+            assert _canon(co, group, short) == _canon(co, group, co.msm(group, bases[:100 * (jac * 2 // 3)], sc[:3200], 100, 0, 1))
+        # a multi-device context is refused (one context per rank)
+        with pkg.Context([0, 0]) as c2:
+            with pytest.raises(pkg.MsmError):
+                pkg.RcclComm(c2, pkg.rccl_unique_id(), 1, 0)
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE sizes

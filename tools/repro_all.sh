@@ -15,7 +15,7 @@ python tools/bench_deserialize.py 20 > gpurun_out/repro/deserialize.txt 2>&1 || 
 python - <<'PY'
 import json
 d = json.loads([l for l in open("gpurun_out/repro/bench_default.json") if l.startswith("{")][-1])
-print("g1_2p20", "%.3g points/s" % d["value"], "%.2f ms" % d["ms_per_step"], "bit_exact", d["bit_exact"], "valu frac %.2f" % d["valu_roofline"]["frac"],
+print("g1_2p20", "%.3g points/s" % d["value"], "%.2f ms" % d["ms_per_step"], "bit_exact", d["bit_exact"], "valu frac %.2f" % d["roofline"]["frac"],
       "cpu_baseline %.3g" % d["cpu_baseline"]["value"])
 for k, v in d["secondary"].items():
     if "error" in v:
