@@ -78,6 +78,10 @@ def load_library(test_hooks: bool = False):
         L.mi_multi_pairing.argtypes = [vp, vp, vp, sz, vp]
         L.mi_final_exponentiation.argtypes = [vp, vp]
         L.mi_msm_set_window_bits.argtypes = [vp, u]
+        L.mi_msm_set_base_cache.argtypes = [vp, u]
+        L.mi_msm_invalidate_base_cache.argtypes = [vp]
+        L.mi_msm_base_cache_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(u)]
+        L.mi_msm_device_id.argtypes = [vp, i]
         L.mi_msm_set_profile_level.argtypes = [vp, i]
         L.mi_msm_last_profile.argtypes = [vp, C.POINTER(Profile)]
         if hasattr(L, "mi_pairing_last_profile"):
@@ -151,6 +155,21 @@ class Context:
 
     def set_window_bits(self, c: int):
         self._check(self._L.mi_msm_set_window_bits(self._h, c), "mi_msm_set_window_bits")
+
+    def set_base_cache(self, entries: int):
+        """base-set cache of the stateless call shape (mi_msm_set_base_cache): 0 = off"""
+        self._check(self._L.mi_msm_set_base_cache(self._h, entries), "mi_msm_set_base_cache")
+
+    def invalidate_base_cache(self):
+        self._check(self._L.mi_msm_invalidate_base_cache(self._h), "mi_msm_invalidate_base_cache")
+
+    def base_cache_stats(self) -> dict:
+        h, m, e = C.c_uint64(0), C.c_uint64(0), C.c_uint(0)
+        self._check(self._L.mi_msm_base_cache_stats(self._h, C.byref(h), C.byref(m), C.byref(e)), "mi_msm_base_cache_stats")
+        return {"hits": h.value, "misses": m.value, "entries": e.value}
+
+    def device_id(self, slot: int = 0) -> int:
+        return self._L.mi_msm_device_id(self._h, slot)
 
     def set_profile_level(self, level: int):
         """0: no timing events, 1 (default): the accumulate kernel's interval only, 2: every phase of mi_profile."""

@@ -76,6 +76,11 @@ int mi_msm_init(mi_ctx** out, const int* device_ids, int n_devices) {
                 for (auto& e : d->cev) HIP_TRY(hipEventCreate(&e));
             }
         }
+        if (const char* e = getenv("ARKBLST_AMD_BASE_CACHE")) {   // the operator's switch: overrides mi_msm_set_base_cache
+            long v = strtol(e, nullptr, 10);
+            ctx->cache_entries = (unsigned)std::min<long>(std::max<long>(v, 0), MI_BASE_CACHE_MAX);
+            ctx->cache_env = true;
+        }
         if (n_devices > 1) {
             // one persistent host thread per device and lane (nothing is spawned per call); peer access so that a device can read
             // its shard of a scalar vector that lives on another device of the context (xGMI)
@@ -123,6 +128,7 @@ void mi_msm_destroy(mi_ctx* ctx) {
             if (d.copy_stream) (void)hipStreamDestroy(d.copy_stream);
             if (d.stream) (void)hipStreamDestroy(d.stream);
         }
+    for (auto& v : ctx->cache) v.clear();   // entries free their shards on their own devices
     for (size_t k = 0; k < ctx->residents.size() && k < ctx->devs.size(); k++) {
         (void)hipSetDevice(ctx->devs[k].dev);
         for (Resident& x : ctx->residents[k]) { x.buf.release(); x.flags.release(); }
@@ -233,6 +239,41 @@ int mi_g2_sum(const mi_g2* partials, size_t n, mi_g2* out) {
         r = r.add(p);
     }
     memcpy(out, &r, sizeof r);
+    return MI_OK;
+}
+
+int mi_msm_set_base_cache(mi_ctx* ctx, unsigned entries) {
+    if (!ctx || entries > MI_BASE_CACHE_MAX) return fail(ctx, MI_E_INVALID, "entries must be 0..MI_BASE_CACHE_MAX");
+    DeviceRestore restore;
+    std::vector<std::shared_ptr<BaseCacheEntry>> dropped;   // freed outside the lock
+    {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        if (ctx->cache_env) return MI_OK;   // ARKBLST_AMD_BASE_CACHE decides
+        ctx->cache_entries = entries;
+        for (auto& v : ctx->cache)
+            while (v.size() > entries) { dropped.push_back(v.back()); v.pop_back(); }
+    }
+    return MI_OK;
+}
+
+int mi_msm_invalidate_base_cache(mi_ctx* ctx) {
+    if (!ctx) return MI_E_INVALID;
+    DeviceRestore restore;
+    std::vector<std::shared_ptr<BaseCacheEntry>> dropped;
+    {
+        std::lock_guard<std::mutex> lk(ctx->cache_mu);
+        for (auto& v : ctx->cache) { for (auto& e : v) dropped.push_back(e); v.clear(); }
+    }
+    return MI_OK;
+}
+
+int mi_msm_base_cache_stats(const mi_ctx* ctx, uint64_t* hits, uint64_t* misses, unsigned* entries_in_use) {
+    if (!ctx) return MI_E_INVALID;
+    mi_ctx* c = const_cast<mi_ctx*>(ctx);
+    std::lock_guard<std::mutex> lk(c->cache_mu);
+    if (hits) *hits = c->cache_hits;
+    if (misses) *misses = c->cache_misses;
+    if (entries_in_use) *entries_in_use = (unsigned)(c->cache[0].size() + c->cache[1].size());
     return MI_OK;
 }
 

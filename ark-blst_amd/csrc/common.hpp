@@ -105,6 +105,26 @@ struct Resident {
     bool validated = false;   // every point passed Valid::check on the GPU (mi_msm_g{1,2}_validate_bases): MSMs over this set may fold signs
 };
 
+// One cached base set of the stateless call shape (mi_msm_set_base_cache): the device-form shards of a host base vector the context has
+// seen, keyed by (host pointer, length, fingerprint of a fixed sample of its points).  Lanes hold a shared_ptr while they use it, so an
+// eviction by the other lane frees the memory only when the last user is done.
+struct BaseCacheEntry {
+    const void* ptr = nullptr;
+    size_t n = 0;
+    uint64_t fp = 0;
+    uint64_t stamp = 0;             // LRU clock
+    std::vector<Resident> shard;    // one per device of the context
+    std::vector<int> devs;          // their HIP ordinals (the buffers are freed on the right device)
+    ~BaseCacheEntry() {
+        for (size_t k = 0; k < shard.size(); k++) {
+            if (!shard[k].buf.p && !shard[k].flags.p) continue;
+            (void)hipSetDevice(devs[k]);
+            shard[k].buf.release();
+            shard[k].flags.release();
+        }
+    }
+};
+
 // Per-device state of ONE LANE of a context: stream, events and scratch.  A context has two lanes per device so that two
 // host threads (arkworks calls the trait method from rayon workers) overlap: one call's sort / reduce / host tail runs
 // under the other's accumulate kernel.  The resident bases are shared.
@@ -215,6 +235,12 @@ struct mi_ctx {
     bool lane_busy[mi::NLANES] = {false, false};
     mutable std::mutex info_mu;                                  // prof / err
     unsigned forced_c = 0;
+    // base-set cache of the stateless call shape (api.hip mi_msm_set_base_cache); [0] = G1, [1] = G2
+    std::mutex cache_mu;
+    unsigned cache_entries = 0;       // 0 = off
+    bool cache_env = false;           // ARKBLST_AMD_BASE_CACHE was set: it overrides mi_msm_set_base_cache
+    uint64_t cache_clock = 0, cache_hits = 0, cache_misses = 0;
+    std::vector<std::shared_ptr<mi::BaseCacheEntry>> cache[2];
     int profile_level = 1;   // 0: no timing events beyond the one the pipeline waits on; 1: + the accumulate kernel's interval; 2: every phase
     mi_profile prof{};
     mi_pairing_profile pprof{};

@@ -261,9 +261,12 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
 }
 
 // One device's share of an MSM call. bases: host raw pointer for this shard or nullptr (= resident, starting at resident index r0).
+// cached (base-set cache, mi_msm_set_base_cache): with bases == nullptr the resident set to read instead of the context's; with
+// bases != nullptr the entry being FILLED — the call's converted points are written into it instead of the lane's scratch, so that a
+// miss costs exactly what the uncached call costs.
 template <class C>
 typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bases, size_t r0, const uint8_t* scalars, bool scalars_on_device,
-                                    size_t n, unsigned fmt, int stage_from_dev = -1, WinOut* wo = nullptr) {
+                                    size_t n, unsigned fmt, int stage_from_dev = -1, WinOut* wo = nullptr, Resident* cached = nullptr) {
     using J = typename HostCurve<C>::J;
     HIP_TRY(hipSetDevice(d.dev));
     d.prof = mi_profile{};
@@ -272,9 +275,15 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
     J total = J::inf();
     if (n == 0) return total;
     hipStream_t s = d.stream;
-    Resident& res = d.res[HostCurve<C>::IDX];
+    Resident& res = (cached && !bases) ? *cached : d.res[HostCurve<C>::IDX];
     const bool shared = !bases && res.tables > 1;
     const size_t part_max = max_part(ctx);
+    DevBuf& conv_bases = cached && bases ? cached->buf : d.call_bases;   // where the call's converted points go
+    DevBuf& conv_flags = cached && bases ? cached->flags : d.call_flags;
+    if (cached && bases) {   // the whole shard in one buffer, whatever the number of passes
+        cached->buf.ensure(n * msmk::Geo<C>::PT_WORDS * 4);
+        cached->flags.ensure(n);
+    }
     if (wo && n > part_max) throw HipFail{"device_windows: n exceeds one pass of the pipeline (2^26 points per device)", false, true};
     // A failure between enqueueing the chunked H2D copies (copy stream) and the call's final synchronisation must not return while
     // copies still read the caller's host buffers and write this lane's scratch: drain both streams before the error leaves
@@ -311,8 +320,11 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
         const uint8_t* d_flags;
         if (bases) {
             d.raw.ensure(m * aff_bytes<C>());
-            d.call_bases.ensure(m * msmk::Geo<C>::PT_WORDS * 4);
-            d.call_flags.ensure(m);
+            const size_t base0 = cached ? lo : 0;   // a cache entry keeps every pass; the lane's scratch is reused per pass
+            if (!cached) {
+                conv_bases.ensure(m * msmk::Geo<C>::PT_WORDS * 4);
+                conv_flags.ensure(m);
+            }
             const size_t K = std::min<size_t>(8, std::max<size_t>(1, m >> 16));
             for (size_t j = 0; j < K; j++) {
                 const size_t p0 = m * j / K, p1 = m * (j + 1) / K;
@@ -321,12 +333,12 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
                 HIP_TRY(hipEventRecord(d.cev[1 + j], d.copy_stream));
                 HIP_TRY(hipStreamWaitEvent(s, d.cev[1 + j], 0));
                 if (p1 > p0)
-                    ingest<C>(d, (const char*)d.raw.p + p0 * aff_bytes<C>(), true, p1 - p0, (uint32_t*)d.call_bases.p + p0 * msmk::Geo<C>::PT_WORDS,
-                              (uint8_t*)d.call_flags.p + p0);
+                    ingest<C>(d, (const char*)d.raw.p + p0 * aff_bytes<C>(), true, p1 - p0, (uint32_t*)conv_bases.p + (base0 + p0) * msmk::Geo<C>::PT_WORDS,
+                              (uint8_t*)conv_flags.p + base0 + p0);
             }
             if (d.prof_level >= 2) HIP_TRY(hipEventRecord(d.ev[1], s));
-            d_bases = reinterpret_cast<const uint32_t*>(d.call_bases.p);
-            d_flags = reinterpret_cast<const uint8_t*>(d.call_flags.p);
+            d_bases = reinterpret_cast<const uint32_t*>(conv_bases.p) + base0 * msmk::Geo<C>::PT_WORDS;
+            d_flags = reinterpret_cast<const uint8_t*>(conv_flags.p) + base0;
         } else {
             if (d.prof_level >= 2) HIP_TRY(hipEventRecord(d.ev[1], s));
             d_bases = reinterpret_cast<const uint32_t*>(res.buf.p) + (r0 + lo) * msmk::Geo<C>::PT_WORDS;
@@ -425,6 +437,37 @@ int set_bases_impl(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute
     });
 }
 
+// 64-bit fingerprint of a host base vector: every byte of K = min(n, 1024) points spread evenly over the vector (the first and the last
+// included), mixed with the length.  ~100 KB of strided reads from DRAM, software-prefetched, four independent multiply-xor chains:
+// ~25 us measured for 2^20 G1 points with cold caches (4096 samples: 120 us — a page walk per sample — for no better protection).  A vector
+// REWRITTEN under the same pointer and length changes it with probability ~1; a sparse in-place edit of points outside the sample does
+// not — the cache is for immutable base sets (an SRS), which is why it is opt-in (include/arkblst_amd.h).
+inline uint64_t base_fingerprint(const uint8_t* p, size_t n, size_t aff) {
+    const size_t K = std::min<size_t>(n, 1024);
+    uint64_t h[4] = {0x9E3779B97F4A7C15ull ^ (uint64_t)n, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+    auto at = [&](size_t j) { return p + ((K > 1 ? (j * (n - 1)) / (K - 1) : 0) * aff); };
+    for (size_t j = 0; j < K; j++) {
+        if (j + 8 < K) {
+            const uint8_t* q = at(j + 8);
+            __builtin_prefetch(q);
+            __builtin_prefetch(q + 64);
+            if (aff > 128) __builtin_prefetch(q + 128);
+        }
+        const uint8_t* q = at(j);
+        for (size_t b = 0; b < aff; b += 32) {   // aff = 96 or 192: whole 32-byte groups
+            uint64_t w[4];
+            memcpy(w, q + b, 32);
+            for (int t = 0; t < 4; t++) {
+                h[t] = (h[t] ^ w[t]) * 0xD6E8FEB86659FD93ull;
+                h[t] ^= h[t] >> 32;
+            }
+        }
+    }
+    uint64_t r = h[0];
+    for (int t = 1; t < 4; t++) r = (r ^ h[t]) * 0xD6E8FEB86659FD93ull + (r >> 29);
+    return r;
+}
+
 template <class C>
 int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scalars_on_device, size_t n, unsigned fmt, void* out) {
     using J = typename HostCurve<C>::J;
@@ -443,6 +486,32 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
             if (have == 0 && n) return fail(ctx, MI_E_NO_BASES, "no resident base set for this group");
             if (n > have) return fail(ctx, MI_E_INVALID, "n exceeds the resident base set");
         }
+        // base-set cache (opt-in): a host base vector this context has converted before is read from HBM instead of crossing PCIe again
+        constexpr size_t CACHE_MIN_POINTS = 1u << 12;   // below that the upload is cheaper than the bookkeeping is worth
+        std::shared_ptr<BaseCacheEntry> hit, fill;
+        if (bases && n >= CACHE_MIN_POINTS) {
+            unsigned entries;
+            {
+                std::lock_guard<std::mutex> lk(ctx->cache_mu);
+                entries = ctx->cache_entries;
+            }
+            if (entries) {
+                const uint64_t fp = base_fingerprint(bases, n, aff_bytes<C>());
+                std::lock_guard<std::mutex> lk(ctx->cache_mu);
+                for (auto& e : ctx->cache[HostCurve<C>::IDX])
+                    if (e->ptr == bases && e->n == n && e->fp == fp) { hit = e; break; }
+                if (hit) {
+                    hit->stamp = ++ctx->cache_clock;
+                    ctx->cache_hits++;
+                } else {
+                    ctx->cache_misses++;
+                    fill = std::make_shared<BaseCacheEntry>();
+                    fill->ptr = bases; fill->n = n; fill->fp = fp;
+                    fill->shard.resize(g);
+                    for (auto& d : devs) fill->devs.push_back(d.dev);
+                }
+            }
+        }
         // device-resident scalars: the shard of device k is read by device k — in place when the vector lives there, through ONE peer
         // copy of the shard otherwise (can_read)
         int owner = -1;
@@ -460,11 +529,33 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
                     hi = std::min(n, res.lo + res.n);
                 }
                 const int stage = scalars_on_device && hi > lo && !can_read(ctx, k, owner) ? owner : -1;
-                part[k] = device_msm<C>(ctx, d, bases ? bases + lo * aff_bytes<C>() : nullptr, 0, scalars + lo * 32, scalars_on_device, hi - lo, fmt, stage);
+                if (hit) {
+                    part[k] = device_msm<C>(ctx, d, nullptr, 0, scalars + lo * 32, scalars_on_device, hi - lo, fmt, stage, nullptr, &hit->shard[k]);
+                } else {
+                    if (fill) { fill->shard[k].lo = lo; fill->shard[k].n = hi - lo; }
+                    part[k] = device_msm<C>(ctx, d, bases ? bases + lo * aff_bytes<C>() : nullptr, 0, scalars + lo * 32, scalars_on_device, hi - lo, fmt, stage,
+                                            nullptr, fill ? &fill->shard[k] : nullptr);
+                }
             });
         });
         for (size_t k = 0; k < g; k++)
             if (errs[k].code != MI_OK) return fail(ctx, errs[k].code, errs[k].msg);
+        if (fill) {   // the converted set is complete on every device: publish it, evict the least recently used entry beyond the limit
+            std::lock_guard<std::mutex> lk(ctx->cache_mu);
+            auto& v = ctx->cache[HostCurve<C>::IDX];
+            bool dup = false;
+            for (auto& e : v) dup = dup || (e->ptr == fill->ptr && e->n == fill->n && e->fp == fill->fp);   // the other lane was faster
+            if (!dup && ctx->cache_entries) {
+                fill->stamp = ++ctx->cache_clock;
+                v.push_back(fill);
+                while (v.size() > ctx->cache_entries) {
+                    size_t old = 0;
+                    for (size_t q = 1; q < v.size(); q++)
+                        if (v[q]->stamp < v[old]->stamp) old = q;
+                    v.erase(v.begin() + (long)old);
+                }
+            }
+        }
         J r = J::inf();
         for (size_t k = 0; k < g; k++) r = r.add(part[k]);
         memcpy(out, &r, sizeof r);

@@ -53,6 +53,12 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         }
         p.chunk_buckets = p.coop_L << log_ll;
         p.serial_reduce = cc.serial_buckets != 0 && p.nbuckets >= cc.serial_buckets && c - 1 >= 6;
+        uint32_t serial_L_lo = 8, serial_L_hi = 64;
+#if defined(MI_TEST_HOOKS)
+        // experiment switches of the test build (tools/sweep_sizes.py --test-hooks): force the single-lane reduce from a bucket count on, pin its L
+        if (const char* e = getenv("MI_TEST_SERIAL_MIN_BUCKETS")) p.serial_reduce = cc.serial_buckets != 0 && p.nbuckets >= (uint64_t)atoll(e) && c - 1 >= 6;
+        if (const char* e = getenv("MI_TEST_SERIAL_L")) serial_L_lo = serial_L_hi = (uint32_t)std::min(64, std::max(1, atoi(e)));
+#endif
         p.chunks_per_win = (p.nb + p.chunk_buckets - 1) / p.chunk_buckets;
         double serial_steps = 0, serial_rounds = 0;
         if (p.serial_reduce) {
@@ -60,7 +66,7 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
             // (rounds of wave slots) x (2 L running-sum steps + the double-and-add chain that turns S into L S).  2^24 points at c = 20:
             // L = 53 fills 2010 of the 2048 slots with 114 steps, where L = 64 left 1664 waves walking 134 (3.0 -> 2.6 ms).
             double best = 1e300;
-            for (uint32_t L = 8; L <= 64; L++) {
+            for (uint32_t L = serial_L_lo; L <= serial_L_hi; L++) {
                 const uint64_t lanes = (uint64_t)((p.nb + L - 1) / L) * p.bwin;
                 const double rounds = std::ceil(std::ceil((double)lanes / 64.0) / (double)cc.max_chunks);
                 uint32_t bits = 0, ones = 0;

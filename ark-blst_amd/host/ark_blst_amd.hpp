@@ -75,6 +75,11 @@ inline mi_ctx* context() {
         }
         int rc = all ? mi_msm_init(&c, nullptr, 0) : mi_msm_init(&c, ids.data(), (int)ids.size());
         if (rc != MI_OK) throw std::runtime_error(std::string("Cannot initialize MI355X MSM context: ") + mi_msm_strerror(rc));
+        // The trait call is stateless (`msm(&[G1Affine], &[Scalar])`, src/g1.rs:604) while a prover's base vectors are a fixed SRS: keep the
+        // device form of the last two base vectors per group, so that the second call with the same slice runs the resident path
+        // (include/arkblst_amd.h, mi_msm_set_base_cache, with its contract: base vectors are not edited in place between calls).
+        // ARKBLST_AMD_BASE_CACHE=0 in the environment switches it off (read by mi_msm_init; it overrides this call).
+        mi_msm_set_base_cache(c, 2);
         return c;
     }();
     return ctx;

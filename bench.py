@@ -155,14 +155,16 @@ def _pairing_traffic():
 
 def _expected_ms(g: str, log_n):
     """single-GPU ms per call at this shard size from the newest committed size sweep (profiles/*_sweep_<g>_*.jsonl): what one
-    rank of a sharded run should take before any exchange cost"""
+    rank of a sharded run should take before any exchange cost.  The plan's own pick (forced_c = 0), its warm row (`auto_row: last`,
+    tools/sweep_sizes.py) where the file has one."""
     try:
         files = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f"_sweep_{g}_" in f and f.endswith(".jsonl")), reverse=True)
         for f in files:
-            for l in open(os.path.join(ROOT, "profiles", f)):
-                r = json.loads(l)
-                if r.get("log_n") == log_n and r.get("ok", True):
-                    return r["ms"], "profiles/" + f
+            rows = [json.loads(l) for l in open(os.path.join(ROOT, "profiles", f))]
+            rows = [r for r in rows if r.get("log_n") == log_n and r.get("ok", True) and not r.get("forced_c")]
+            if rows:
+                rows.sort(key=lambda r: r.get("auto_row") != "last")
+                return rows[0]["ms"], "profiles/" + f
     except Exception:
         pass
     return None, None
@@ -860,10 +862,19 @@ def main() -> None:
             assert co.to_affine(g, r) == co.to_affine(g, result)
             return b * 1e3
         if not args.precomputed:
-            secondary["call_shapes"] = {
+            shapes = {
                 "resident_bases_host_scalars_ms": best_of(lambda: leg.ctx.msm(g, None, leg.scalars, n, pkg.SCALAR_CANONICAL)),
-                "host_bases_host_scalars_ms": best_of(lambda: leg.ctx.msm(g, leg.bases, leg.scalars, n, pkg.SCALAR_CANONICAL)),
-                "note": "per call incl. H2D of the scalars (and bases) from pageable host memory; the headline keeps both in HBM"}
+                "host_bases_host_scalars_ms": best_of(lambda: leg.ctx.msm(g, leg.bases, leg.scalars, n, pkg.SCALAR_CANONICAL))}
+            # the trait's own shape — host slices on every call, no handle (src/g1.rs:604) — with the base-set cache the shim of
+            # INTEGRATION.md §2 turns on: the first call with a slice converts and keeps it, later ones find it by fingerprint
+            leg.ctx.set_base_cache(2)
+            shapes["host_bases_cached_ms"] = best_of(lambda: leg.ctx.msm(g, leg.bases, leg.scalars, n, pkg.SCALAR_CANONICAL))
+            shapes["base_cache"] = leg.ctx.base_cache_stats()
+            leg.ctx.set_base_cache(0)
+            shapes["note"] = ("per call incl. H2D of the scalars (and bases) from pageable host memory; the headline keeps both in HBM.  A Rust caller "
+                              "of the trait method gets host_bases_cached_ms from the second call with the same base slice on (cache on in the shim), "
+                              "host_bases_host_scalars_ms with ARKBLST_AMD_BASE_CACHE=0")
+            secondary["call_shapes"] = shapes
 
     # ---- CPU baseline (rank 0, N = 1): SURVEY 8(d): one warm-up + median of >= 5 runs (3 above 2^20), CPU model and core count in
     # the result, plus a single-thread figure (on a 2^16-point prefix) for scaling

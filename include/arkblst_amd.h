@@ -129,6 +129,23 @@ int mi_msm_g1(mi_ctx *ctx, const mi_g1_affine *bases, const uint8_t *scalars, si
 int mi_msm_g2(mi_ctx *ctx, const mi_g2_affine *bases, const uint8_t *scalars, size_t n, unsigned scalar_fmt,
               mi_g2 *out);
 
+/* Base-set cache for the stateless call shape.  The trait method is `msm(&[G1Affine], &[Scalar])` (src/g1.rs:604): no handle, so a
+ * prover with a fixed SRS passes the same host base vector on every call, and the call above converts and uploads it every time (as the
+ * reference does, src/gpu.rs:149: 6.2 ms instead of 4.1 ms at 2^20 points).  With `entries` > 0 the context keeps the device form of the
+ * last `entries` base vectors per group it was given (mi_msm_g{1,2} with bases != NULL, n >= 4096; least recently used out first), keyed
+ * by (host pointer, n, a 64-bit fingerprint of every byte of 1024 points spread evenly over the vector — ~25 us per call).  A
+ * hit runs the resident path: the bases do not cross PCIe.  A miss costs what the uncached call costs (the conversion writes into the new
+ * entry).  CONTRACT: the fingerprint catches a vector that was rewritten or reallocated under the same address with probability ~1; it
+ * does NOT see an in-place edit of a few points outside the sample.  A caller that edits single points of a base vector between calls
+ * keeps the cache off or calls mi_msm_invalidate_base_cache.  Default: off (entries = 0).  The environment variable
+ * ARKBLST_AMD_BASE_CACHE=<entries> (0 = off), read by mi_msm_init, overrides this call: an operator can switch the cache of a shim that
+ * enables it (INTEGRATION.md §2 does) off without rebuilding anything.  Memory: 128 B (G1) / 256 B (G2) of HBM per cached point.
+ * No counterpart in the reference. */
+#define MI_BASE_CACHE_MAX 4
+int mi_msm_set_base_cache(mi_ctx *ctx, unsigned entries);
+int mi_msm_invalidate_base_cache(mi_ctx *ctx);
+int mi_msm_base_cache_stats(const mi_ctx *ctx, uint64_t *hits, uint64_t *misses, unsigned *entries_in_use);
+
 /* Same computation with the scalars ALREADY in device memory (hipMalloc'd or a torch CUDA tensor's data_ptr) and the bases
  * resident: nothing crosses PCIe except one Jacobian point per window.  The library reads d_scalars on its OWN stream: the
  * caller must have synchronised the stream that produced them (hipStreamSynchronize / torch.cuda.synchronize) before the

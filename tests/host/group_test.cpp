@@ -47,6 +47,35 @@ static int run(const std::string& dir, const char* tag) {
     G b = G::msm({affines.begin() + h, affines.end()}, {scalars.begin() + h, scalars.end()}).unwrap();
     auto n3 = G::normalize_batch({G::sum({a, b})});
     CHECK(std::memcmp(&n3[0], &expect[0], sizeof(Aff)) == 0);
+    // The stateless trait call with a base vector the context has seen (the host mirror enables the base-set cache; the first call is a
+    // miss that fills an entry, the second a hit that reads the bases from HBM): 20 copies of the bases make the vector long enough
+    // (>= 4096 points).  Expected: 20 x the plain result.  Then an in-place rewrite of a sampled point must MISS and change the result.
+    {
+        const size_t reps = 4096 / affines.size() + 1;
+        std::vector<Aff> big;
+        std::vector<Scalar> bigs;
+        for (size_t r = 0; r < reps; r++) { big.insert(big.end(), affines.begin(), affines.end()); bigs.insert(bigs.end(), scalars.begin(), scalars.end()); }
+        uint64_t h0 = 0, m0 = 0, h1 = 0, m1 = 0;
+        mi_msm_base_cache_stats(context(), &h0, &m0, nullptr);
+        G first = G::msm(big, bigs).unwrap();
+        G second = G::msm(big, bigs).unwrap();
+        mi_msm_base_cache_stats(context(), &h1, &m1, nullptr);
+        const bool cache_on = std::getenv("ARKBLST_AMD_BASE_CACHE") == nullptr || std::atoi(std::getenv("ARKBLST_AMD_BASE_CACHE")) > 0;
+        if (cache_on) CHECK(m1 == m0 + 1 && h1 == h0 + 1);
+        else CHECK(m1 == m0 && h1 == h0);
+        auto want = G::normalize_batch({G::sum(std::vector<G>(reps, res))});
+        auto g1 = G::normalize_batch({first}), g2 = G::normalize_batch({second});
+        CHECK(std::memcmp(&g1[0], &want[0], sizeof(Aff)) == 0 && std::memcmp(&g2[0], &want[0], sizeof(Aff)) == 0);
+        big[0] = big[1];                                   // rewrite the first point in place (always in the fingerprint's sample)
+        G third = G::msm(big, bigs).unwrap();              // must not be served from the stale entry
+        // third = want + s_0 (b_1 - b_0); there is no field arithmetic on this side of the ABI, so compare against a run that cannot
+        // come from the cache (invalidated first) and check that it differs from the old value
+        mi_msm_invalidate_base_cache(context());
+        G fresh = G::msm(big, bigs).unwrap();
+        auto g3 = G::normalize_batch({third}), g4 = G::normalize_batch({fresh});
+        CHECK(std::memcmp(&g3[0], &g4[0], sizeof(Aff)) == 0);
+        CHECK(std::memcmp(&g3[0], &want[0], sizeof(Aff)) != 0);
+    }
     std::printf("%s group_test OK (n = %zu)\n", tag, affines.size());
     return 0;
 }

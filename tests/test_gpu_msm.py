@@ -661,6 +661,74 @@ def test_validated_bases_fold_signs_with_identical_results(pkg, co, group):
         assert c.profile()["num_windows"] == 18
 
 
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_base_set_cache_for_the_stateless_call(pkg, co, group):
+    """mi_msm_g{1,2} with host bases and the base-set cache on.  Second call with the same slice = a hit, same point as the
+    uncached context and the C oracle; a slice REWRITTEN in place (a sampled point: the first) misses and gives the new value; three
+    slices through a two-entry cache evict the least recently used; invalidate empties it; below 4096 points nothing is cached;
+    ARKBLST_AMD_BASE_CACHE=0 overrides the call."""
+    import numpy as np
+
+    aff = 96 if group == "g1" else 192
+    n = 6000
+    sets = [np.frombuffer(co.gen_bases(group, 555 + k, n, 4), dtype=np.uint8).copy() for k in range(3)]
+    sc = co.gen_scalars(556, n)
+    want = [co.to_affine(group, co.msm(group, b.tobytes(), sc, n, 0, 4)) for b in sets]
+    with pkg.Context([0]) as c:
+        c.set_base_cache(2)
+        for rep in range(3):
+            assert _canon(co, group, c.msm(group, sets[0], sc, n, 0)) == want[0]
+        st = c.base_cache_stats()
+        assert (st["hits"], st["misses"], st["entries"]) == (2, 1, 1), st
+        # rewrite point 0 in place: same pointer, same length, different content
+        sets[0][:aff] = sets[1][:aff]
+        changed = co.to_affine(group, co.msm(group, sets[0].tobytes(), sc, n, 0, 4))
+        assert changed != want[0]
+        assert _canon(co, group, c.msm(group, sets[0], sc, n, 0)) == changed
+        assert c.base_cache_stats()["misses"] == 2
+        # LRU: sets[1], sets[2] push the two entries of sets[0] out; sets[1] stays warm
+        for k in (1, 2, 1, 2):
+            assert _canon(co, group, c.msm(group, sets[k], sc, n, 0)) == want[k]
+        st = c.base_cache_stats()
+        assert st["entries"] == 2 and st["misses"] == 4 and st["hits"] == 4, st
+        assert _canon(co, group, c.msm(group, sets[0], sc, n, 0)) == changed and c.base_cache_stats()["misses"] == 5
+        # Montgomery scalars and a shorter prefix of a cached vector (a different key: n is part of it)
+        assert _canon(co, group, c.msm(group, sets[0], co.fr_to_mont(sc), n, 1)) == changed
+        assert _canon(co, group, c.msm(group, sets[0], sc, 5000, 0)) == co.to_affine(group, co.msm(group, sets[0].tobytes(), sc, 5000, 0, 4))
+        c.invalidate_base_cache()
+        assert c.base_cache_stats()["entries"] == 0
+        before = c.base_cache_stats()
+        assert _canon(co, group, c.msm(group, sets[0][:aff * 1000], sc, 1000, 0)) == co.to_affine(group, co.msm(group, sets[0].tobytes(), sc, 1000, 0, 4))
+        assert c.base_cache_stats() == before          # under 4096 points: not cached, not counted
+        c.set_base_cache(0)
+        assert _canon(co, group, c.msm(group, sets[1], sc, n, 0)) == want[1] and c.base_cache_stats() == before
+    os.environ["ARKBLST_AMD_BASE_CACHE"] = "0"
+    try:
+        with pkg.Context([0]) as c:
+            c.set_base_cache(2)                         # ignored: the environment decides
+            for rep in range(2):
+                assert _canon(co, group, c.msm(group, sets[2], sc, n, 0)) == want[2]
+            assert c.base_cache_stats() == {"hits": 0, "misses": 0, "entries": 0}
+    finally:
+        del os.environ["ARKBLST_AMD_BASE_CACHE"]
+    # two host threads on one context, the same slice: both lanes may miss at once, one entry survives, both results right
+    import threading
+
+    with pkg.Context([0]) as c:
+        c.set_base_cache(2)
+        res = [None, None]
+
+        def work(t):
+            for _ in range(3):
+                res[t] = c.msm(group, sets[1], sc, n, 0)
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+        for x in th: x.start()
+        for x in th: x.join()
+        assert _canon(co, group, res[0]) == want[1] and _canon(co, group, res[1]) == want[1]
+        assert c.base_cache_stats()["entries"] == 1
+
+
 def test_call_abi_reproducer():
     """The compiler issue behind round 3's "codegen-dependent miscompares" (csrc/Makefile): tools/call_abi/repro_tower.hip
     — the test-only single-lane Miller loop's shape: a 512-register kernel that keeps the point and the line state across ~40 calls
