@@ -118,9 +118,25 @@ def _mont_one() -> bytes:
     return b"".join(l.to_bytes(8, "little") for l in limbs)
 
 
+def source_hash() -> str:
+    """sha256 over the sources every kernel is built from (ark-blst_amd/csrc/* and include/*.h, names and contents, sorted).  A profile
+    summary under profiles/ carries the hash of the tree it was measured on (tools/summarize_profile.py); bench.py compares it with the
+    tree it runs from and marks a replayed traffic figure `traffic_stale` when the two differ.  A hash of the
+    sources, not of the .so: the library is rebuilt on other boxes, and byte-identical output is not promised."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in (os.path.join(ROOT, "ark-blst_amd", "csrc"), os.path.join(ROOT, "include")):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".cuh", ".hpp", ".h")) or f == "Makefile":
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
 def _traffic(g: str, log_n, precomputed: bool):
     """HBM bytes per launch of the accumulate kernel: measured with rocprofv3 PMC passes (tools/profile_bench.sh) on this
-    exact workload and committed under profiles/ (bench.py cannot collect counters itself); None when no summary matches."""
+    exact workload and committed under profiles/ (bench.py cannot collect counters itself); (None, None, None) when no summary matches.
+    Third value: True when the summary was measured on other sources than the ones this run was built from."""
     try:
         key = "msmk::k_accumulate<msmk::G1C>" if g == "g1" else "msmk::k_accumulate_g2_coop<msmk::G2C>"
         files = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json")), reverse=True)
@@ -132,10 +148,10 @@ def _traffic(g: str, log_n, precomputed: bool):
             if (wl.get("group"), wl.get("log_n"), bool(wl.get("precomputed"))) != (g, log_n, precomputed):
                 continue
             if key in pj.get("kernels", {}) and "hbm_bytes_per_launch_corrected" in pj["kernels"][key]:
-                return pj["kernels"][key]["hbm_bytes_per_launch_corrected"], "profiles/" + f
+                return pj["kernels"][key]["hbm_bytes_per_launch_corrected"], "profiles/" + f, pj.get("source_sha256") != source_hash()
     except Exception:
         pass
-    return None, None
+    return None, None, None
 
 
 def _pairing_traffic():
@@ -143,14 +159,15 @@ def _pairing_traffic():
     try:
         files = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if "pairing" in f and f.endswith("_pmc_summary.json")), reverse=True)
         for f in files:
-            ks = json.load(open(os.path.join(ROOT, "profiles", f))).get("kernels", {})
+            pj = json.load(open(os.path.join(ROOT, "profiles", f)))
+            ks = pj.get("kernels", {})
             t = [v["hbm_bytes_largest_launch_corrected"] for k, v in ks.items()
                  if ("k_miller_lines2" in k or "k_miller_accumulate" in k) and "hbm_bytes_largest_launch_corrected" in v]
             if len(t) == 2:
-                return sum(t), "profiles/" + f
+                return sum(t), "profiles/" + f, pj.get("source_sha256") != source_hash()
     except Exception:
         pass
-    return None, None
+    return None, None, None
 
 
 def _expected_ms(g: str, log_n):
@@ -252,7 +269,7 @@ def _compact(d: dict, keys) -> dict:
 def _rooflines(g: str, n: int, log_n, acc_ms: float, nwin: int, precomputed: bool) -> dict:
     alg_bytes = ALG_BYTES_PER_POINT[g] * n
     gbs = alg_bytes / (acc_ms * 1e-3) / 1e9
-    traffic, src = _traffic(g, log_n, precomputed) if log_n is not None else (None, None)
+    traffic, src, stale = _traffic(g, log_n, precomputed) if log_n is not None else (None, None, None)
     mads = nwin * FP_MULS_PER_ADD[g] * MADS_PER_FP_MUL       # window-aware: one mixed addition per point and window
     kernel = "k_accumulate<G1C>" if g == "g1" else "k_accumulate_g2_coop<G2C>"
     key = "k_accumulate<msmk::G1C>" if g == "g1" else "k_accumulate_g2_coop"
@@ -263,7 +280,7 @@ def _rooflines(g: str, n: int, log_n, acc_ms: float, nwin: int, precomputed: boo
     wave_adds = nwin * n / 64.0
     cyc = lambda hz: acc_ms * 1e-3 * hz * SIMDS / wave_adds
     cost = ADD_INSTRUCTION_COST.get(g)
-    extra = {"traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": alg_bytes,
+    extra = {"traffic": traffic, "traffic_source": src, "traffic_stale": stale, "algorithmic_bytes_per_launch": alg_bytes,
              "model_mads_per_point": mads,
              "cycles_per_wave_addition": cyc(clock * 1e9) if clock else None,
              "cycles_per_wave_addition_at_2p4ghz": cyc(CLOCK_HZ),
@@ -402,13 +419,13 @@ def _pairing_leg(pkg, co, ncpu, device) -> dict:
     acc_ms, lines_ms, miller_ms = pp["accumulate_ms"], pp["lines_ms"], pp["miller_ms"]
     mads = PAIRING_FP_MULS_PER_PAIR * MADS_PER_FP_MUL
     gbs = 288.0 * n / (miller_ms * 1e-3) / 1e9
-    traffic, tsrc = _pairing_traffic()
+    traffic, tsrc, tstale = _pairing_traffic()
     clock, clock_src = _measured_clock("k_miller_accumulate")
     pc = ADD_INSTRUCTION_COST.get("pairing") or {}
     valu = _valu_roofline("k_miller_lines2 + k_miller_accumulate",
                           f"{PAIRING_FP_MULS_PER_PAIR} Fp-mul per pair (63 doubling + 5 addition steps: line + sparse Fp12 product; "
                           f"Fp12 squarings shared by all pairs) x {MADS_PER_FP_MUL} MAD", mads * n, miller_ms, clock, clock_src,
-                          {"traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": 288 * n, "model_mads_per_pair": mads,
+                          {"traffic": traffic, "traffic_source": tsrc, "traffic_stale": tstale, "algorithmic_bytes_per_launch": 288 * n, "model_mads_per_pair": mads,
                            "per_kernel": {"k_miller_lines2": {"ms": lines_ms, "model_Tmad_s": (63 * 31 + 5 * 41) * MADS_PER_FP_MUL * n / (lines_ms * 1e-3) / 1e12},
                                           "k_miller_accumulate": {"ms": acc_ms, "model_Tmad_s": 68 * 39 * MADS_PER_FP_MUL * n / (acc_ms * 1e-3) / 1e12}},
                            "instruction_cost": pc or None})

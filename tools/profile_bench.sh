@@ -10,6 +10,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary $*"
 echo "$ARGS" > $OUT/command.txt
+python3 -c "import bench; print(bench.source_hash())" > $OUT/source.sha256   # the tree the counters were measured on
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/bench_line_under_rocprof.json 2> $OUT/stats.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.log 2>&1
