@@ -498,10 +498,8 @@ def _normalize_leg(pkg, co, ncpu, device, g="g1", log_n=20) -> dict:
 
 def _deserialize_g2_leg(pkg, co, ncpu, device, log_n=18) -> dict:
     """Row (f)-4 for G2 (src/g2.rs:366-411): 2^18 compressed 96-byte encodings with Valid::check on through mi_g2_deserialize_batch (two
-    kernels: decoder, then the subgroup test).  Parity: every decoded point equals the point it was serialised from, and a 48-point sample
-    is decoded by the big-int oracle (oracle/bls12_381.py g2_deserialize — the C oracle has no G2 decoder, so this leg carries no
-    timed CPU baseline)."""
-    from oracle import bls12_381 as o
+    kernels: decoder, then the subgroup test).  Parity: every decoded point equals the point it was serialised from, and a sample is
+    decoded by the C oracle, which is also the timed CPU baseline."""
     n = 1 << log_n
     bases = co.gen_bases("g2", SEED_B + 203, n, ncpu)
     with pkg.Context([device]) as ctx:
@@ -513,12 +511,11 @@ def _deserialize_g2_leg(pkg, co, ncpu, device, log_n=18) -> dict:
         kms = ctx.profile()["accumulate_ms"]
         ctx.deserialize_batch("g2", enc, True, False)
         kms_novalidate = ctx.profile()["accumulate_ms"]
-    m = 48
-    sample_ok = True
-    for i in range(m):
-        pt, status = o.g2_deserialize(enc[96 * i:96 * (i + 1)], True, True)
-        sample_ok = sample_ok and status == 0 and o.affine_to_bytes(o.F2, pt) == dec[192 * i:192 * (i + 1)]
-    ok = dec == bases and st == bytes(n) and sample_ok
+    m = 1 << 13   # CPU sample: ~1 s on 16 threads
+    t1 = time.perf_counter()
+    cdec, cst = co.g2_deserialize_batch(enc[:96 * m], True, True, 1, ncpu)
+    cpu_s = time.perf_counter() - t1
+    ok = dec == bases and st == bytes(n) and cdec == bases[:192 * m] and cst == bytes(m)
     fp_muls = DESER_G2_FP_MULS_PER_POINT
     clock, clock_src = _measured_clock("k_accumulate<msmk::G1C>")
     return {"metric": "G2 points/s, deserialize_batch (compressed, validate on)", "value": n / (kms * 1e-3), "unit": "points/s", "n": n,
@@ -526,7 +523,9 @@ def _deserialize_g2_leg(pkg, co, ncpu, device, log_n=18) -> dict:
             "workload": f"2^{log_n} compressed G2 encodings (96 B), decompression (Fp2 square root) + on-curve + subgroup check, host buffers in and out",
             "roofline": _valu_roofline("k_deserialize_g2 + k_validate<G2C>", f"~{fp_muls} Fp-mul x {MADS_PER_FP_MUL} MAD per point",
                                        fp_muls * MADS_PER_FP_MUL * n, kms, clock, clock_src, {"traffic": None, "algorithmic_bytes_per_launch": (96 + 192) * n}),
-            "cpu_baseline": None}
+            "cpu_baseline": {"value": m / cpu_s, "unit": "points/s", "cores": ncpu, "kind": "port", "cpu_model": _cpu_model(), "seconds": cpu_s,
+                             "sample": f"{m} of the encodings: Fp2 square root by two exponentiations + psi-endomorphism subgroup test in C "
+                                       "(oracle/msm_oracle.c orc_g2_deserialize_batch, mode 1)"}}
 
 
 def _deserialize_leg(pkg, co, ncpu, device, log_n=20) -> dict:

@@ -43,6 +43,8 @@ def lib():
             getattr(L, f"orc_{g}_normalize_batch").argtypes = [u8p, sz, i32, u8p]
         L.orc_g1_deserialize_batch.argtypes = [u8p, sz, i32, i32, i32, i32, u8p, u8p]
         L.orc_g1_deserialize_batch.restype = i32
+        L.orc_g2_deserialize_batch.argtypes = [u8p, sz, i32, i32, i32, i32, u8p, u8p]
+        L.orc_g2_deserialize_batch.restype = i32
         L.orc_gen_scalars.argtypes = [u64, sz, i32, u8p]
         L.orc_gen_dlogs.argtypes = [u64, sz, u8p]
         L.orc_dot_mod_r.argtypes = [u8p, u64, sz, u8p]
@@ -151,6 +153,18 @@ def g1_deserialize_batch(data: bytes, compressed: bool, validate: bool, subgroup
     out, st = C.create_string_buffer(G1_AFF * n), C.create_string_buffer(n)
     rc = lib().orc_g1_deserialize_batch(data, n, int(compressed), int(validate), subgroup_mode, nthreads, out, st)
     assert rc == 0
+    return out.raw, st.raw
+
+
+def g2_deserialize_batch(data: bytes, compressed: bool, validate: bool, subgroup_mode: int = 0, nthreads: int = 1):
+    """(affine bytes, status bytes) — /root/reference/src/g2.rs:366-411 restated in oracle/msm_oracle.c (orc_g2_deserialize_batch)"""
+    size = 96 if compressed else 192
+    n = len(data) // size
+    out = C.create_string_buffer(192 * n)
+    st = C.create_string_buffer(n)
+    rc = lib().orc_g2_deserialize_batch(data, n, int(compressed), int(validate), subgroup_mode, nthreads, out, st)
+    if rc != 0:
+        raise RuntimeError("orc_g2_deserialize_batch: the psi constants failed their self-check")
     return out.raw, st.raw
 
 

@@ -540,3 +540,130 @@ int orc_g1_deserialize_batch(const uint8_t *bytes, size_t n, int compressed, int
     if (n) parallel_for(chunks, nthreads, g1_deser_slice, &c);
     return 0;
 }
+
+/* ---- G2 (/root/reference/src/g2.rs:338-411): 96-byte compressed / 192-byte uncompressed, Fp2 coordinates c1 FIRST, y^2 = x^3 + 4 (1 + u).
+ * Square root in Fp2 for p = 3 mod 4 (Adj, Rodriguez-Henriquez, eprint 2012/685, Alg. 9): a1 = a^((p-3)/4), alpha = a1^2 a, x0 = a1 a;
+ * root = u x0 if alpha = -1, else (1 + alpha)^((p-1)/2) x0; "larger" root: c1 compared first, then c0 (the ZCash rule).
+ * subgroup_mode 0 = the definition ([r] Q == infinity: the CHECKER), 1 = psi(Q) == [z] Q (M. Scott, eprint 2021/1130; psi = the untwist-
+ * Frobenius-twist map (x, y) -> (conj(x) cx, conj(y) cy), cx = (1 + u)^-((p-1)/3), cy = (1 + u)^-((p-1)/2), computed at first use). */
+static void fp2_conj(fp2 *r, const fp2 *a) { r->c0 = a->c0; fp_neg(&r->c1, &a->c1); }
+static void fp2_pow6(fp2 *r, const fp2 *a, const uint64_t e[6]) {
+    fp2 acc; acc.c0 = FP_ONE; memset(&acc.c1, 0, sizeof acc.c1);
+    int top = 383;
+    while (top > 0 && !((e[top >> 6] >> (top & 63)) & 1)) top--;
+    for (int i = top; i >= 0; i--) {
+        fp2_sqr(&acc, &acc);
+        if ((e[i >> 6] >> (i & 63)) & 1) fp2_mul(&acc, &acc, a);
+    }
+    *r = acc;
+}
+static void p_minus_k_over_d(uint64_t e[6], unsigned k, unsigned d) { /* (p - k) / d, exact for the (k, d) used here */
+    fp t = FP_P; t.l[0] -= k;
+    uint64_t rem = 0;
+    for (int i = 5; i >= 0; i--) { unsigned __int128 v = ((unsigned __int128)rem << 64) | t.l[i]; e[i] = (uint64_t)(v / d); rem = (uint64_t)(v % d); }
+}
+static int fp2_sqrt(fp2 *r, const fp2 *a) { /* 1 = a is a square and *r a root */
+    uint64_t e34[6], e12[6];
+    p_minus_k_over_d(e34, 3, 4);
+    p_minus_k_over_d(e12, 1, 2);
+    fp2 a1, x0, alpha, t, one; one.c0 = FP_ONE; memset(&one.c1, 0, sizeof one.c1);
+    fp2_pow6(&a1, a, e34);
+    fp2_mul(&x0, &a1, a);
+    fp2_mul(&alpha, &a1, &x0);
+    fp2_add(&t, &alpha, &one);
+    if (fp2_is_zero(&t)) { fp_neg(&r->c0, &x0.c1); r->c1 = x0.c0; }          /* u x0 */
+    else { fp2 b; fp2_pow6(&b, &t, e12); fp2_mul(r, &b, &x0); }
+    fp2 chk; fp2_sqr(&chk, r);
+    return fp2_eq(&chk, a);
+}
+static int fp2_lex_largest(const fp2 *y) {
+    if (!fp_is_zero(&y->c1)) return fp_canon_gt_half(&y->c1);
+    return fp_canon_gt_half(&y->c0);
+}
+static fp2 G2_PSI_X, G2_PSI_Y; static int G2_PSI_READY = 0;
+static void g2_mul_u64(g2_jac *r, const g2_jac *p, uint64_t k) {
+    g2_jac acc; g2_jac_set_inf(&acc);
+    for (int i = 63; i >= 0; i--) {
+        g2_jac_double(&acc, &acc);
+        if ((k >> i) & 1) g2_jac_add(&acc, &acc, p);
+    }
+    *r = acc;
+}
+static int g2_psi_holds(const g2_affine *p) { /* psi(P) == [z] P = -[|z|] P */
+    g2_jac j, q; g2_jac_from_affine(&j, p);
+    g2_mul_u64(&q, &j, 0xd201000000010000ULL);
+    if (g2_jac_is_inf(&q)) return 0;
+    g2_affine qa; g2_jac_to_affine(&qa, &q);
+    fp2 cx, cy, px, py, ny;
+    fp2_conj(&cx, &p->x); fp2_conj(&cy, &p->y);
+    fp2_mul(&px, &cx, &G2_PSI_X); fp2_mul(&py, &cy, &G2_PSI_Y);
+    fp2_neg(&ny, &qa.y);
+    return fp2_eq(&qa.x, &px) && fp2_eq(&ny, &py);
+}
+static void g2_psi_init(void) {
+    pthread_mutex_lock(&BETA_MU);
+    if (!G2_PSI_READY) {
+        uint64_t e13[6], e12[6];
+        p_minus_k_over_d(e13, 1, 3);
+        p_minus_k_over_d(e12, 1, 2);
+        fp2 xi, t; xi.c0 = FP_ONE; xi.c1 = FP_ONE;                              /* 1 + u */
+        fp2_pow6(&t, &xi, e13); fp2_inv(&G2_PSI_X, &t);
+        fp2_pow6(&t, &xi, e12); fp2_inv(&G2_PSI_Y, &t);
+        g2_affine g; g2_generator(&g);
+        G2_PSI_READY = g2_psi_holds(&g) ? 1 : -1;                                /* the generator is in the subgroup: the constants are right */
+    }
+    pthread_mutex_unlock(&BETA_MU);
+}
+static uint8_t g2_deserialize_one(const uint8_t *b, int compressed, int validate, int mode, g2_affine *out) {
+    memset(out, 0, sizeof *out);
+    unsigned c_flag = b[0] >> 7, i_flag = (b[0] >> 6) & 1, s_flag = (b[0] >> 5) & 1;
+    if (c_flag != (unsigned)(compressed ? 1 : 0)) return 1;
+    uint64_t x1[6], x0[6], y1[6] = {0, 0, 0, 0, 0, 0}, y0[6] = {0, 0, 0, 0, 0, 0};
+    int ok = be48_to_fp_canon(x1, b, 0x1f) & be48_to_fp_canon(x0, b + 48, 0xff);
+    if (!compressed) ok &= be48_to_fp_canon(y1, b + 96, 0xff) & be48_to_fp_canon(y0, b + 144, 0xff);
+    if (i_flag) {
+        uint64_t any = s_flag;
+        for (int k = 0; k < 6; k++) any |= x1[k] | x0[k] | y1[k] | y0[k];
+        return any ? 1 : 0;
+    }
+    if (!ok || (!compressed && s_flag)) return 1;
+    fp t; fp2 x, y, rhs, b4, y2;
+    memcpy(t.l, x0, 48); fp_to_mont(&x.c0, &t);
+    memcpy(t.l, x1, 48); fp_to_mont(&x.c1, &t);
+    fp four; fp_add(&four, &FP_ONE, &FP_ONE); fp_add(&four, &four, &four);
+    b4.c0 = four; b4.c1 = four;                                                   /* 4 (1 + u) */
+    fp2_sqr(&rhs, &x); fp2_mul(&rhs, &rhs, &x); fp2_add(&rhs, &rhs, &b4);
+    if (compressed) {
+        if (!fp2_sqrt(&y, &rhs)) return 1;
+        if (fp2_lex_largest(&y) != (int)s_flag) fp2_neg(&y, &y);
+    } else {
+        memcpy(t.l, y0, 48); fp_to_mont(&y.c0, &t);
+        memcpy(t.l, y1, 48); fp_to_mont(&y.c1, &t);
+        fp2_sqr(&y2, &y);
+        if (validate && !fp2_eq(&y2, &rhs)) return 2;
+    }
+    g2_affine p; p.x = x; p.y = y;
+    if (validate) {
+        if (mode == 0) {
+            g2_jac r; g2_mul_naive(&r, &p, FR_R.l);
+            if (!g2_jac_is_inf(&r)) return 3;
+        } else if (!g2_psi_holds(&p)) return 3;
+    }
+    *out = p;
+    return 0;
+}
+static void g2_deser_slice(void *vctx, size_t t) {
+    deser_ctx *c = (deser_ctx *)vctx;
+    size_t lo = t * c->per, hi = lo + c->per < c->n ? lo + c->per : c->n, size = c->compressed ? 96 : 192;
+    for (size_t i = lo; i < hi; i++)
+        c->status[i] = g2_deserialize_one(c->bytes + i * size, c->compressed, c->validate, c->mode, (g2_affine *)c->out + i);
+}
+int orc_g2_deserialize_batch(const uint8_t *bytes, size_t n, int compressed, int validate, int subgroup_mode, int nthreads,
+                             uint8_t *out_aff, uint8_t *status) {
+    if (subgroup_mode == 1) { g2_psi_init(); if (G2_PSI_READY != 1) return -1; }
+    if (nthreads < 1) nthreads = 1;
+    size_t chunks = (size_t)nthreads * 8;
+    deser_ctx c = {bytes, n, (n + chunks - 1) / chunks, compressed, validate, subgroup_mode, out_aff, status};
+    if (n) parallel_for(chunks, nthreads, g2_deser_slice, &c);
+    return 0;
+}

@@ -189,3 +189,30 @@ def test_c_oracle_g1_deserialize(co, o, golden):
         blob = b"".join((o.g1_compress(p) if compressed else o.g1_uncompressed(p)) for p in pts)
         out, st = co.g1_deserialize_batch(blob, compressed, True, 1, 3)
         assert st == bytes(len(pts)) and out == b"".join(o.affine_to_bytes(o.F1, p) for p in pts)
+
+
+def test_c_oracle_g2_deserialize(co, o, golden):
+    """orc_g2_deserialize_batch (bench.py's G2 deserialize cpu_baseline; src/g2.rs:366-411) against the frozen G2 encoding fixtures and
+    the Python oracle: the definition [r] Q and the psi(Q) == [z] Q form of the subgroup test agree on points inside AND outside the
+    subgroup; malformed encodings (no square root in Fp2, unreduced coordinate, flipped flags) and off-curve points get the
+    reference's statuses."""
+    from cofactor_util import off_subgroup_points
+
+    for case in golden["g2_encoding"]:
+        for mode in (0, 1):
+            out, st = co.g2_deserialize_batch(bytes.fromhex(case["bytes"]), case["compressed"], case["validate"], mode, 1)
+            assert st[0] == case["status"], (case["name"], mode)
+            assert out.hex() == (case["affine"] if st[0] == 0 and case["affine"] else bytes(192).hex()), case["name"]
+    off = off_subgroup_points(o, "g2", 2)
+    enc = b"".join(o.g2_compress(p) for p in off) + o.g2_compress(o.G2_GEN)
+    for mode in (0, 1):
+        out, st = co.g2_deserialize_batch(enc, True, True, mode, 2)
+        assert st == bytes([3, 3, 0]) and out[:384] == bytes(384) and out[384:] == o.affine_to_bytes(o.F2, o.G2_GEN)
+    out, st = co.g2_deserialize_batch(enc, True, False, 0, 1)
+    assert st == bytes(3) and out == b"".join(o.affine_to_bytes(o.F2, p) for p in off + [o.G2_GEN])
+    bases = co.gen_bases("g2", 4711, 12, 2)
+    pts = [o.affine_from_bytes(o.F2, bases[192 * i:192 * (i + 1)]) for i in range(12)]
+    for compressed in (True, False):
+        blob = b"".join((o.g2_compress(p) if compressed else o.g2_uncompressed(p)) for p in pts)
+        out, st = co.g2_deserialize_batch(blob, compressed, True, 1, 3)
+        assert st == bytes(len(pts)) and out == bases
