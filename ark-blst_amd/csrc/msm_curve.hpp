@@ -2,6 +2,7 @@
 // in msm_g1.hip and msm_g2.hip.  Replaces crate::gpu::msm + SingleMultiexpKernel::multiexp of the reference
 // (/root/reference/src/gpu.rs:126-241) behind <G{1,2}Projective as VariableBaseMSM>::msm (src/g1.rs:602-632, src/g2.rs:582-612).
 #pragma once
+#include <future>
 #include <exception>
 #include "internal.hpp"
 #include "curve_kernels.cuh"
@@ -486,30 +487,18 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
             if (have == 0 && n) return fail(ctx, MI_E_NO_BASES, "no resident base set for this group");
             if (n > have) return fail(ctx, MI_E_INVALID, "n exceeds the resident base set");
         }
-        // base-set cache (opt-in): a host base vector this context has converted before is read from HBM instead of crossing PCIe again
+        // base-set cache (opt-in): a host base vector this context has converted before is read from HBM instead of crossing PCIe again.
+        // The fingerprint (~25-100 us of strided DRAM reads) runs on a helper thread UNDER the GPU work: an entry with the same (pointer,
+        // n) is used speculatively and confirmed before the result leaves; a miss fills its entry first and learns its key at the end.
         constexpr size_t CACHE_MIN_POINTS = 1u << 12;   // below that the upload is cheaper than the bookkeeping is worth
         std::shared_ptr<BaseCacheEntry> hit, fill;
+        std::future<uint64_t> fp_job;
         if (bases && n >= CACHE_MIN_POINTS) {
-            unsigned entries;
-            {
-                std::lock_guard<std::mutex> lk(ctx->cache_mu);
-                entries = ctx->cache_entries;
-            }
-            if (entries) {
-                const uint64_t fp = base_fingerprint(bases, n, aff_bytes<C>());
-                std::lock_guard<std::mutex> lk(ctx->cache_mu);
+            std::lock_guard<std::mutex> lk(ctx->cache_mu);
+            if (ctx->cache_entries) {
                 for (auto& e : ctx->cache[HostCurve<C>::IDX])
-                    if (e->ptr == bases && e->n == n && e->fp == fp) { hit = e; break; }
-                if (hit) {
-                    hit->stamp = ++ctx->cache_clock;
-                    ctx->cache_hits++;
-                } else {
-                    ctx->cache_misses++;
-                    fill = std::make_shared<BaseCacheEntry>();
-                    fill->ptr = bases; fill->n = n; fill->fp = fp;
-                    fill->shard.resize(g);
-                    for (auto& d : devs) fill->devs.push_back(d.dev);
-                }
+                    if (e->ptr == bases && e->n == n && (!hit || e->stamp > hit->stamp)) hit = e;   // the most recent candidate
+                fp_job = std::async(std::launch::async, base_fingerprint, bases, n, aff_bytes<C>());
             }
         }
         // device-resident scalars: the shard of device k is read by device k — in place when the vector lives there, through ONE peer
@@ -517,42 +506,81 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
         int owner = -1;
         if (scalars_on_device && n) owner = device_of_ptr(scalars, "d_scalars");
         auto t0 = std::chrono::steady_clock::now();
-        for_each_device(lane, g, [&](size_t k) {
-            guarded_part(errs[k], [&] {
-                DevState& d = devs[k];
-                size_t lo, hi;
-                if (bases) {
-                    shard_range(n, g, k, lo, hi);
-                } else {
-                    auto& res = d.res[HostCurve<C>::IDX];
-                    lo = std::min(n, res.lo);
-                    hi = std::min(n, res.lo + res.n);
-                }
-                const int stage = scalars_on_device && hi > lo && !can_read(ctx, k, owner) ? owner : -1;
-                if (hit) {
-                    part[k] = device_msm<C>(ctx, d, nullptr, 0, scalars + lo * 32, scalars_on_device, hi - lo, fmt, stage, nullptr, &hit->shard[k]);
-                } else {
-                    if (fill) { fill->shard[k].lo = lo; fill->shard[k].n = hi - lo; }
-                    part[k] = device_msm<C>(ctx, d, bases ? bases + lo * aff_bytes<C>() : nullptr, 0, scalars + lo * 32, scalars_on_device, hi - lo, fmt, stage,
-                                            nullptr, fill ? &fill->shard[k] : nullptr);
-                }
+        auto run = [&]() -> int {   // one pass over the devices with the current (hit, fill)
+            for (auto& e : errs) e = PartErr{};
+            for_each_device(lane, g, [&](size_t k) {
+                guarded_part(errs[k], [&] {
+                    DevState& d = devs[k];
+                    size_t lo, hi;
+                    if (bases) {
+                        shard_range(n, g, k, lo, hi);
+                    } else {
+                        auto& res = d.res[HostCurve<C>::IDX];
+                        lo = std::min(n, res.lo);
+                        hi = std::min(n, res.lo + res.n);
+                    }
+                    const int stage = scalars_on_device && hi > lo && !can_read(ctx, k, owner) ? owner : -1;
+                    if (hit) {
+                        part[k] = device_msm<C>(ctx, d, nullptr, 0, scalars + lo * 32, scalars_on_device, hi - lo, fmt, stage, nullptr, &hit->shard[k]);
+                    } else {
+                        if (fill) { fill->shard[k].lo = lo; fill->shard[k].n = hi - lo; }
+                        part[k] = device_msm<C>(ctx, d, bases ? bases + lo * aff_bytes<C>() : nullptr, 0, scalars + lo * 32, scalars_on_device, hi - lo, fmt, stage,
+                                                nullptr, fill ? &fill->shard[k] : nullptr);
+                    }
+                });
             });
-        });
-        for (size_t k = 0; k < g; k++)
-            if (errs[k].code != MI_OK) return fail(ctx, errs[k].code, errs[k].msg);
-        if (fill) {   // the converted set is complete on every device: publish it, evict the least recently used entry beyond the limit
+            for (size_t k = 0; k < g; k++)
+                if (errs[k].code != MI_OK) return fail(ctx, errs[k].code, errs[k].msg);
+            return MI_OK;
+        };
+        auto new_entry = [&]() {
+            auto e = std::make_shared<BaseCacheEntry>();
+            e->ptr = bases; e->n = n;
+            e->shard.resize(g);
+            for (auto& d : devs) e->devs.push_back(d.dev);
+            return e;
+        };
+        struct JoinFp {   // the helper thread reads the caller's bases: it is joined on every path out of this call
+            std::future<uint64_t>& f;
+            ~JoinFp() { if (f.valid()) f.wait(); }
+        } join_fp{fp_job};
+        if (fp_job.valid() && !hit) fill = new_entry();
+        int rc = run();
+        if (rc != MI_OK) return rc;
+        if (fp_job.valid()) {
+            const uint64_t fp = fp_job.get();
+            if (hit && hit->fp != fp) {
+                // mis-speculation: the vector under this pointer changed since the candidate was built.  Another entry may hold the
+                // new content (a buffer that alternates between two sets); otherwise convert it now.
+                hit.reset();
+                {
+                    std::lock_guard<std::mutex> lk(ctx->cache_mu);
+                    for (auto& e : ctx->cache[HostCurve<C>::IDX])
+                        if (e->ptr == bases && e->n == n && e->fp == fp) { hit = e; break; }
+                }
+                if (!hit) fill = new_entry();
+                rc = run();
+                if (rc != MI_OK) return rc;
+            }
             std::lock_guard<std::mutex> lk(ctx->cache_mu);
             auto& v = ctx->cache[HostCurve<C>::IDX];
-            bool dup = false;
-            for (auto& e : v) dup = dup || (e->ptr == fill->ptr && e->n == fill->n && e->fp == fill->fp);   // the other lane was faster
-            if (!dup && ctx->cache_entries) {
-                fill->stamp = ++ctx->cache_clock;
-                v.push_back(fill);
-                while (v.size() > ctx->cache_entries) {
-                    size_t old = 0;
-                    for (size_t q = 1; q < v.size(); q++)
-                        if (v[q]->stamp < v[old]->stamp) old = q;
-                    v.erase(v.begin() + (long)old);
+            if (hit) {
+                hit->stamp = ++ctx->cache_clock;
+                ctx->cache_hits++;
+            } else {
+                ctx->cache_misses++;
+                fill->fp = fp;
+                bool dup = false;
+                for (auto& e : v) dup = dup || (e->ptr == fill->ptr && e->n == fill->n && e->fp == fill->fp);   // the other lane was faster
+                if (!dup && ctx->cache_entries) {   // publish; evict the least recently used entry beyond the limit
+                    fill->stamp = ++ctx->cache_clock;
+                    v.push_back(fill);
+                    while (v.size() > ctx->cache_entries) {
+                        size_t old = 0;
+                        for (size_t q = 1; q < v.size(); q++)
+                            if (v[q]->stamp < v[old]->stamp) old = q;
+                        v.erase(v.begin() + (long)old);
+                    }
                 }
             }
         }

@@ -305,7 +305,7 @@ def _rooflines(g: str, n: int, log_n, acc_ms: float, nwin: int, precomputed: boo
 class MsmLeg:
     """One MSM workload on this rank's GPU: inputs, resident bases, device scalars, timed steps, parity."""
 
-    def __init__(self, pkg, co, torch, g, n, seed_b, seed_s, ncpu, device, dist="uniform", window_bits=0, precomputed=False):
+    def __init__(self, pkg, co, torch, g, n, seed_b, seed_s, ncpu, device, dist="uniform", window_bits=0, precomputed=False, validate=True):
         self.pkg, self.co, self.torch, self.g, self.n = pkg, co, torch, g, n
         self.seed_b, self.seed_s, self.ncpu = seed_b, seed_s, ncpu
         t0 = time.time()
@@ -321,6 +321,12 @@ class MsmLeg:
         else:
             self.ctx.set_bases(g, self.bases, n)
         self.set_bases_s = time.time() - t0
+        # An SRS is validated ONCE when it is loaded (Valid::check of every point, as arkworks' deserialisers do with Validate::Yes): the
+        # library does it on the GPU and records a clean set, which lets the MSMs over it fold the scalars' signs (one digit window
+        # fewer at c = 15 / 17 — nothing at the 2^20 and 2^24 sizes, ~5 % at the 2^21-2^23 shards of config #3).  Outside every timed region.
+        t0 = time.time()
+        self.validated = validate and self.ctx.validate_bases(g) == 0
+        self.validate_s = time.time() - t0
         self.d_scalars = torch.frombuffer(bytearray(self.scalars), dtype=torch.uint8).cuda()
         torch.cuda.synchronize()   # the library reads the scalars on its own stream (include/arkblst_amd.h)
 
@@ -644,6 +650,8 @@ def main() -> None:
                     help="opt-in mode: resident 2^(c j) P tables (mi_msm_g1_set_bases_precomputed); never the default headline")
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zero_one", "small64", "all_equal", "all_ones", "r1cs_mix"],
                     help="scalar distribution (secondary robustness figures; the headline is uniform)")
+    ap.add_argument("--no-validate", action="store_true",
+                    help="skip mi_msm_g1_validate_bases after the base upload: the MSMs then recode the integer scalar (an unvalidated SRS)")
     ap.add_argument("--no-secondary", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--secondary-out", default=None, metavar="FILE",
                     help="where the full records of the secondary legs go (default: bench_secondary.json beside bench.py); the stdout "
@@ -736,7 +744,7 @@ def main() -> None:
     wl += (", bases resident as precomputed 2^(c j) P tables" if args.precomputed else ", bases resident") + ", scalars in HBM"
 
     leg = MsmLeg(pkg, co, torch, g, n, SEED_B + 1000 * rank, SEED_S + 1000 * rank, ncpu, local_rank, dist=args.dist,
-                 window_bits=args.window_bits, precomputed=args.precomputed)
+                 window_bits=args.window_bits, precomputed=args.precomputed, validate=not args.no_validate)
 
     jac_bytes = 144 if g == "g1" else 288
     cdev = "cuda" if on_gpu else "cpu"
@@ -916,7 +924,7 @@ def main() -> None:
                         "seconds": med, "best_seconds": min(times),
                         "single_thread": {"value": n1 / t_single, "unit": "points/s", "points": n1}}
 
-    headline_n, gen_s = n, leg.gen_s
+    headline_n, gen_s, validated, validate_s = n, leg.gen_s, leg.validated, leg.validate_s
     p0 = prof_acc[-1]
     acc_ms = sum(p["accumulate_ms"] for p in prof_acc) / len(prof_acc)
     if xchg.get("comm") is not None:
@@ -970,13 +978,13 @@ def main() -> None:
             "bit_exact": bit_exact,
             "config": {"workload": wl, "points_per_gpu": headline_n, "total_points": total, "window_bits": p0["window_bits"],
                        "num_windows": p0["num_windows"], "parallelism": f"base-set sharded x{world}", "scalar_dist": args.dist,
-                       "precomputed_tables": bool(args.precomputed), "field_repr": "14 x 28-bit limbs in u32 (v_mad_u64_u32)"},
+                       "precomputed_tables": bool(args.precomputed), "bases_validated": validated, "field_repr": "14 x 28-bit limbs in u32 (v_mad_u64_u32)"},
             "roofline": _compact(roof, _ROOF_KEYS),
             "hbm_roofline": _compact(full["hbm_roofline"], _HBM_KEYS),
             "step_frac": step_frac,
             "phases_ms": {k: round(v, 4) for k, v in _phases(prof_acc, breakdown).items()},
         }
-        detail = {"headline_roofline": roof, "headline_hbm_roofline": full["hbm_roofline"], "input_gen_s": gen_s}
+        detail = {"headline_roofline": roof, "headline_hbm_roofline": full["hbm_roofline"], "input_gen_s": gen_s, "validate_bases_s": validate_s}
         if exchange:
             exp_ms, exp_src = _expected_ms(g, log_n) if log_n is not None else (None, None)
             out["config"]["expected_ms_per_rank"] = exp_ms
