@@ -71,6 +71,31 @@ def loop(ctx, rnd, tid):
                     print("PRECOMPUTED MISMATCH", seed, g, n, m, kind); failed.append(1); return
                 stats["precomputed"] = stats.get("precomputed", 0) + 1; stats["points"] += m
             ctx.set_bases(g, bases[:aff], 1)   # drop the tables (the W x allocation is given back: DevBuf::ensure_fit)
+        elif r < 0.045 and nthreads == 1:   # round 5: a resident set through Valid::check on the GPU, then MSMs with the sign fold (c = 15 / 17 lose a window)
+            g = rnd.choice(["g1", "g1", "g2"])
+            aff, lim = AFF[g], POOL[g] // 2
+            n = rnd.randrange(1, lim)
+            start = rnd.randrange(0, POOL[g] - n + 1)
+            bases = bytearray(pools[g][aff * start:aff * (start + n)])
+            if rnd.random() < 0.5: bases[aff * rnd.randrange(n):][:aff] = bytes(aff)   # infinity passes the check
+            bases = bytes(bases)
+            ctx.set_bases(g, bases, n)
+            if ctx.validate_bases(g) != 0:
+                print("VALIDATE MISMATCH: subgroup points rejected", seed, g, n); failed.append(1); return
+            for cb in (15, 17, rnd.choice([0, 13, 16])):
+                m = rnd.choice([n, rnd.randrange(1, n + 1)])
+                sc = [rnd.choice([rnd.randrange(o.R_ORDER), o.R_ORDER - 1 - rnd.randrange(1000), (o.R_ORDER + 1) // 2 + rnd.randrange(1000)]) for _ in range(m)]
+                canon = b"".join(o.fr_to_canon_bytes(x) for x in sc)
+                ctx.set_window_bits(cb)
+                try:
+                    got = ctx.msm(g, None, canon, m, pkg.SCALAR_CANONICAL)
+                    folded = ctx.profile()["num_windows"] == -(-255 // cb) if cb in (15, 17) else True
+                finally:
+                    ctx.set_window_bits(0)
+                if not folded or co.to_affine(g, got) != co.to_affine(g, co.msm(g, bases, canon, m, 0, ncpu)):
+                    print("VALIDATED MISMATCH", seed, g, n, m, cb, folded); failed.append(1); return
+                stats["validated"] = stats.get("validated", 0) + 1; stats["points"] += m
+            ctx.set_bases(g, bases[:aff], 1)
         elif r < 0.06 and nthreads == 1:   # batch entry point over a resident base set (two MSMs in flight on the context's lanes)
             g = rnd.choice(["g1", "g1", "g2"])
             aff, lim = AFF[g], POOL[g]
@@ -179,9 +204,13 @@ def loop(ctx, rnd, tid):
 
 
 with pkg.Context([0], test_hooks=True) as ctx:   # the test build: the same sources plus the mi_test_* hooks
+    # round 5: the base-set cache ON for every host-bases call of 4096 points or more.  The loop's base vectors are fresh `bytes` objects:
+    # the allocator hands the same address (and length) out again with other content — exactly what the fingerprint has to catch
+    ctx.set_base_cache(2)
     ths = [threading.Thread(target=loop, args=(ctx, random.Random(seed * 1000 + t), t)) for t in range(nthreads)]
     for t in ths: t.start()
     for t in ths: t.join()
+    stats["base_cache"] = ctx.base_cache_stats()
 if failed:
     sys.exit(1)
 stats.update({"seconds": round(time.time() - t0, 1), "seed": seed, "threads": nthreads, "mismatches": 0})
