@@ -49,10 +49,13 @@ SIMDS, CLOCK_HZ = 1024, 2.4e9
 # Sum of the measured per-instruction issue costs (real cycles at the measured shader clock; tools/ubench_carry.hip re-based with
 # tools/probe/clock_probe.hip: clock64 ticks 100 MHz, the figures of profiles/r03_ubench_*.txt are 2.4-GHz pseudo-cycles and shrink by
 # clock / 2.4) of ONE wave-wide mixed addition, counted off the shipped code objects by tools/kernel_resources.py --mix; filled from
-# profiles/r04_instruction_costs.json when present
+# the newest profiles/r*_instruction_costs.json when present
 def _load_instruction_costs():
+    """the newest profiles/r*_instruction_costs.json (tools/instruction_costs.py: hot loops of the shipped code objects priced per instruction)"""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r04_instruction_costs.json")))
+        pdir = os.path.join(ROOT, "profiles")
+        f = sorted(f for f in os.listdir(pdir) if f.endswith("_instruction_costs.json"))[-1]
+        return json.load(open(os.path.join(pdir, f)))
     except Exception:
         return {}
 ADD_INSTRUCTION_COST = _load_instruction_costs()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r04_instruction_costs.json: what the hot loops of the shipped code objects cost a SIMD if every instruction issues at its
+"""profiles/r05_instruction_costs.json: what the hot loops of the shipped code objects cost a SIMD if every instruction issues at its
 measured rate (tools/kernel_resources.py COST: tools/ubench_carry.hip / ubench_mad_banks.hip, two waves per SIMD).  Those figures
 were taken as time x 2.4 GHz; the kernels run at the shader clock the PMC passes measure (GRBM_GUI_ACTIVE / duration, ~2.04 GHz
 under this load — and the micro-benchmarks, pure multiply-add streams, are under the same power limit), so every cost is rescaled by
@@ -72,7 +72,7 @@ def main():
                           "k_miller_lines2": {"step_loop": lk, "instruction_cost_ms_2p16_pairs": lines_cycles / (c * 1e9) * 1e3,
                                               "trip": "one iteration of the bit loop = one doubling step (plus, statically, the addition step body "
                                                       "taken 5 times in 63) for the 32 pairs of a wave (two lanes each)"}}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r04_instruction_costs.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "r05_instruction_costs.json"), "w"), indent=1)
     print(json.dumps({k: (v if k == "note" else {a: b for a, b in v.items() if not isinstance(b, dict)}) for k, v in out.items()}, indent=1)[:1500])
 
 
