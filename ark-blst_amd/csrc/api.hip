@@ -22,7 +22,7 @@ bool cpu_ok() {
 }
 
 // Host fold of gathered window sums: out = sum_w 2^(c w) sum_r windows[r * rank_stride + w] (Horner over the windows; the
-// doubling chain is the one thing the GPU cannot do in time).  Deterministic: ranks are added in index order.
+// doubling chain is the one thing the GPU cannot do in time, DESIGN_HISTORY.md §2.6).  Deterministic: ranks are added in index order.
 template <class J, class Raw>
 int fold_windows(const Raw* windows, size_t n_ranks, size_t rank_stride, const mi_window_info* info, Raw* out) {
     if (!out || !info || (n_ranks && info->num_windows && !windows)) return MI_E_INVALID;

@@ -1,6 +1,6 @@
 // Curve-generic kernels of the MSM pipeline (ingest, accumulate, merge, reduce, combine) and normalize_batch.
 //
-// Launch-bounds rule (csrc/Makefile, DESIGN.md §9 "call-ABI miscompare"): a kernel whose body or callees contain a CALL of an
+// Launch-bounds rule (csrc/Makefile, DESIGN_HISTORY.md §9 "call-ABI miscompare"): a kernel whose body or callees contain a CALL of an
 // out-of-line device function is declared with two waves per SIMD (second __launch_bounds__ argument 2): at most 256 registers per
 // lane, hence no AGPRs — ROCm 7.2's hipcc miscompiles calls combined with VGPR spills into AGPRs.  Kernels built for one wave per
 // SIMD (512 registers: PairG2 reduce, the Fp12 kernels) contain no call.  tests/test_cabi.py checks both on the shipped code objects.

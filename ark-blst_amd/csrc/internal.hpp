@@ -10,7 +10,7 @@
 namespace mi {
 
 // ---- msm_sort.hip
-struct CurveCost {        // what the plan needs to know about the curve's kernels (microseconds, measured)
+struct CurveCost {        // what the plan needs to know about the curve's kernels (microseconds, measured; DESIGN_HISTORY.md §8)
     int log_ll;           // log2 logical lanes per reduce wave (coop scheme of k_reduce_coop)
     int comb_log_ll;      // log2 logical lanes per combine wave (k_combine may use a narrower, lower-latency scheme)
     uint32_t max_chunks;  // reduce waves that run at once (1024 SIMDs x occupancy)

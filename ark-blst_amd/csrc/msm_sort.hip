@@ -6,7 +6,7 @@
 
 namespace mi {
 
-// Window size c by a time model of the pipeline on one MI355X (microseconds; constants measured):
+// Window size c by a time model of the pipeline on one MI355X (microseconds; constants measured, see DESIGN_HISTORY.md §8):
 //   accumulate  max(throughput: N W mixed additions at cc.add_per_us,  latency: one lane walks an item of T entries)
 //   merge       one launch per binary-tree level when the short top window overfills its buckets
 //   reduce      a latency chain of 2L + 2 LOG_LL + chain(L) + 1 complete additions per wave, max_chunks waves per round

@@ -44,7 +44,7 @@ MAD_PEAK_T = 39.3                              # 1024 SIMD x 64 lanes x 2.4 GHz 
 MAD_MEASURED_T = 33.4                          # tools/ubench_valu.hip on MI355X: what a pure MAD loop reaches (profiles/r01_ubench_valu.txt)
 # k_accumulate<G1C>: instructions of one mixed addition in the shipped code object (tools/kernel_resources.py + llvm-objdump) priced
 # with the measured per-instruction costs at two waves per SIMD (profiles/r03_ubench_carry.txt): 3542 v_mad_u64_u32 x 4.8 + 126 v_mul_lo x 4.4
-# + 234 v_lshrrev_b64 x 4.6 + 235 v_lshl_add_u64 x 5.05 + 257 v_and x 2.6 + ~330 others x 2.6
+# + 234 v_lshrrev_b64 x 4.6 + 235 v_lshl_add_u64 x 5.05 + 257 v_and x 2.6 + ~330 others x 2.6 (DESIGN_HISTORY.md §9)
 SIMDS, CLOCK_HZ = 1024, 2.4e9
 # Sum of the measured per-instruction issue costs (real cycles at the measured shader clock; tools/ubench_carry.hip re-based with
 # tools/probe/clock_probe.hip: clock64 ticks 100 MHz, the figures of profiles/r03_ubench_*.txt are 2.4-GHz pseudo-cycles and shrink by
@@ -59,7 +59,7 @@ def _load_instruction_costs():
     except Exception:
         return {}
 ADD_INSTRUCTION_COST = _load_instruction_costs()
-PAIRING_FP_MULS_PER_PAIR = 63 * (31 + 39) + 5 * (41 + 39)   # line + sparse Fp12 product per step, squarings shared
+PAIRING_FP_MULS_PER_PAIR = 63 * (31 + 39) + 5 * (41 + 39)   # DESIGN_HISTORY.md §5: line + sparse Fp12 product per step, squarings shared
 
 
 def _free_port() -> int:

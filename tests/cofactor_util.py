@@ -4,7 +4,7 @@ reference-held cofactors (/root/reference/src/g1.rs:42, src/g2.rs:45-54) that mu
 The reference holds no MSM vector, but it does hold h1 and h2.  For a point P of E(Fp) (resp. E'(Fp2)) that is not in the
 r-torsion, h * P lies in it exactly when h is the cofactor and the group law is right: r * (h * P) = infinity while r * P is not.
 That ties the addition / doubling formulas and the scalar path of every implementation to a reference-held constant, not only to
-each other ("group law pinned by cofactor clearing")."""
+each other (DESIGN_HISTORY.md §3: "group law pinned by cofactor clearing")."""
 
 H1_LIMBS = [0x8C00AAAB0000AAAB, 0x396C8C005555E156]                       # src/g1.rs:42
 H2_LIMBS = [0xCF1C38E31C7238E5, 0x1616EC6E786F0C70, 0x21537E293A6691AE, 0xA628F1CB4D9E82EF,

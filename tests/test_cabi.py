@@ -82,12 +82,12 @@ def test_hot_kernels_do_not_spill(pkg):
     # two waves per SIMD where the design says so: at most 256 registers (VGPR + AGPR share one 512-entry file per SIMD lane)
     for k, v in hot.items():
         if "k_reduce_coop<msmk::PairG2>" in k or "k_fp12_prod" in k or "k_miller_accumulate" in k:
-            continue   # one wave per SIMD by design (the pairing's accumulate / tree kernels keep three column sets)
+            continue   # one wave per SIMD by design (DESIGN_HISTORY.md §2.6; the pairing's accumulate / tree kernels keep three column sets)
         assert v["vgpr_count"] + v.get("agpr_count", 0) <= 256, (k, v)
 
 
 def test_no_kernel_mixes_calls_and_agprs(pkg):
-    """Guard for the compiler issue of round 4 (csrc/Makefile, DESIGN.md §9 "call-ABI miscompare"; reproducer
+    """Guard for the compiler issue of round 4 (csrc/Makefile, DESIGN_HISTORY.md §9 "call-ABI miscompare"; reproducer
     tools/call_abi/repro_tower.hip): ROCm 7.2's hipcc miscompiles a kernel that keeps values across calls of out-of-line device
     functions when interprocedural register allocation meets VGPR spills into AGPRs.  The library never lets the two meet: a
     kernel with a call in its body is built for <= 256 registers per lane (.agpr_count, which the assembler maximises over the
@@ -254,7 +254,7 @@ def test_plan_picks_against_the_committed_scans(pkg):
     """The plan's window size against the forced-c scans taken on MI355X after the last change of the pipeline
     (profiles/r04_scan_c_*_merge_tree.jsonl, *_final.jsonl: every window size forced at 2^8 .. 2^24 points, both groups): at every
     scanned size the plan's choice must have measured within 15 % of the best choice (the two known misses are G2 2^13 / 2^14 at
-    13 %).  Host only: the plan needs no device."""
+    13 %, DESIGN_HISTORY.md section 9).  Host only: the plan needs no device."""
     import glob
     import json
 

@@ -730,7 +730,7 @@ def test_base_set_cache_for_the_stateless_call(pkg, co, group):
 
 
 def test_call_abi_reproducer():
-    """The compiler issue behind round 3's "codegen-dependent miscompares" (csrc/Makefile): tools/call_abi/repro_tower.hip
+    """The compiler issue behind round 3's "codegen-dependent miscompares" (DESIGN_HISTORY.md §9, csrc/Makefile): tools/call_abi/repro_tower.hip
     — the test-only single-lane Miller loop's shape: a 512-register kernel that keeps the point and the line state across ~40 calls
     of out-of-line tower functions per round — built twice from the shipped headers.  With the library's flags (VGPR spill slots are
     NOT turned into AGPRs) it must agree with the host run of the same source on all 64 lanes; with the compiler's default it is

@@ -93,7 +93,7 @@ def resources(lib: str | None = None) -> dict[str, dict[str, int]]:
     return res
 
 
-# kernels whose inner loops must run without register spills: substrings of the demangled name
+# kernels whose inner loops must run without register spills (DESIGN_HISTORY.md §5): substrings of the demangled name
 HOT = ("msmk::k_accumulate", "msmk::k_reduce_", "msmk::k_combine", "msmk::k_miller_", "msmk::k_fp12_prod")
 
 

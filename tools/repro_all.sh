@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box call that reproduces every number quoted in DESIGN.md section 8 (takes ~4 minutes):
+# One GPU-box call that reproduces every number quoted in DESIGN_HISTORY.md section 8 (takes ~4 minutes):
 #   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/repro_all.sh'
 # The default bench line carries every single-GPU BASELINE config (secondary.g1_2p24, g2_2p20, pairing_2p16, precomputed tables,
 # in-process multi-device); the size sweep and the row (f) timings follow.
