@@ -278,14 +278,16 @@ def test_plan_picks_against_the_committed_scans(pkg):
         checked += 1
     assert checked >= 25
     # round 5: the PLAIN plan (integer recoding: what every unvalidated base set gets) against its own scan, 2^10 .. 2^23 points
-    tab = {}
-    for f in sorted(glob.glob(os.path.join(root, "profiles", "r05_scan_c_*_plain.jsonl"))):
-        for line in open(f):
-            r = json.loads(line)
-            if r["forced_c"] and r["ok"] and not r.get("validated"):
-                t = tab.setdefault((r["group"], r["log_n"]), {})
-                t[r["forced_c"]] = min(t.get(r["forced_c"], 1e9), r["ms"])
-    assert tab
-    for (group, log_n), t in sorted(tab.items()):
-        c = pkg.test_plan(1 << log_n, 0, group)["c"]
-        assert c in t and t[c] <= 1.15 * min(t.values()), (group, log_n, c, t)
+    # ... and the round-5 scans of both plans, G1 and G2 (the validated plan folds the scalars' signs)
+    for kind, fold in (("plain", False), ("validated", True)):
+        tab = {}
+        for f in sorted(glob.glob(os.path.join(root, "profiles", f"r05_scan_c_*_{kind}.jsonl"))):
+            for line in open(f):
+                r = json.loads(line)
+                if r["forced_c"] and r["ok"] and bool(r.get("validated")) == fold:
+                    t = tab.setdefault((r["group"], r["log_n"]), {})
+                    t[r["forced_c"]] = min(t.get(r["forced_c"], 1e9), r["ms"])
+        assert len(tab) >= 15, kind
+        for (group, log_n), t in sorted(tab.items()):
+            c = pkg.test_plan(1 << log_n, 0, group, fold=fold)["c"]
+            assert c in t and t[c] <= 1.15 * min(t.values()), (kind, group, log_n, c, t)
