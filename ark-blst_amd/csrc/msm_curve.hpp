@@ -498,7 +498,13 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
             if (ctx->cache_entries) {
                 for (auto& e : ctx->cache[HostCurve<C>::IDX])
                     if (e->ptr == bases && e->n == n && (!hit || e->stamp > hit->stamp)) hit = e;   // the most recent candidate
-                fp_job = std::async(std::launch::async, base_fingerprint, bases, n, aff_bytes<C>());
+                try {
+                    fp_job = std::async(std::launch::async, base_fingerprint, bases, n, aff_bytes<C>());
+                } catch (const std::system_error&) {   // no thread to be had: compute it here, as a ready future
+                    std::promise<uint64_t> pr;
+                    pr.set_value(base_fingerprint(bases, n, aff_bytes<C>()));
+                    fp_job = pr.get_future();
+                }
             }
         }
         // device-resident scalars: the shard of device k is read by device k — in place when the vector lives there, through ONE peer

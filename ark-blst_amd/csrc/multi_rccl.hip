@@ -50,6 +50,7 @@ struct Header {
     uint64_t n;
 };
 constexpr uint32_t MAGIC = 0x4d495243u;   // "MIRC"
+constexpr uint32_t FAILED = 0xffffffffu;  // Header::window_bits of a rank whose local part failed: it still joins the collective, so that nobody hangs
 
 double ms_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -107,9 +108,14 @@ int allgather_fold(mi_rccl_comm* c, const void* d_scalars, size_t n, unsigned fm
         // ---- local part: this rank's shard through the single-GPU pipeline; the window sums stay in device memory
         auto t0 = std::chrono::steady_clock::now();
         mi_window_info info{};
+        int local_rc = MI_OK;
+        std::string local_msg;
         if (n) {
-            int rc = device_windows(c->ctx, d_scalars, n, fmt, c->d_send + JAC, &info);
-            if (rc != MI_OK) return fail(rc, std::string("device_windows: ") + mi_msm_last_error(c->ctx));
+            local_rc = device_windows(c->ctx, d_scalars, n, fmt, c->d_send + JAC, &info);
+            if (local_rc != MI_OK) {   // e.g. n beyond this rank's resident shard: the other ranks are already on their way into the all-gather
+                local_msg = std::string("device_windows: ") + mi_msm_last_error(c->ctx);
+                info = mi_window_info{FAILED, 0};
+            }
         } else {
             HIP_RC(hipMemsetAsync(c->d_send, 0, block, c->stream));   // Z = 0 everywhere: the point at infinity per window
         }
@@ -125,10 +131,12 @@ int allgather_fold(mi_rccl_comm* c, const void* d_scalars, size_t n, unsigned fm
         mi_window_info agreed{};
         bool same = true;
         uint32_t cmax = 0;
+        if (local_rc != MI_OK) return fail(local_rc, local_msg);   // after the collective: every rank has seen this rank's FAILED header
         for (int r = 0; r < c->n_ranks; r++) {
             Header h;
             memcpy(&h, c->h_recv + (size_t)r * block, sizeof h);
-            if (h.magic != MAGIC || h.num_windows > MI_MAX_WINDOWS) return fail(MI_E_COMM, "all-gather returned a malformed block");
+            if (h.magic != MAGIC || (h.window_bits != FAILED && h.num_windows > MI_MAX_WINDOWS)) return fail(MI_E_COMM, "all-gather returned a malformed block");
+            if (h.window_bits == FAILED) return fail(MI_E_COMM, "the local part of rank " + std::to_string(r) + " failed: no result on any rank");
             if (h.num_windows == 0) continue;   // a rank without points: its slots are infinity
             if (agreed.num_windows == 0) agreed = mi_window_info{h.window_bits, h.num_windows};
             same = same && h.window_bits == agreed.window_bits && h.num_windows == agreed.num_windows;

@@ -46,7 +46,8 @@ int mi_rccl_comm_rank(const mi_rccl_comm *comm);
  * context's device, synchronised by the caller as for mi_msm_g1_device) over the first n_r points of ITS resident shard; every rank
  * receives the same point.  Ranks may pass different n (0 included).  All ranks must arrive at the same window size: equal shard sizes
  * do; when they do not, the call pins the largest one on every rank's context (mi_msm_set_window_bits) and repeats the local part once —
- * later calls with the same sizes agree at once.  Blocking. */
+ * later calls with the same sizes agree at once.  A rank whose local part fails (say n beyond its resident shard) still joins the all-gather with a
+ * failure mark: it returns its own error, every other rank MI_E_COMM naming it — nobody is left waiting inside the collective.  Blocking. */
 int mi_msm_g1_allgather_fold(mi_rccl_comm *comm, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g1 *out);
 int mi_msm_g2_allgather_fold(mi_rccl_comm *comm, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g2 *out);
 

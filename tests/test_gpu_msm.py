@@ -925,6 +925,10 @@ def test_rccl_allgather_fold_world_size_one(pkg, co, group):
             t = comm.timing()
             assert t["msm_ms"] > 0 and t["exchange_ms"] > 0 and t["repeats"] == 0 and t["num_windows"] > 0 and t["bytes_per_rank"] == 38 * jac
             assert comm.allgather_fold(group, 0, 0, pkg.SCALAR_CANONICAL) == bytes(jac)      # nobody has a point: infinity
+            # a rank whose local part fails (n beyond its resident shard) still joins the collective and gets ITS error; the communicator lives on
+            with pytest.raises(pkg.MsmError) as ei:
+                comm.allgather_fold(group, d_sc.data_ptr(), n + 1, pkg.SCALAR_CANONICAL)
+            assert ei.value.code == -1 and "resident" in str(ei.value)
             short = comm.allgather_fold(group, d_sc.data_ptr(), 100, pkg.SCALAR_CANONICAL)
             assert _canon(co, group, short) == _canon(co, group, co.msm(group, bases[:100 * (jac * 2 // 3)], sc[:3200], 100, 0, 1))
         # a multi-device context is refused (one context per rank)
