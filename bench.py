@@ -626,9 +626,9 @@ def _in_process_isolated(pkg, co, torch, ncpu, slots: int) -> dict:
     import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--in-process-child", "--in-process", str(slots)],
-                           capture_output=True, text=True, timeout=300, cwd=ROOT)
+                           capture_output=True, text=True, timeout=120, cwd=ROOT)
     except subprocess.TimeoutExpired:
-        return {"error": "child process exceeded 300 s (a normal run takes under 30 s)"}
+        return {"error": "child process exceeded 120 s (a normal run takes under 30 s)"}
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if r.returncode != 0 or not lines:
         return {"error": f"child process rc={r.returncode}", "stderr_tail": r.stderr[-600:]}
