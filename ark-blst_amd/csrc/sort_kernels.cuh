@@ -536,25 +536,25 @@ __global__ void __launch_bounds__(1024) k_sched1(const uint32_t* __restrict__ hi
     if (t == 0) { blk_e[blk] = se; blk_i[blk] = si; blk_max[blk] = smax; }
 }
 
-// one workgroup: exclusive scans over the <= 256 block sums, and per (class, block) the base position in order[]
+// one workgroup: exclusive scans over the <= SCHED_MAX_BLK block sums, and per (class, block) the base position in order[]
+// (1024 blocks since round 5: at 2^24 points the 6.8 M buckets were spread over 208 blocks, 32 consecutive buckets per lane — one lane per
+// 128-byte line, one block per CU — and k_sched1 / k_sched3 took 0.12 + 0.50 ms)
+constexpr uint32_t SCHED_MAX_BLK = 1024;
 __global__ void __launch_bounds__(1024) k_sched2(uint32_t nblk, uint32_t* __restrict__ blk_e, uint32_t* __restrict__ blk_i,
                                                  uint32_t* __restrict__ blk_cls, const uint32_t* __restrict__ blk_max,
                                                  uint32_t* __restrict__ meta) {
-    __shared__ uint32_t a[256], b[256], ctot[SCHED_CLASSES], cbase[SCHED_CLASSES];
+    __shared__ uint32_t a[SCHED_MAX_BLK], b[SCHED_MAX_BLK], ctot[SCHED_CLASSES], cbase[SCHED_CLASSES];
     uint32_t t = threadIdx.x;
-    uint32_t ve = 0, vi = 0;
-    if (t < 256) {
-        ve = t < nblk ? blk_e[t] : 0;
-        vi = t < nblk ? blk_i[t] : 0;
-        a[t] = ve;
-        b[t] = vi;
-    }
+    const uint32_t ve = t < nblk ? blk_e[t] : 0, vi = t < nblk ? blk_i[t] : 0;
+    a[t] = ve;
+    b[t] = vi;
     __syncthreads();
-    for (uint32_t d = 1; d < 256; d <<= 1) {
+    for (uint32_t d = 1; d < SCHED_MAX_BLK; d <<= 1) {
         uint32_t xa = 0, xb = 0;
-        if (t < 256 && t >= d) { xa = a[t - d]; xb = b[t - d]; }
+        if (t >= d) { xa = a[t - d]; xb = b[t - d]; }
         __syncthreads();
-        if (t < 256) { a[t] += xa; b[t] += xb; }
+        a[t] += xa;
+        b[t] += xb;
         __syncthreads();
     }
     if (t < nblk) { blk_e[t] = a[t] - ve; blk_i[t] = b[t] - vi; }
@@ -585,9 +585,9 @@ __global__ void __launch_bounds__(1024) k_sched2(uint32_t nblk, uint32_t* __rest
     if (t == 0) {
         uint32_t mx = 1;
         for (uint32_t k = 0; k < nblk; k++) mx = blk_max[k] > mx ? blk_max[k] : mx;
-        meta[0] = b[255];  // total items   (a[], b[] are inclusive scans; entries past nblk are zero)
+        meta[0] = b[SCHED_MAX_BLK - 1];  // total items   (a[], b[] are inclusive scans; entries past nblk are zero)
         meta[1] = mx;      // max items of any bucket
-        meta[2] = a[255];  // total entries
+        meta[2] = a[SCHED_MAX_BLK - 1];  // total entries
         meta[3] = 0;       // merge-list length (level 0 of the merge tree), filled by k_sched3
         meta[4] = 0;       // number of split buckets, filled by k_sched3
         for (uint32_t k = 5; k < MERGE_META; k++) meta[k] = 0;   // [8 + l]: list length of merge level l >= 1 (k_merge appends)
