@@ -74,6 +74,7 @@ def load_library(test_hooks: bool = False):
         for g in ("g1", "g2"):
             getattr(L, f"mi_{g}_deserialize_batch").argtypes = [vp, vp, sz, i, i, vp, vp]
             getattr(L, f"mi_{g}_serialize_batch").argtypes = [vp, vp, sz, i, vp]
+            getattr(L, f"mi_{g}_check_batch").argtypes = [vp, vp, sz, vp]
         L.mi_multi_miller_loop.argtypes = [vp, vp, vp, sz, vp]
         L.mi_multi_pairing.argtypes = [vp, vp, vp, sz, vp]
         L.mi_final_exponentiation.argtypes = [vp, vp]
@@ -249,6 +250,15 @@ class Context:
         self._check(getattr(self._L, f"mi_{group}_deserialize_batch")(self._h, data, n, int(compressed), int(validate), out, st),
                     f"mi_{group}_deserialize_batch")
         return out.raw, st.raw
+
+    def check_batch(self, group: str, points: bytes) -> bytes:
+        """Valid::batch_check over affine points: status bytes (0 valid, 2 not on the curve, 3 not in the subgroup)"""
+        aff = G1_AFF if group == "g1" else G2_AFF
+        n = len(points) // aff
+        st = C.create_string_buffer(n)
+        p, keep = _buf(points)
+        self._check(getattr(self._L, f"mi_{group}_check_batch")(self._h, p, n, st), f"mi_{group}_check_batch")
+        return st.raw
 
     def serialize_batch(self, group: str, points: bytes, compressed: bool = True) -> bytes:
         unit = 48 if group == "g1" else 96

@@ -208,6 +208,9 @@ int mi_g2_serialize_batch(mi_ctx* ctx, const mi_g2_affine* points, size_t n, int
     return g2_serialize(ctx, points, n, compressed, bytes);
 }
 
+int mi_g1_check_batch(mi_ctx* ctx, const mi_g1_affine* points, size_t n, uint8_t* status) { return g1_check_batch(ctx, points, n, status); }
+int mi_g2_check_batch(mi_ctx* ctx, const mi_g2_affine* points, size_t n, uint8_t* status) { return g2_check_batch(ctx, points, n, status); }
+
 int mi_multi_miller_loop(mi_ctx* ctx, const mi_g1_affine* p, const mi_g2_affine* q, size_t n, mi_fp12* out) {
     return miller(ctx, p, q, n, out, false);
 }

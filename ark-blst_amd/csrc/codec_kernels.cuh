@@ -314,30 +314,42 @@ template <> struct PointCheck<G2C> {
     static __device__ __forceinline__ bool in_subgroup(const ec::Fp2& x, const ec::Fp2& y) { return g2_in_subgroup(x, y); }
 };
 
-// Valid::check (is_on_curve && is_torsion_free, /root/reference/src/g1.rs:419-431, src/g2.rs:399-411) of n affine points in device memory.
-//   RAW = true   second pass of mi_g2_deserialize_batch: points in the reference's form as the decoder wrote them (all-zero = infinity or
-//                rejected: skipped), already known to be on the curve; a point outside the subgroup gets status 3 and is zeroed.
-//   RAW = false  mi_msm_g{1,2}_validate_bases: the RESIDENT base set in the device form (infinity flag in the point's last word);
-//                both halves of the check; *n_bad counts the points that fail.
-template <class C, bool RAW>
+// Valid::check (is_on_curve && is_torsion_free, /root/reference/src/g1.rs:386-396, src/g2.rs:366-376) of n affine points in device memory.
+//   MODE 0  mi_msm_g{1,2}_validate_bases: the RESIDENT base set in the device form (infinity flag in the point's last word);
+//           both halves of the check; *n_bad counts the points that fail.
+//   MODE 1  second pass of mi_g2_deserialize_batch: points in the reference's form as the decoder wrote them (all-zero = infinity or
+//           rejected: skipped), already known to be on the curve; a point outside the subgroup gets status 3 and is zeroed.
+//   MODE 2  mi_g{1,2}_check_batch (Valid::batch_check over affine points): points in the reference's form, both halves of the check,
+//           status[i] = 0 / 2 (not on the curve) / 3 (not in the subgroup); the points are not touched.
+template <class C, int MODE>
 __global__ void __launch_bounds__(256, 2) k_validate(uint32_t* __restrict__ pts, uint32_t n, uint8_t* __restrict__ status, uint32_t* __restrict__ n_bad) {
     using E = typename C::F::E;
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     E x, y;
-    if constexpr (RAW) {
-        if (status[i] != 0) return;
+    if constexpr (MODE != 0) {
+        if (MODE == 1 && status[i] != 0) return;
         uint32_t* q = pts + (size_t)i * Geo<C>::RAW_AFF;
         uint32_t any = 0;
 #pragma unroll 4
         for (int k = 0; k < Geo<C>::RAW_AFF; k++) any |= q[k];
-        if (any == 0) return;   // infinity
+        if (any == 0) {   // infinity: a member of every subgroup
+            if (MODE == 2) status[i] = 0;
+            return;
+        }
         ElemIO<E>::from_raw(x, q);
         ElemIO<E>::from_raw(y, q + ElemIO<E>::RAW);
-        if (!PointCheck<C>::in_subgroup(x, y)) {
-            status[i] = 3;
+        if constexpr (MODE == 1) {
+            if (!PointCheck<C>::in_subgroup(x, y)) {
+                status[i] = 3;
 #pragma unroll 4
-            for (int k = 0; k < Geo<C>::RAW_AFF; k++) q[k] = 0u;
+                for (int k = 0; k < Geo<C>::RAW_AFF; k++) q[k] = 0u;
+            }
+        } else {
+            uint8_t st = 0;
+            if (!PointCheck<C>::on_curve(x, y)) st = 2;
+            else if (!PointCheck<C>::in_subgroup(x, y)) st = 3;
+            status[i] = st;
         }
     } else {
         const uint32_t* q = pts + (size_t)i * Geo<C>::PT_WORDS;

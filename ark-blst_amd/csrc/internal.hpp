@@ -65,6 +65,8 @@ int g1_deserialize(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, 
 int g1_serialize(mi_ctx* ctx, const mi_g1_affine* points, size_t n, int compressed, uint8_t* bytes);
 int g2_deserialize(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int validate, mi_g2_affine* out, uint8_t* status);
 int g2_serialize(mi_ctx* ctx, const mi_g2_affine* points, size_t n, int compressed, uint8_t* bytes);
+int g1_check_batch(mi_ctx* ctx, const mi_g1_affine* points, size_t n, uint8_t* status);
+int g2_check_batch(mi_ctx* ctx, const mi_g2_affine* points, size_t n, uint8_t* status);
 int g1_validate_bases(mi_ctx* ctx, size_t* n_invalid);
 int g2_validate_bases(mi_ctx* ctx, size_t* n_invalid);
 #if defined(MI_TEST_HOOKS)

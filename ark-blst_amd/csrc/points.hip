@@ -103,7 +103,7 @@ int validate_bases_impl(mi_ctx* ctx, int idx, size_t* n_invalid) {
             HIP_TRY(hipSetDevice(d.dev));
             HIP_TRY(hipMalloc((void**)&counters[k], 4));
             HIP_TRY(hipMemsetAsync(counters[k], 0, 4, d.stream));
-            hipLaunchKernelGGL((msmk::k_validate<C, false>), dim3((uint32_t)((res.n + 255) / 256)), dim3(256), 0, d.stream, (uint32_t*)res.buf.p,
+            hipLaunchKernelGGL((msmk::k_validate<C, 0>), dim3((uint32_t)((res.n + 255) / 256)), dim3(256), 0, d.stream, (uint32_t*)res.buf.p,
                                (uint32_t)res.n, (uint8_t*)nullptr, counters[k]);
             HIP_TRY(hipGetLastError());
         }
@@ -127,7 +127,43 @@ int validate_bases_impl(mi_ctx* ctx, int idx, size_t* n_invalid) {
     });
 }
 
+// Valid::batch_check over affine points in host memory (src/g1.rs:386-396 per element; the projective form, src/g1.rs:570-579, is
+// normalize_batch followed by this)
+template <class C>
+int check_batch_impl(mi_ctx* ctx, const void* points, size_t n, uint8_t* status) {
+    if (!ctx || (n && (!points || !status))) return fail(ctx, MI_E_INVALID, "invalid argument");
+    if (n == 0) return MI_OK;
+    if (n > 0x7fffffffull) return fail(ctx, MI_E_INVALID, "n too large");
+    LaneLock lk(ctx, true);
+    return guarded(ctx, [&]() -> int {
+        DevState& d = ctx->devs[0];
+        HIP_TRY(hipSetDevice(d.dev));
+        const size_t aff = (size_t)msmk::Geo<C>::RAW_AFF * 4;
+        DevBuf din, dst;
+        struct Rel { DevBuf &a, &b; ~Rel() { a.release(); b.release(); } } rel{din, dst};
+        din.ensure(n * aff); dst.ensure(n);
+        HIP_TRY(hipEventRecord(d.ev[0], d.stream));
+        HIP_TRY(hipMemcpyAsync(din.p, points, n * aff, hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(hipEventRecord(d.ev[1], d.stream));
+        hipLaunchKernelGGL((msmk::k_validate<C, 2>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, d.stream, (uint32_t*)din.p, (uint32_t)n,
+                           (uint8_t*)dst.p, (uint32_t*)nullptr);
+        HIP_TRY(hipEventRecord(d.ev[2], d.stream));
+        HIP_TRY(hipMemcpyAsync(status, dst.p, n, hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        HIP_TRY(hipGetLastError());
+        mi_profile pr{};
+        pr.n = n;
+        pr.h2d_ms = ev_ms(d.ev[0], d.ev[1]);
+        pr.accumulate_ms = ev_ms(d.ev[1], d.ev[2]);
+        set_prof(ctx, pr);
+        return MI_OK;
+    });
+}
+
 }  // namespace
+
+int g1_check_batch(mi_ctx* ctx, const mi_g1_affine* points, size_t n, uint8_t* status) { return check_batch_impl<msmk::G1C>(ctx, points, n, status); }
+int g2_check_batch(mi_ctx* ctx, const mi_g2_affine* points, size_t n, uint8_t* status) { return check_batch_impl<msmk::G2C>(ctx, points, n, status); }
 
 int g1_validate_bases(mi_ctx* ctx, size_t* n_invalid) { return validate_bases_impl<msmk::G1C>(ctx, 0, n_invalid); }
 int g2_validate_bases(mi_ctx* ctx, size_t* n_invalid) { return validate_bases_impl<msmk::G2C>(ctx, 1, n_invalid); }
@@ -139,7 +175,7 @@ int g1_serialize(mi_ctx* ctx, const mi_g1_affine* points, size_t n, int compress
     return serialize_impl(ctx, msmk::k_serialize_g1, 48, points, n, compressed, bytes);
 }
 int g2_deserialize(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int validate, mi_g2_affine* out, uint8_t* status) {
-    return deserialize_impl(ctx, msmk::k_deserialize_g2, msmk::k_validate<msmk::G2C, true>, 96, bytes, n, compressed, validate, out, status);
+    return deserialize_impl(ctx, msmk::k_deserialize_g2, msmk::k_validate<msmk::G2C, 1>, 96, bytes, n, compressed, validate, out, status);
 }
 int g2_serialize(mi_ctx* ctx, const mi_g2_affine* points, size_t n, int compressed, uint8_t* bytes) {
     return serialize_impl(ctx, msmk::k_serialize_g2, 96, points, n, compressed, bytes);

@@ -132,6 +132,17 @@ struct G1Projective {
         return out;
     }
     static std::vector<G1Affine> batch_convert_to_mul_base(const std::vector<G1Projective>& bases) { return normalize_batch(bases); }
+    // impl Valid: fn batch_check(batch) -> Result<(), SerializationError> (src/g1.rs:570-579: normalize_batch, then check() per affine point,
+    // src/g1.rs:386-396).  true = every point is on the curve and in the prime-order subgroup (Ok(())), false = Err(InvalidData).
+    static bool batch_check(const std::vector<G1Projective>& batch) {
+        std::vector<G1Affine> aff = normalize_batch(batch);
+        std::vector<uint8_t> st(aff.size());
+        if (aff.empty()) return true;
+        int rc = mi_g1_check_batch(context(), aff.data(), aff.size(), st.data());
+        if (rc != MI_OK) throw std::runtime_error(std::string("batch_check: ") + mi_msm_last_error(context()));
+        for (uint8_t s : st) if (s) return false;
+        return true;
+    }
     // iter::Sum (src/g1.rs:634-660)
     static G1Projective sum(const std::vector<G1Projective>& xs) {
         G1Projective r = zero();

@@ -186,6 +186,13 @@ int mi_g2_deserialize_batch(mi_ctx *ctx, const uint8_t *bytes, size_t n, int com
                             mi_g2_affine *out, uint8_t *status);
 int mi_g2_serialize_batch(mi_ctx *ctx, const mi_g2_affine *points, size_t n, int compressed, uint8_t *bytes);
 
+/* Valid::check = is_on_curve && is_torsion_free (src/g1.rs:386-396, src/g2.rs:366-376) for n affine points in host memory: what
+ * ark_serialize::Valid::batch_check runs per element on the CPU (the projective form, src/g1.rs:570-579, is normalize_batch followed by this).
+ * status[i]: 0 valid (infinity included), 2 not on the curve, 3 on the curve but not in the prime-order subgroup.  The endomorphism tests of
+ * the decoders above, without the decoding. */
+int mi_g1_check_batch(mi_ctx *ctx, const mi_g1_affine *points, size_t n, uint8_t *status);
+int mi_g2_check_batch(mi_ctx *ctx, const mi_g2_affine *points, size_t n, uint8_t *status);
+
 /* Pairing (BASELINE config #5).  Replaces <Bls12 as Pairing>::multi_miller_loop (src/pairing.rs:49-74:
  * a serial loop of blstrs::miller_loop_lines + blst_fp12_mul on one CPU thread) and final_exponentiation
  * (src/pairing.rs:76-80).  On the GPU: two lanes per pair compute the 68 line evaluations, six lanes per accumulator

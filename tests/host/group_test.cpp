@@ -76,6 +76,9 @@ static int run(const std::string& dir, const char* tag) {
         CHECK(std::memcmp(&g3[0], &g4[0], sizeof(Aff)) == 0);
         CHECK(std::memcmp(&g3[0], &want[0], sizeof(Aff)) != 0);
     }
+    if constexpr (std::is_same<G, G1Projective>::value) {   // Valid::batch_check over the projective inputs (all of them subgroup points)
+        CHECK(G::batch_check(jac));
+    }
     std::printf("%s group_test OK (n = %zu)\n", tag, affines.size());
     return 0;
 }

@@ -729,6 +729,43 @@ def test_base_set_cache_for_the_stateless_call(pkg, co, group):
         assert c.base_cache_stats()["entries"] == 1
 
 
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_check_batch_is_valid_check(ctx, co, o, group):
+    """mi_g{1,2}_check_batch = Valid::check per point (src/g1.rs:386-396, src/g2.rs:366-376): subgroup points and infinity pass, curve
+    points outside the subgroup get 3, points off the curve get 2; against the big-int oracle's on_curve / in_subgroup on every point,
+    and the input is left untouched."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cofactor_util import off_subgroup_points
+
+    F = o.F1 if group == "g1" else o.F2
+    aff = 96 if group == "g1" else 192
+    in_sub = o.g1_in_subgroup if group == "g1" else o.g2_in_subgroup
+    good = co.gen_bases(group, 6061, 500, 4)
+    pts = [good[aff * i:aff * (i + 1)] for i in range(500)]
+    off = [o.affine_to_bytes(F, p) for p in off_subgroup_points(o, group, 3)]
+    bad = []
+    for i in range(3):   # y + 1: not on the curve
+        p = o.affine_from_bytes(F, pts[i])
+        y1 = (p[1] + 1) % o.P if group == "g1" else ((p[1][0] + 1) % o.P, p[1][1])
+        assert not o.on_curve(F, (p[0], y1))
+        bad.append(o._felt_bytes(F, p[0]) + o._felt_bytes(F, y1))
+    blob = pts[:100] + [off[0], bytes(aff)] + pts[100:300] + [bad[0], off[1], bad[1]] + pts[300:] + [off[2], bad[2], bytes(aff)]
+    want = bytearray()
+    for b in blob:
+        if b == bytes(aff):
+            want.append(0)
+            continue
+        p = o.affine_from_bytes(F, b)
+        want.append(2 if not o.on_curve(F, p) else (0 if in_sub(p) else 3))
+    data = b"".join(blob)
+    st = ctx.check_batch(group, data)
+    assert st == bytes(want)
+    assert st.count(3) == 3 and st.count(2) == 3 and len(st) == 508
+    assert ctx.check_batch(group, b"") == b""
+
+
 def test_call_abi_reproducer():
     """The compiler issue behind round 3's "codegen-dependent miscompares" (DESIGN_HISTORY.md §9, csrc/Makefile): tools/call_abi/repro_tower.hip
     — the test-only single-lane Miller loop's shape: a 512-register kernel that keeps the point and the line state across ~40 calls
