@@ -255,6 +255,84 @@ struct mi_ctx {
 
 namespace mi {
 
+// 64-bit fingerprint of a host base vector: every byte of K = min(n, 1024) points spread evenly over the vector (the first and the last
+// included), mixed with the length.  ~100 KB of strided reads from DRAM, software-prefetched, four independent multiply-xor chains:
+// ~25 us measured for 2^20 G1 points with cold caches (4096 samples: 120 us — a page walk per sample — for no better protection).  A vector
+// REWRITTEN under the same pointer and length changes it with probability ~1; a sparse in-place edit of points outside the sample does
+// not — the cache is for immutable base sets (an SRS), which is why it is opt-in (include/arkblst_amd.h).
+inline uint64_t base_fingerprint(const uint8_t* p, size_t n, size_t aff) {
+    const size_t K = std::min<size_t>(n, 1024);
+    uint64_t h[4] = {0x9E3779B97F4A7C15ull ^ (uint64_t)n, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+    auto at = [&](size_t j) { return p + ((K > 1 ? (j * (n - 1)) / (K - 1) : 0) * aff); };
+    for (size_t j = 0; j < K; j++) {
+        if (j + 8 < K) {
+            const uint8_t* q = at(j + 8);
+            __builtin_prefetch(q);
+            __builtin_prefetch(q + 64);
+            if (aff > 128) __builtin_prefetch(q + 128);
+        }
+        const uint8_t* q = at(j);
+        for (size_t b = 0; b < aff; b += 32) {   // aff = 96 or 192: whole 32-byte groups
+            uint64_t w[4];
+            memcpy(w, q + b, 32);
+            for (int t = 0; t < 4; t++) {
+                h[t] = (h[t] ^ w[t]) * 0xD6E8FEB86659FD93ull;
+                h[t] ^= h[t] >> 32;
+            }
+        }
+    }
+    uint64_t r = h[0];
+    for (int t = 1; t < 4; t++) r = (r ^ h[t]) * 0xD6E8FEB86659FD93ull + (r >> 29);
+    return r;
+}
+
+
+// ---- bookkeeping of the base-set cache (mi_ctx::cache, guarded by cache_mu).  Host-only and free of HIP calls, so that
+// tests/host/workers_test.cpp can run it under ThreadSanitizer / AddressSanitizer.
+// cache_begin: false when the cache is off; otherwise `candidate` = the most recently used entry with the same (pointer, n), if any —
+// the caller uses it speculatively while the fingerprint is computed, then confirms it.
+inline bool cache_begin(mi_ctx* ctx, int idx, const void* ptr, size_t n, std::shared_ptr<BaseCacheEntry>& candidate) {
+    std::lock_guard<std::mutex> lk(ctx->cache_mu);
+    if (!ctx->cache_entries) return false;
+    for (auto& e : ctx->cache[idx])
+        if (e->ptr == ptr && e->n == n && (!candidate || e->stamp > candidate->stamp)) candidate = e;
+    return true;
+}
+inline std::shared_ptr<BaseCacheEntry> cache_find(mi_ctx* ctx, int idx, const void* ptr, size_t n, uint64_t fp) {
+    std::lock_guard<std::mutex> lk(ctx->cache_mu);
+    for (auto& e : ctx->cache[idx])
+        if (e->ptr == ptr && e->n == n && e->fp == fp) return e;
+    return nullptr;
+}
+// cache_finish: a confirmed hit is stamped; a filled entry gets its key and is published (unless the other lane published the same
+// key first, or the cache was switched off meanwhile), the least recently used entries beyond the limit leave the list — their
+// memory is freed when the last lane that still reads them drops its reference.
+inline void cache_finish(mi_ctx* ctx, int idx, const std::shared_ptr<BaseCacheEntry>& hit, const std::shared_ptr<BaseCacheEntry>& fill, uint64_t fp) {
+    std::vector<std::shared_ptr<BaseCacheEntry>> dropped;   // destroyed after the lock is released
+    std::lock_guard<std::mutex> lk(ctx->cache_mu);
+    auto& v = ctx->cache[idx];
+    if (hit) {
+        hit->stamp = ++ctx->cache_clock;
+        ctx->cache_hits++;
+        return;
+    }
+    ctx->cache_misses++;
+    if (!fill) return;
+    fill->fp = fp;
+    bool dup = false;
+    for (auto& e : v) dup = dup || (e->ptr == fill->ptr && e->n == fill->n && e->fp == fill->fp);
+    if (dup || !ctx->cache_entries) return;
+    fill->stamp = ++ctx->cache_clock;
+    v.push_back(fill);
+    while (v.size() > ctx->cache_entries) {
+        size_t old = 0;
+        for (size_t q = 1; q < v.size(); q++)
+            if (v[q]->stamp < v[old]->stamp) old = q;
+        dropped.push_back(v[old]);
+        v.erase(v.begin() + (long)old);
+    }
+}
+
 // An MSM call takes ONE free lane (two calls run concurrently); everything that touches the resident bases or the
 // shared settings takes BOTH (exclusive).
 struct LaneLock {

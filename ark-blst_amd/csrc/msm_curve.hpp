@@ -438,37 +438,6 @@ int set_bases_impl(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute
     });
 }
 
-// 64-bit fingerprint of a host base vector: every byte of K = min(n, 1024) points spread evenly over the vector (the first and the last
-// included), mixed with the length.  ~100 KB of strided reads from DRAM, software-prefetched, four independent multiply-xor chains:
-// ~25 us measured for 2^20 G1 points with cold caches (4096 samples: 120 us — a page walk per sample — for no better protection).  A vector
-// REWRITTEN under the same pointer and length changes it with probability ~1; a sparse in-place edit of points outside the sample does
-// not — the cache is for immutable base sets (an SRS), which is why it is opt-in (include/arkblst_amd.h).
-inline uint64_t base_fingerprint(const uint8_t* p, size_t n, size_t aff) {
-    const size_t K = std::min<size_t>(n, 1024);
-    uint64_t h[4] = {0x9E3779B97F4A7C15ull ^ (uint64_t)n, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
-    auto at = [&](size_t j) { return p + ((K > 1 ? (j * (n - 1)) / (K - 1) : 0) * aff); };
-    for (size_t j = 0; j < K; j++) {
-        if (j + 8 < K) {
-            const uint8_t* q = at(j + 8);
-            __builtin_prefetch(q);
-            __builtin_prefetch(q + 64);
-            if (aff > 128) __builtin_prefetch(q + 128);
-        }
-        const uint8_t* q = at(j);
-        for (size_t b = 0; b < aff; b += 32) {   // aff = 96 or 192: whole 32-byte groups
-            uint64_t w[4];
-            memcpy(w, q + b, 32);
-            for (int t = 0; t < 4; t++) {
-                h[t] = (h[t] ^ w[t]) * 0xD6E8FEB86659FD93ull;
-                h[t] ^= h[t] >> 32;
-            }
-        }
-    }
-    uint64_t r = h[0];
-    for (int t = 1; t < 4; t++) r = (r ^ h[t]) * 0xD6E8FEB86659FD93ull + (r >> 29);
-    return r;
-}
-
 template <class C>
 int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scalars_on_device, size_t n, unsigned fmt, void* out) {
     using J = typename HostCurve<C>::J;
@@ -493,18 +462,13 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
         constexpr size_t CACHE_MIN_POINTS = 1u << 12;   // below that the upload is cheaper than the bookkeeping is worth
         std::shared_ptr<BaseCacheEntry> hit, fill;
         std::future<uint64_t> fp_job;
-        if (bases && n >= CACHE_MIN_POINTS) {
-            std::lock_guard<std::mutex> lk(ctx->cache_mu);
-            if (ctx->cache_entries) {
-                for (auto& e : ctx->cache[HostCurve<C>::IDX])
-                    if (e->ptr == bases && e->n == n && (!hit || e->stamp > hit->stamp)) hit = e;   // the most recent candidate
-                try {
-                    fp_job = std::async(std::launch::async, base_fingerprint, bases, n, aff_bytes<C>());
-                } catch (const std::system_error&) {   // no thread to be had: compute it here, as a ready future
-                    std::promise<uint64_t> pr;
-                    pr.set_value(base_fingerprint(bases, n, aff_bytes<C>()));
-                    fp_job = pr.get_future();
-                }
+        if (bases && n >= CACHE_MIN_POINTS && cache_begin(ctx, HostCurve<C>::IDX, bases, n, hit)) {
+            try {
+                fp_job = std::async(std::launch::async, base_fingerprint, bases, n, aff_bytes<C>());
+            } catch (const std::system_error&) {   // no thread to be had: compute it here, as a ready future
+                std::promise<uint64_t> pr;
+                pr.set_value(base_fingerprint(bases, n, aff_bytes<C>()));
+                fp_job = pr.get_future();
             }
         }
         // device-resident scalars: the shard of device k is read by device k — in place when the vector lives there, through ONE peer
@@ -558,37 +522,12 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
             if (hit && hit->fp != fp) {
                 // mis-speculation: the vector under this pointer changed since the candidate was built.  Another entry may hold the
                 // new content (a buffer that alternates between two sets); otherwise convert it now.
-                hit.reset();
-                {
-                    std::lock_guard<std::mutex> lk(ctx->cache_mu);
-                    for (auto& e : ctx->cache[HostCurve<C>::IDX])
-                        if (e->ptr == bases && e->n == n && e->fp == fp) { hit = e; break; }
-                }
+                hit = cache_find(ctx, HostCurve<C>::IDX, bases, n, fp);
                 if (!hit) fill = new_entry();
                 rc = run();
                 if (rc != MI_OK) return rc;
             }
-            std::lock_guard<std::mutex> lk(ctx->cache_mu);
-            auto& v = ctx->cache[HostCurve<C>::IDX];
-            if (hit) {
-                hit->stamp = ++ctx->cache_clock;
-                ctx->cache_hits++;
-            } else {
-                ctx->cache_misses++;
-                fill->fp = fp;
-                bool dup = false;
-                for (auto& e : v) dup = dup || (e->ptr == fill->ptr && e->n == fill->n && e->fp == fill->fp);   // the other lane was faster
-                if (!dup && ctx->cache_entries) {   // publish; evict the least recently used entry beyond the limit
-                    fill->stamp = ++ctx->cache_clock;
-                    v.push_back(fill);
-                    while (v.size() > ctx->cache_entries) {
-                        size_t old = 0;
-                        for (size_t q = 1; q < v.size(); q++)
-                            if (v[q]->stamp < v[old]->stamp) old = q;
-                        v.erase(v.begin() + (long)old);
-                    }
-                }
-            }
+            cache_finish(ctx, HostCurve<C>::IDX, hit, fill, fp);
         }
         J r = J::inf();
         for (size_t k = 0; k < g; k++) r = r.add(part[k]);

@@ -118,6 +118,68 @@ int main() {
             CHECK(next == n);
         }
     }
+    // 6. base-set cache (round 5): the fingerprint and the bookkeeping that msm_impl drives from two lanes at once
+    {
+        // fingerprint: equal content -> equal value; any byte of a SAMPLED point, the length, or the first / last point changes it
+        const size_t n = 50000, aff = 96;
+        std::vector<uint8_t> a(n * aff), b;
+        for (size_t i = 0; i < a.size(); i++) a[i] = (uint8_t)(i * 131 + (i >> 7));
+        b = a;
+        const uint64_t fa = base_fingerprint(a.data(), n, aff);
+        CHECK(fa == base_fingerprint(b.data(), n, aff));
+        CHECK(fa != base_fingerprint(a.data(), n - 1, aff));
+        b[0] ^= 1;                          CHECK(fa != base_fingerprint(b.data(), n, aff)); b = a;
+        b[(n - 1) * aff + 95] ^= 0x80;      CHECK(fa != base_fingerprint(b.data(), n, aff)); b = a;
+        const size_t K = 1024;
+        for (size_t j : {1ul, 511ul, 1022ul}) {   // sampled indices: floor(j (n - 1) / (K - 1))
+            b[(j * (n - 1) / (K - 1)) * aff + 40] += 3;
+            CHECK(fa != base_fingerprint(b.data(), n, aff));
+            b = a;
+        }
+        CHECK(base_fingerprint(a.data(), 1, aff) != base_fingerprint(a.data() + aff, 1, aff));
+        std::vector<uint8_t> g2(3000 * 192, 7);
+        (void)base_fingerprint(g2.data(), 3000, 192);   // 192-byte points: whole 32-byte groups, no read past the end (ASan)
+        // bookkeeping under contention: four threads, three base vectors, a two-entry cache, entries without device memory
+        mi_ctx ctx;
+        ctx.cache_entries = 2;
+        std::vector<std::vector<uint8_t>> sets(3, std::vector<uint8_t>(8192 * aff));
+        for (size_t k = 0; k < 3; k++)
+            for (size_t i = 0; i < sets[k].size(); i++) sets[k][i] = (uint8_t)(i * (k + 3) + k);
+        std::atomic<int> bad{0};
+        auto body = [&](int t) {
+            for (int i = 0; i < 4000; i++) {
+                const size_t k = (size_t)((i * 7 + t) % 3);
+                const uint8_t* ptr = sets[k].data();
+                std::shared_ptr<BaseCacheEntry> hit, fill;
+                if (!cache_begin(&ctx, 0, ptr, 8192, hit)) { bad++; continue; }
+                const uint64_t fp = base_fingerprint(ptr, 8192, aff);
+                if (hit && hit->fp != fp) hit = cache_find(&ctx, 0, ptr, 8192, fp);
+                if (hit && (hit->ptr != ptr || hit->fp != fp)) bad++;
+                if (!hit) {
+                    fill = std::make_shared<BaseCacheEntry>();
+                    fill->ptr = ptr; fill->n = 8192;
+                    fill->shard.resize(1);
+                    fill->devs.push_back(0);
+                }
+                cache_finish(&ctx, 0, hit, fill, fp);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 0; t < 4; t++) th.emplace_back(body, t);
+        for (auto& t : th) t.join();
+        CHECK(bad.load() == 0);
+        CHECK(ctx.cache[0].size() <= 2 && ctx.cache_hits + ctx.cache_misses == 16000 && ctx.cache_misses >= 3);
+        for (size_t x = 0; x < ctx.cache[0].size(); x++)
+            for (size_t y = x + 1; y < ctx.cache[0].size(); y++) CHECK(ctx.cache[0][x]->ptr != ctx.cache[0][y]->ptr);   // no duplicate keys
+        // an in-place rewrite: the candidate is found by (pointer, n) but its fingerprint no longer matches
+        sets[0][5] ^= 0xff;
+        std::shared_ptr<BaseCacheEntry> cand;
+        CHECK(cache_begin(&ctx, 0, sets[0].data(), 8192, cand));
+        if (cand) CHECK(cand->fp != base_fingerprint(sets[0].data(), 8192, aff));
+        ctx.cache_entries = 0;
+        std::shared_ptr<BaseCacheEntry> none;
+        CHECK(!cache_begin(&ctx, 0, sets[1].data(), 8192, none));
+    }
     printf("workers OK\n");
     return 0;
 }
