@@ -766,6 +766,35 @@ def test_check_batch_is_valid_check(ctx, co, o, group):
     assert ctx.check_batch(group, b"") == b""
 
 
+def test_plain_cpp_harness_of_the_exchange(tmp_path, co):
+    """examples/multi_gpu_msm.cpp: the one-process-per-GPU deployment in plain C++ against the two C ABIs — no Python host, no torch, the
+    system's RCCL — built with g++ and run as ONE rank on this box's GPU (rank 0 writes the ncclUniqueId file, creates the communicator,
+    runs mi_msm_g1_allgather_fold over device-resident scalars): the 144-byte result equals the C oracle's."""
+    import json
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    exe = os.path.join(here, "host", "multi_gpu_msm")
+    lib = os.path.join(root, "ark-blst_amd", "lib")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", exe,
+                           os.path.join(root, "examples", "multi_gpu_msm.cpp"), "-L" + lib, "-larkblst_amd_rccl", "-larkblst_amd",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+    n = 70000
+    bases = co.gen_bases("g1", 9911, n, 8)
+    sc = co.gen_scalars(9912, n)
+    (tmp_path / "bases.bin").write_bytes(bases)
+    (tmp_path / "scalars.bin").write_bytes(sc)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([exe, "0", "1", str(tmp_path / "id"), str(tmp_path / "bases.bin"), str(tmp_path / "scalars.bin"), str(tmp_path / "out.bin"), "2"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_ranks"] == 1 and line["points_total"] == n and line["ms"] > 0 and line["exchange_ms"] > 0
+    got = (tmp_path / "out.bin.0").read_bytes()
+    assert len(got) == 144 and co.to_affine("g1", got) == co.dlog_expected("g1", sc, 9911, n)
+
+
 def test_call_abi_reproducer():
     """The compiler issue behind round 3's "codegen-dependent miscompares" (DESIGN_HISTORY.md §9, csrc/Makefile): tools/call_abi/repro_tower.hip
     — the test-only single-lane Miller loop's shape: a 512-register kernel that keeps the point and the line state across ~40 calls
