@@ -181,6 +181,16 @@ struct G2Projective {
         return out;
     }
     static std::vector<G2Affine> batch_convert_to_mul_base(const std::vector<G2Projective>& bases) { return normalize_batch(bases); }
+    // impl Valid: batch_check (src/g2.rs:545-562, 366-376), as for G1
+    static bool batch_check(const std::vector<G2Projective>& batch) {
+        std::vector<G2Affine> aff = normalize_batch(batch);
+        std::vector<uint8_t> st(aff.size());
+        if (aff.empty()) return true;
+        int rc = mi_g2_check_batch(context(), aff.data(), aff.size(), st.data());
+        if (rc != MI_OK) throw std::runtime_error(std::string("batch_check: ") + mi_msm_last_error(context()));
+        for (uint8_t s : st) if (s) return false;
+        return true;
+    }
     static G2Projective sum(const std::vector<G2Projective>& xs) {
         G2Projective r = zero();
         if (!xs.empty()) mi_g2_sum(reinterpret_cast<const mi_g2*>(xs.data()), xs.size(), &r.p);

@@ -76,8 +76,11 @@ static int run(const std::string& dir, const char* tag) {
         CHECK(std::memcmp(&g3[0], &g4[0], sizeof(Aff)) == 0);
         CHECK(std::memcmp(&g3[0], &want[0], sizeof(Aff)) != 0);
     }
-    if constexpr (std::is_same<G, G1Projective>::value) {   // Valid::batch_check over the projective inputs (all of them subgroup points)
-        CHECK(G::batch_check(jac));
+    CHECK(G::batch_check(jac));   // Valid::batch_check over the projective inputs (all of them subgroup points)
+    {
+        auto broken = jac;            // a point moved off the curve (x + 1 in the limbs' Montgomery form) must fail the check
+        reinterpret_cast<uint64_t*>(&broken[0])[0] ^= 1;
+        CHECK(!G::batch_check(broken));
     }
     std::printf("%s group_test OK (n = %zu)\n", tag, affines.size());
     return 0;
