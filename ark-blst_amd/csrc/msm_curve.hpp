@@ -40,6 +40,9 @@ inline size_t max_part(mi_ctx* ctx) {
 // Device of a caller-supplied device pointer.  A pointer this runtime does not know — plain host memory, or memory of a second HIP
 // runtime loaded into the process (load order) — is the caller's error (MI_E_INVALID), not an opaque fault later.
 inline int device_of_ptr(const void* p, const char* what) {
+    // the kernels read scalars and write window sums as 16-byte vectors: a misaligned device pointer would fault on the GPU
+    if (reinterpret_cast<uintptr_t>(p) & 15u)
+        throw HipFail{std::string(what) + " must be 16-byte aligned", false, true};
     hipPointerAttribute_t a{};
     hipError_t e = hipPointerGetAttributes(&a, p);
     if (e != hipSuccess) (void)hipGetLastError();

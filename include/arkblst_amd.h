@@ -151,7 +151,7 @@ int mi_msm_base_cache_stats(const mi_ctx *ctx, uint64_t *hits, uint64_t *misses,
  * caller must have synchronised the stream that produced them (hipStreamSynchronize / torch.cuda.synchronize) before the
  * call.  With a multi-device context device k reads its shard [lo_k, hi_k) of the one vector: in place when the vector lives on
  * that device, through one peer copy of the shard (hipMemcpyPeerAsync) otherwise.  A pointer the runtime does not know
- * (host memory; memory of a second HIP runtime in the process) is MI_E_INVALID. */
+ * (host memory; memory of a second HIP runtime in the process) or one that is not 16-byte aligned is MI_E_INVALID. */
 int mi_msm_g1_device(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g1 *out);
 int mi_msm_g2_device(mi_ctx *ctx, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g2 *out);
 

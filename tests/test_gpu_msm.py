@@ -795,6 +795,23 @@ def test_plain_cpp_harness_of_the_exchange(tmp_path, co):
     assert len(got) == 144 and co.to_affine("g1", got) == co.dlog_expected("g1", sc, 9911, n)
 
 
+def test_misaligned_device_pointer_is_an_error_not_a_fault(pkg, co):
+    """device scalars are read as 16-byte vectors: a device pointer off that alignment comes back as MI_E_INVALID (the GPU is never asked)"""
+    import torch
+
+    n = 1000
+    bases = co.gen_bases("g1", 1212, n, 2)
+    d = torch.zeros(32 * n + 64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with pkg.Context([0]) as c:
+        c.set_bases("g1", bases, n)
+        for off in (4, 8, 1):
+            with pytest.raises(pkg.MsmError) as ei:
+                c.msm_device("g1", d.data_ptr() + off, n, pkg.SCALAR_CANONICAL)
+            assert ei.value.code == -1 and "aligned" in str(ei.value)
+        assert c.msm_device("g1", d.data_ptr() + 16, n, pkg.SCALAR_CANONICAL) == bytes(144)   # all-zero scalars: infinity
+
+
 def test_call_abi_reproducer():
     """The compiler issue behind round 3's "codegen-dependent miscompares" (DESIGN_HISTORY.md §9, csrc/Makefile): tools/call_abi/repro_tower.hip
     — the test-only single-lane Miller loop's shape: a 512-register kernel that keeps the point and the line state across ~40 calls
