@@ -133,7 +133,8 @@ int mi_msm_g2(mi_ctx *ctx, const mi_g2_affine *bases, const uint8_t *scalars, si
  * prover with a fixed SRS passes the same host base vector on every call, and the call above converts and uploads it every time (as the
  * reference does, src/gpu.rs:149: 6.2 ms instead of 4.1 ms at 2^20 points).  With `entries` > 0 the context keeps the device form of the
  * last `entries` base vectors per group it was given (mi_msm_g{1,2} with bases != NULL, n >= 4096; least recently used out first), keyed
- * by (host pointer, n, a 64-bit fingerprint of every byte of 1024 points spread evenly over the vector — ~25 us per call).  A
+ * by (host pointer, n, a 64-bit fingerprint of every byte of 1024 points spread evenly over the vector — ~25 us, computed on a helper thread
+ * under the GPU work: an entry with the same pointer and n is used speculatively and confirmed before the result leaves).  A
  * hit runs the resident path: the bases do not cross PCIe.  A miss costs what the uncached call costs (the conversion writes into the new
  * entry).  CONTRACT: the fingerprint catches a vector that was rewritten or reallocated under the same address with probability ~1; it
  * does NOT see an in-place edit of a few points outside the sample.  A caller that edits single points of a base vector between calls
