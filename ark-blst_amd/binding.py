@@ -25,7 +25,8 @@ class Profile(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("h2d_ms", "ingest_ms", "digits_ms", "scan_ms", "scatter_ms", "accumulate_ms",
                                           "reduce_ms", "combine_ms", "d2h_ms", "host_fold_ms", "total_ms")] + [
         ("window_bits", C.c_uint32), ("num_windows", C.c_uint32), ("n", C.c_uint64), ("accumulate_adds", C.c_uint64),
-        ("work_items", C.c_uint32), ("max_items_per_bucket", C.c_uint32)]
+        ("work_items", C.c_uint32), ("max_items_per_bucket", C.c_uint32),
+        ("window_groups", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 def profile_dict(p: Profile) -> dict:
@@ -79,6 +80,7 @@ def load_library(test_hooks: bool = False):
         L.mi_multi_pairing.argtypes = [vp, vp, vp, sz, vp]
         L.mi_final_exponentiation.argtypes = [vp, vp]
         L.mi_msm_set_window_bits.argtypes = [vp, u]
+        L.mi_msm_set_pipeline.argtypes = [vp, C.POINTER(u), u]
         L.mi_msm_set_base_cache.argtypes = [vp, u]
         L.mi_msm_invalidate_base_cache.argtypes = [vp]
         L.mi_msm_base_cache_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(u)]
@@ -156,6 +158,12 @@ class Context:
 
     def set_window_bits(self, c: int):
         self._check(self._L.mi_msm_set_window_bits(self._h, c), "mi_msm_set_window_bits")
+
+    def set_pipeline(self, weights=None):
+        """Window groups of a pipelined call (mi_msm_set_pipeline): None = built-in choice, [1] = off, else relative sizes, top windows first."""
+        w = list(weights or [])
+        arr = (C.c_uint * max(1, len(w)))(*w)
+        self._check(self._L.mi_msm_set_pipeline(self._h, arr, len(w)), "mi_msm_set_pipeline")
 
     def set_base_cache(self, entries: int):
         """base-set cache of the stateless call shape (mi_msm_set_base_cache): 0 = off"""

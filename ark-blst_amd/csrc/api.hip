@@ -74,7 +74,24 @@ int mi_msm_init(mi_ctx** out, const int* device_ids, int n_devices) {
                 HIP_TRY(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
                 for (auto& e : d->ev) HIP_TRY(hipEventCreate(&e));
                 for (auto& e : d->cev) HIP_TRY(hipEventCreate(&e));
+                for (Scratch& sc : d->sc)
+                    for (auto& e : sc.ev) HIP_TRY(hipEventCreate(&e));
             }
+        }
+        if (const char* e = getenv("ARKBLST_AMD_PIPELINE")) {   // window groups of a pipelined call (mi_msm_set_pipeline): "0" / "off", "auto", or weights "3,5,5,3"
+            std::vector<unsigned> w;
+            if (!strcmp(e, "0") || !strcmp(e, "off") || !strcmp(e, "1")) w = {1};
+            else if (strcmp(e, "auto"))
+                for (const char* q = e; *q;) {
+                    char* end = nullptr;
+                    unsigned long v = strtoul(q, &end, 10);
+                    if (end == q) break;
+                    w.push_back((unsigned)std::min<unsigned long>(std::max<unsigned long>(v, 1), 1000));
+                    q = *end == ',' ? end + 1 : end;
+                    if (*end && *end != ',') break;
+                }
+            if (w.size() > (size_t)MAX_GROUPS) w.resize(MAX_GROUPS);
+            ctx->pipe_weights = w;
         }
         if (const char* e = getenv("ARKBLST_AMD_BASE_CACHE")) {   // the operator's switch: overrides mi_msm_set_base_cache
             long v = strtol(e, nullptr, 10);
@@ -118,13 +135,21 @@ void mi_msm_destroy(mi_ctx* ctx) {
         for (auto& d : *lane) {
             (void)hipSetDevice(d.dev);
             if (d.stream) (void)hipStreamSynchronize(d.stream);
+            if (d.acc2_stream) (void)hipStreamSynchronize(d.acc2_stream);
+            if (d.aux_stream) (void)hipStreamSynchronize(d.aux_stream);
             d.for_each_buf([](DevBuf& b) { b.release(); });
             if (d.h_pairs) (void)hipHostFree(d.h_pairs);
-            if (d.h_meta) (void)hipHostFree(d.h_meta);
             for (auto& e : d.ev)
                 if (e) (void)hipEventDestroy(e);
             for (auto& e : d.cev)
                 if (e) (void)hipEventDestroy(e);
+            for (Scratch& sc : d.sc) {
+                if (sc.h_meta) (void)hipHostFree(sc.h_meta);
+                for (auto& e : sc.ev)
+                    if (e) (void)hipEventDestroy(e);
+            }
+            if (d.aux_stream) (void)hipStreamDestroy(d.aux_stream);
+            if (d.acc2_stream) (void)hipStreamDestroy(d.acc2_stream);
             if (d.copy_stream) (void)hipStreamDestroy(d.copy_stream);
             if (d.stream) (void)hipStreamDestroy(d.stream);
         }
@@ -284,6 +309,15 @@ int mi_msm_set_window_bits(mi_ctx* ctx, unsigned window_bits) {
     if (!ctx || (window_bits != 0 && (window_bits < 7 || window_bits > 22))) return fail(ctx, MI_E_INVALID, "window_bits must be 0 or 7..22");
     LaneLock lk(ctx, true);
     ctx->forced_c = window_bits;
+    return MI_OK;
+}
+
+int mi_msm_set_pipeline(mi_ctx* ctx, const unsigned* weights, unsigned n_groups) {
+    if (!ctx || n_groups > (unsigned)MAX_GROUPS || (n_groups > 1 && !weights)) return fail(ctx, MI_E_INVALID, "at most 4 window groups; weights must be given for more than one");
+    LaneLock lk(ctx, true);
+    ctx->pipe_weights.clear();
+    if (n_groups == 1) ctx->pipe_weights = {1};
+    for (unsigned g = 0; n_groups > 1 && g < n_groups; g++) ctx->pipe_weights.push_back(std::min(std::max(weights[g], 1u), 1000u));
     return MI_OK;
 }
 

@@ -56,7 +56,8 @@ extern std::atomic<int> g_fail_allocs;   // > 0: that many upcoming DevBuf::ensu
 inline uint32_t num_windows(unsigned c, bool fold) { return (255 + c - 1) / c + ((!fold && 255 % c == 0) ? 1u : 0u); }
 
 struct Plan {
-    uint32_t c, nwin;     // window bits, digit windows = num_windows(c, fold)
+    uint32_t c, nwin;     // window bits; digit windows of this plan: num_windows(c, fold) for a whole call, fewer for one window group of it
+    uint32_t win0;        // first digit window (0 for a whole call; a group of a pipelined call covers [win0, win0 + nwin))
     bool fold;            // sign fold (see num_windows): travels to the digit kernels as bit 1 of their fmt argument
     uint32_t bwin;        // bucket sets: nwin, or 1 when all windows share one (precomputed tables)
     uint32_t nb, coop_L, chunks_per_win, logT, lo_bits;   // coop_L: buckets per logical lane of k_reduce_coop (any value 1..64)
@@ -125,24 +126,45 @@ struct BaseCacheEntry {
     }
 };
 
-// Per-device state of ONE LANE of a context: stream, events and scratch.  A context has two lanes per device so that two
+// Scratch of ONE WINDOW GROUP of an MSM call: everything the sort, the schedule, the accumulate kernel and the reduction of a set of
+// digit windows write.  A call is either one group (all windows, one stream: small inputs, shared bucket sets) or up to MAX_GROUPS
+// groups whose phases overlap on the lane's streams (run_msm, msm_curve.hpp): sort(g + 1) and reduce(g - 1) run under accumulate(g).
+constexpr int MAX_GROUPS = 4;
+struct Scratch {
+    DevBuf hist, offsets, woff, meta, sched, sorted, partial, order, item_bucket, pairs, pairs2;
+    DevBuf tilecnt, tileoff, bin_tot, bin_base, binA_base, coarse, coarseA, seg_cnt, seg_base, segcnt, segoff, merge_list, merge_list2;
+    uint32_t* h_meta = nullptr;   // pinned, 32 B: the schedule's item counts
+    // [0] sort start, [1] coarse partition done, [2] fine sort done, [3] schedule done (always recorded: read_schedule waits on it and the
+    // accumulate stream of a pipelined call does), [4] accumulate done, [5] reduce done, [6] combine done, [7] window sums copied out
+    hipEvent_t ev[8] = {};
+    template <class Fn> void for_each_buf(Fn fn) {
+        for (DevBuf* b : {&hist, &offsets, &woff, &meta, &sched, &sorted, &partial, &order, &item_bucket, &pairs, &pairs2, &tilecnt, &tileoff, &bin_tot,
+                          &bin_base, &binA_base, &coarse, &coarseA, &seg_cnt, &seg_base, &segcnt, &segoff, &merge_list, &merge_list2})
+            fn(*b);
+    }
+};
+
+// Per-device state of ONE LANE of a context: streams, events and scratch.  A context has two lanes per device so that two
 // host threads (arkworks calls the trait method from rayon workers) overlap: one call's sort / reduce / host tail runs
 // under the other's accumulate kernel.  The resident bases are shared.
 struct DevState {
     int dev = 0;
     uint32_t simds = 1024;   // 4 per compute unit (256 CUs on MI355X)
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // everything of a one-group call; accumulate kernels of the even groups of a pipelined call
     hipStream_t copy_stream = nullptr;   // chunked H2D of host-slice calls, overlapped with the kernels that consume the chunks
+    // pipelined calls only, created on the lane's first one (ensure_pipeline_streams): the accumulate kernels of the odd groups, and the
+    // sorts + reductions of every group (high priority: short latency-bound launches that must find wave slots under the accumulate kernels)
+    hipStream_t acc2_stream = nullptr, aux_stream = nullptr;
     hipEvent_t ev[12] = {};
     hipEvent_t cev[10] = {};             // copy stream: [0] first copy issued, [1..8] chunk landed, [9] last copy done
     Resident* res = nullptr;   // -> mi_ctx::residents[device][2]
     // scratch
-    DevBuf raw, call_bases, call_flags, scalars, hist, offsets, woff, meta, sched, sorted, partial, order, item_bucket, pairs, pairs2;
-    DevBuf tilecnt, tileoff, bin_tot, bin_base, binA_base, coarse, coarseA, seg_cnt, seg_base, segcnt, segoff, merge_list, merge_list2;
+    DevBuf raw, call_bases, call_flags, scalars;
+    Scratch sc[MAX_GROUPS];
     DevBuf pr_p, pr_q, pr_lvl[2], pr_raw, pr_lines;   // pairing: inputs, tree levels, top values, line coefficients
-    void* h_pairs = nullptr;   // pinned host staging: window sums (D2H) and the schedule's item counts
+    DevBuf io_in, io_out, io_status, nv_vals, nv_pref, nv_inv, nv_top;   // rows (f): staging of normalize / (de)serialize / check, kept across calls
+    void* h_pairs = nullptr;   // pinned host staging: window sums (D2H), pairing top values
     size_t h_pairs_cap = 0;
-    uint32_t* h_meta = nullptr;   // pinned, 32 B
     mi_profile prof{};
     int prof_level = 1;   // copied from the context at the start of a call (mi_msm_set_profile_level): which events the pipeline records
 
@@ -154,11 +176,21 @@ struct DevState {
         HIP_TRY(hipHostMalloc(&h_pairs, bytes, hipHostMallocDefault));
         h_pairs_cap = bytes;
     }
+    // the two extra streams of a pipelined call.  Stream priorities: the HIP runtime keeps one pool of hardware queues per priority level
+    // (GPU_MAX_HW_QUEUES = 4 each) and streams beyond a pool's size SHARE a queue, which serialises their kernels; the high-priority
+    // aux stream therefore never competes for a queue with the accumulate streams.
+    void ensure_pipeline_streams() {
+        if (aux_stream) return;
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // numerically lower = higher priority
+        HIP_TRY(hipStreamCreateWithFlags(&acc2_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithPriority(&aux_stream, hipStreamNonBlocking, hi));
+    }
     template <class Fn> void for_each_buf(Fn fn) {
-        for (DevBuf* b : {&raw, &call_bases, &call_flags, &scalars, &hist, &offsets, &woff, &meta, &sched, &sorted, &partial, &order, &item_bucket,
-                          &pairs, &pairs2, &tilecnt, &tileoff, &bin_tot, &bin_base, &binA_base, &coarse, &coarseA, &seg_cnt, &seg_base, &segcnt, &segoff, &merge_list, &merge_list2, &pr_p, &pr_q, &pr_lvl[0],
-                          &pr_lvl[1], &pr_raw, &pr_lines})
+        for (DevBuf* b : {&raw, &call_bases, &call_flags, &scalars, &pr_p, &pr_q, &pr_lvl[0], &pr_lvl[1], &pr_raw, &pr_lines, &io_in, &io_out, &io_status,
+                          &nv_vals, &nv_pref, &nv_inv, &nv_top})
             fn(*b);
+        for (Scratch& s : sc) s.for_each_buf(fn);
     }
 };
 
@@ -235,6 +267,9 @@ struct mi_ctx {
     bool lane_busy[mi::NLANES] = {false, false};
     mutable std::mutex info_mu;                                  // prof / err
     unsigned forced_c = 0;
+    // window groups of a pipelined call (run_msm): 0 entries = the built-in choice; {1} = never pipeline; otherwise relative weights of the
+    // groups, top windows first (mi_msm_set_pipeline / ARKBLST_AMD_PIPELINE)
+    std::vector<unsigned> pipe_weights;
     // base-set cache of the stateless call shape (api.hip mi_msm_set_base_cache); [0] = G1, [1] = G2
     std::mutex cache_mu;
     unsigned cache_entries = 0;       // 0 = off

@@ -209,6 +209,7 @@ __global__ void __launch_bounds__(64, CS::MAX_OCC) k_merge(uint32_t* __restrict_
                                                            const uint32_t* __restrict__ woff, const uint32_t* __restrict__ list_in,
                                                            const uint32_t* __restrict__ count_in, uint32_t* __restrict__ list_out,
                                                            uint32_t* __restrict__ count_out, uint32_t d) {
+    aux_priority();
     using Pt = typename CS::Pt;
     constexpr int NLL = 1 << CS::LOG_LL, BK = Geo<typename CS::C>::BK_WORDS;
     const uint32_t slot = blockIdx.x * NLL + CS::ll();
@@ -503,6 +504,7 @@ template <class CS>
 __global__ void __launch_bounds__(64, CS::MAX_OCC) k_reduce_coop(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ woff,
                                                                  const uint32_t* __restrict__ offsets, uint32_t* __restrict__ pairs, uint32_t L,
                                                                  uint32_t nb, uint32_t cpw) {
+    aux_priority();
     using Pt = typename CS::Pt;
     constexpr int NLL = 1 << CS::LOG_LL, BK = Geo<typename CS::C>::BK_WORDS;
     const uint32_t chunk = blockIdx.x, ll = CS::ll();
@@ -619,6 +621,7 @@ template <class C>
 __global__ void __launch_bounds__(64, 2) k_reduce_serial(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ woff,
                                                         const uint32_t* __restrict__ offsets, uint32_t nlanes, uint32_t L, uint32_t nb,
                                                         uint32_t lpw, uint32_t* __restrict__ pairs) {
+    aux_priority();
     using F = typename C::F;
     using FR = typename C::FR;
     using E = typename F::E;
@@ -724,6 +727,7 @@ __global__ void __launch_bounds__(64, 2) k_reduce_serial(const uint32_t* __restr
 template <class CS>
 __global__ void __launch_bounds__(64, CS::MAX_OCC) k_combine(const uint32_t* __restrict__ pairs_in, uint32_t cpw_in, uint32_t cpw_out,
                                                              uint32_t* __restrict__ pairs_out, uint32_t* __restrict__ jac_out) {
+    aux_priority();
     using Pt = typename CS::Pt;
     constexpr int NLL = 1 << CS::LOG_LL, BK = Geo<typename CS::C>::BK_WORDS, RJ = Geo<typename CS::C>::RAW_JAC;
     const uint32_t w = blockIdx.x / cpw_out, g = blockIdx.x % cpw_out, ll = CS::ll();

@@ -36,15 +36,19 @@ struct SortOut {
     size_t items_cap = 0;   // upper bound of nitems known before the schedule has run (sizes the accumulate launch and its output)
 };
 // scalars -> signed digits -> sorted (index | sign) entries, bucket offsets, work items, processing order.  Records
-// d.ev[ev0] .. d.ev[ev0 + 3] (start, coarse done, fine done, schedule done).  Only ENQUEUES: the item counts (d.meta on the device, copied to
-// d.h_meta before ev0 + 3) are read by read_schedule, which the caller runs after it has queued the accumulate kernel behind the
+// sc.ev[0] .. sc.ev[3] (start, coarse done, fine done, schedule done).  Only ENQUEUES: the item counts (sc.meta on the device, copied to
+// sc.h_meta before ev[3]) are read by read_schedule, which the caller runs after it has queued the accumulate kernel behind the
 // schedule — the host's wait for the counts then overlaps that kernel instead of leaving the device idle (round 4).
 // host_scalars != nullptr: the scalars are still in host memory.  They are copied into d_scalars (device scratch of n x 32 B) in
 // chunks of whole point tiles on the lane's copy stream, and the count pass of a chunk starts when that chunk has landed
 // (the trait's actual call shape: host slices, /root/reference/src/g1.rs:604,623, uploaded per call at src/gpu.rs:149-150).
-void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, const uint8_t* d_flags, size_t n, unsigned fmt, bool shared_buckets,
-                       size_t stride, int ev0, SortOut& out, const uint8_t* host_scalars = nullptr);
-void read_schedule(DevState& d, int ev0, SortOut& out);   // waits for d.ev[ev0 + 3], fills nitems / max_items / entries / nlist
+// under_accumulate: the launches will run beside an accumulate kernel (pipelined call): digit passes in 256-lane workgroups.
+// sc / s: the scratch set and the stream of this window group (a one-group call: d.sc[0], d.stream); pl.win0 / pl.nwin: its digit windows.
+void sort_and_schedule(DevState& d, Scratch& sc, hipStream_t s, const Plan& pl, const uint32_t* d_scalars, const uint8_t* d_flags, size_t n, unsigned fmt,
+                       bool shared_buckets, size_t stride, SortOut& out, const uint8_t* host_scalars = nullptr, bool under_accumulate = false);
+void read_schedule(Scratch& sc, SortOut& out);   // waits for sc.ev[3], fills nitems / max_items / entries / nlist
+// window groups of a pipelined call, top windows first ({pl} = one group: no pipelining)
+std::vector<Plan> split_plan(const Plan& pl, const CurveCost& cc, size_t n, bool shared, const std::vector<unsigned>& weights);
 
 // ---- msm_g1.hip / msm_g2.hip
 int g1_set_bases(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute_c);

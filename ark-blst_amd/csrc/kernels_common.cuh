@@ -225,6 +225,19 @@ __device__ __forceinline__ bool load_scalar(uint32_t (&s)[8], const uint32_t* sc
     return flip;
 }
 
+// Wave priority of the latency-bound kernels of the pipeline (sort, schedule, merge, reduce, combine).  In a pipelined call (run_msm,
+// msm_curve.hpp) they run UNDER an accumulate kernel whose two waves per SIMD keep the VALU issue port busy: at equal priority the arbiter
+// serves the older accumulate waves first and a sort kernel's handful of instructions wait behind thousands of multiply-adds (a 15-us
+// k_colscan took 355 us).  s_setprio 3 lets these short waves issue whenever they are ready; the accumulate waves stay at 0.
+#ifndef MI_AUX_PRIO
+#define MI_AUX_PRIO 3
+#endif
+__device__ __forceinline__ void aux_priority() {
+#if MI_AUX_PRIO
+    __builtin_amdgcn_s_setprio(MI_AUX_PRIO);
+#endif
+}
+
 constexpr uint32_t MERGE_FAN = 4;   // fan-in of one level of the merge of split buckets (k_merge, curve_kernels.cuh; the plan counts its levels)
 // the schedule's counters in device memory (words): [0] items, [1] max items of a bucket, [2] entries, [3] merge list length of level 0,
 // [4] split buckets, [8 + l] merge list length of level l >= 1

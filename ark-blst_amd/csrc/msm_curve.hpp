@@ -155,9 +155,20 @@ void launch_accumulate(hipStream_t s, const uint32_t* bases, const uint32_t* sor
 }
 
 // The pipeline on one device.  d_bases: device-form points (tables of `stride` points when shared); d_scalars: n x 32 B on device.
+//
+// A call is ONE window group on the lane's stream (small inputs, shared bucket sets), or — from 2^17 points on — up to MAX_GROUPS groups of
+// digit windows, top windows first, each with its own scratch set, PIPELINED over three streams of the lane:
+//     aux stream (high priority)   sort(0) sort(1) .. sort(G-1)  [acc(0) done] merge / reduce / combine(0)  [acc(1) done] reduce(1) ..
+//     lane stream                  [sort(0) done] accumulate(0)   [sort(2) done] accumulate(2)
+//     second accumulate stream     [sort(1) done] accumulate(1)   [sort(3) done] accumulate(3)
+// so that the sort of the later groups and the bucket reduction of the earlier ones — LDS-atomic / latency-chain work that leaves the
+// VALUs idle — run under an accumulate kernel, and the accumulate kernels of consecutive groups overlap at their ends (the waves of
+// group g + 1 take the slots the last, short items of group g give back).  What stays exposed is the sort of the first group, the
+// reduction of the last and a Horner tail of that group's windows only: the host folds the window sums of group g while the GPU still
+// works on g + 1.  The reference runs one launch and folds on the host (/root/reference/src/gpu.rs:172-209).
 template <class C>
 typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint8_t* d_flags, const uint32_t* d_scalars,
-                                 size_t n, unsigned fmt, bool shared, unsigned table_c, size_t stride, int ev0, bool fold, WinOut* wo = nullptr,
+                                 size_t n, unsigned fmt, bool shared, unsigned table_c, size_t stride, bool fold, WinOut* wo = nullptr,
                                  const uint8_t* host_scalars = nullptr) {
     using J = typename HostCurve<C>::J;
     using RS = typename msmk::CoopOf<C>::RS;   // lane scheme of the reduce kernel
@@ -165,102 +176,149 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     constexpr int BK = msmk::Geo<C>::BK_WORDS;
     Plan pl = make_plan(n, shared ? table_c : ctx->forced_c, HostCurve<C>::cost(), shared, stride, fold);
     if (pl.c == 0) throw HipFail{"window_bits not usable for this n (sort geometry)"};
+    const std::vector<Plan> groups = split_plan(pl, HostCurve<C>::cost(), n, shared, ctx->pipe_weights);
+    const size_t G = groups.size();
+    const bool piped = G > 1;
     d.prof.window_bits = pl.c;
     d.prof.num_windows = pl.nwin;
     d.prof.n = n;
-    d.pairs.ensure(pl.nchunks * 2 * BK * 4);
-    d.pairs2.ensure(((pl.nchunks >> CS::LOG_LL) + pl.bwin) * 2 * BK * 4 + (size_t)pl.bwin * jac_bytes<C>());
+    d.prof.window_groups = (uint32_t)G;
     d.ensure_host((size_t)pl.bwin * jac_bytes<C>());
 
-    SortOut so;
-    sort_and_schedule(d, pl, d_scalars, d_flags, n, fmt, shared, stride, ev0, so, host_scalars);
-
-    hipStream_t s = d.stream;
-    // the accumulate kernel is queued behind the schedule BEFORE the host learns the item count (only the merge launches need it):
-    // the read-back's latency is hidden behind the kernel instead of idling the device between the two
-    d.partial.ensure(so.items_cap * BK * 4);
-    launch_accumulate<C>(s, d_bases, (const uint32_t*)d.sorted.p, (const uint32_t*)d.offsets.p, (const uint32_t*)d.woff.p,
-                         (const uint32_t*)d.order.p, (const uint32_t*)d.item_bucket.p, so.items_cap, (const uint32_t*)d.meta.p, pl.logT | (pl.logS << 16),
-                         (uint32_t*)d.partial.p);
-    read_schedule(d, ev0, so);
-    const uint32_t nitems = so.nitems, max_items = so.max_items;
-    if (max_items > 1 && so.nlist) {
-        // the fan-in tree over the items of split buckets: one launch per level; level l reads list l and appends list l + 1 (device
-        // counters meta[3], meta[8 + l]); the grid is the host's bound of the list length: ceil(items / FAN^(l+1)) summed over the split buckets
-        uint32_t* meta = (uint32_t*)d.meta.p;
-        uint32_t* lists[2] = {(uint32_t*)d.merge_list.p, (uint32_t*)d.merge_list2.p};
-        uint64_t dd = 1, shrink = 1;
-        for (uint32_t l = 0; dd < max_items; l++, dd *= msmk::MERGE_FAN, shrink *= msmk::MERGE_FAN) {
-            if (8 + l + 1 >= msmk::MERGE_META) throw HipFail{"merge tree deeper than its counters"};
-            const uint64_t bound = std::min<uint64_t>(so.nlist, so.nlist / shrink + so.nsplit);
-            hipLaunchKernelGGL(msmk::k_merge<CS>, dim3((uint32_t)((bound + (1u << CS::LOG_LL) - 1) >> CS::LOG_LL)), dim3(64), 0, s, (uint32_t*)d.partial.p,
-                               (const uint32_t*)d.item_bucket.p, (const uint32_t*)d.woff.p, (const uint32_t*)lists[l & 1],
-                               (const uint32_t*)(l == 0 ? meta + 3 : meta + 8 + l), lists[(l + 1) & 1], meta + 8 + l + 1, (uint32_t)dd);
-        }
+    hipStream_t sS = d.stream, sAcc[2] = {d.stream, d.stream};
+    if (piped) {
+        d.ensure_pipeline_streams();
+        sS = d.aux_stream;
+        sAcc[1] = d.acc2_stream;
+        // the aux stream starts behind what the caller queued on the lane's stream (base conversion, a staged scalar shard)
+        HIP_TRY(hipEventRecord(d.ev[10], d.stream));
+        HIP_TRY(hipStreamWaitEvent(sS, d.ev[10], 0));
     }
     const bool phases = d.prof_level >= 2;   // see sort_and_schedule
-    if (d.prof_level >= 1) HIP_TRY(hipEventRecord(d.ev[ev0 + 4], s));
-    // bucket reduction: one wave per chunk of chunk_buckets buckets -> (K S, T) pairs; then the per-window combine, 2^LOG_LL pairs per
-    // wave and level, down to one Jacobian point per window
-    bool reduced = false;
-    if constexpr (std::is_same<C, msmk::G1C>::value) {   // the throughput form exists for G1 only (HostCurve<G2C>::cost() never asks for it)
-        if (pl.serial_reduce) {
-            hipLaunchKernelGGL(msmk::k_reduce_serial<C>, dim3((uint32_t)((pl.nchunks + 63) / 64)), dim3(64), 0, s, (const uint32_t*)d.partial.p,
-                               (const uint32_t*)d.woff.p, (const uint32_t*)d.offsets.p, (uint32_t)pl.nchunks, pl.serial_L, pl.nb, pl.chunks_per_win,
-                               (uint32_t*)d.pairs.p);
-            reduced = true;
+    std::vector<SortOut> so(G);
+    // ---- phase 1: every group's sort + schedule (aux stream, in group order) and, behind its schedule, its accumulate kernel.  The
+    // accumulate kernel is queued BEFORE the host learns the item count (only the merge launches need it): the read-back's latency is
+    // hidden behind the kernel instead of idling the device between the two
+    for (size_t g = 0; g < G; g++) {
+        Scratch& sc = d.sc[g];
+        const Plan& gp = groups[g];
+        sc.pairs.ensure(gp.nchunks * 2 * BK * 4);
+        sc.pairs2.ensure(((gp.nchunks >> CS::LOG_LL) + gp.bwin) * 2 * BK * 4 + (size_t)gp.bwin * jac_bytes<C>());
+        sort_and_schedule(d, sc, sS, gp, d_scalars, d_flags, n, fmt, shared, stride, so[g], g == 0 ? host_scalars : nullptr, piped && g > 0);
+        sc.partial.ensure(so[g].items_cap * BK * 4);
+        hipStream_t sa = sAcc[g & 1];
+        if (piped) HIP_TRY(hipStreamWaitEvent(sa, sc.ev[3], 0));
+        launch_accumulate<C>(sa, d_bases, (const uint32_t*)sc.sorted.p, (const uint32_t*)sc.offsets.p, (const uint32_t*)sc.woff.p,
+                             (const uint32_t*)sc.order.p, (const uint32_t*)sc.item_bucket.p, so[g].items_cap, (const uint32_t*)sc.meta.p, gp.logT | (gp.logS << 16),
+                             (uint32_t*)sc.partial.p);
+        if (piped) HIP_TRY(hipEventRecord(sc.ev[4], sa));
+    }
+    // ---- phase 2: per group, once its schedule's counts are on the host: merges of split buckets, bucket reduction, combine, window sums out
+    for (size_t g = 0; g < G; g++) {
+        Scratch& sc = d.sc[g];
+        const Plan& gp = groups[g];
+        read_schedule(sc, so[g]);
+        if (piped) HIP_TRY(hipStreamWaitEvent(sS, sc.ev[4], 0));
+        const uint32_t max_items = so[g].max_items;
+        if (max_items > 1 && so[g].nlist) {
+            // the fan-in tree over the items of split buckets: one launch per level; level l reads list l and appends list l + 1 (device
+            // counters meta[3], meta[8 + l]); the grid is the host's bound of the list length: ceil(items / FAN^(l+1)) summed over the split buckets
+            uint32_t* meta = (uint32_t*)sc.meta.p;
+            uint32_t* lists[2] = {(uint32_t*)sc.merge_list.p, (uint32_t*)sc.merge_list2.p};
+            uint64_t dd = 1, shrink = 1;
+            for (uint32_t l = 0; dd < max_items; l++, dd *= msmk::MERGE_FAN, shrink *= msmk::MERGE_FAN) {
+                if (8 + l + 1 >= msmk::MERGE_META) throw HipFail{"merge tree deeper than its counters"};
+                const uint64_t bound = std::min<uint64_t>(so[g].nlist, so[g].nlist / shrink + so[g].nsplit);
+                hipLaunchKernelGGL(msmk::k_merge<CS>, dim3((uint32_t)((bound + (1u << CS::LOG_LL) - 1) >> CS::LOG_LL)), dim3(64), 0, sS, (uint32_t*)sc.partial.p,
+                                   (const uint32_t*)sc.item_bucket.p, (const uint32_t*)sc.woff.p, (const uint32_t*)lists[l & 1],
+                                   (const uint32_t*)(l == 0 ? meta + 3 : meta + 8 + l), lists[(l + 1) & 1], meta + 8 + l + 1, (uint32_t)dd);
+            }
         }
-    }
-    if (!reduced) {
-        if (pl.serial_reduce) throw HipFail{"serial reduce requested for a curve without it"};
-        hipLaunchKernelGGL(msmk::k_reduce_coop<RS>, dim3((uint32_t)pl.nchunks), dim3(64), 0, s, (const uint32_t*)d.partial.p,
-                           (const uint32_t*)d.woff.p, (const uint32_t*)d.offsets.p, (uint32_t*)d.pairs.p, pl.coop_L, pl.nb, pl.chunks_per_win);
-    }
-    if (phases) HIP_TRY(hipEventRecord(d.ev[ev0 + 5], s));
-    uint32_t* jac_dev = (uint32_t*)((char*)d.pairs2.p + d.pairs2.cap - (size_t)pl.bwin * jac_bytes<C>());
-    {
-        uint32_t cpw = pl.chunks_per_win;
-        uint32_t* in = (uint32_t*)d.pairs.p;
-        uint32_t* out = (uint32_t*)d.pairs2.p;
-        for (;;) {
-            uint32_t cpw_out = (cpw + (1u << CS::LOG_LL) - 1) >> CS::LOG_LL;
-            const bool last = cpw_out == 1;
-            hipLaunchKernelGGL(msmk::k_combine<CS>, dim3(pl.bwin * cpw_out), dim3(64), 0, s, (const uint32_t*)in, cpw, cpw_out, out,
-                               last ? jac_dev : (uint32_t*)nullptr);
-            if (last) break;
-            std::swap(in, out);   // the levels shrink by 2^LOG_LL: ping-pong between the two pair buffers
-            cpw = cpw_out;
+        if (!piped && d.prof_level >= 1) HIP_TRY(hipEventRecord(sc.ev[4], sS));   // one group: the interval covers the merges as well
+        // bucket reduction: one wave per chunk of chunk_buckets buckets -> (K S, T) pairs; then the per-window combine, 2^LOG_LL pairs per
+        // wave and level, down to one Jacobian point per window
+        bool reduced = false;
+        if constexpr (std::is_same<C, msmk::G1C>::value) {   // the throughput form exists for G1 only (HostCurve<G2C>::cost() never asks for it)
+            if (gp.serial_reduce) {
+                hipLaunchKernelGGL(msmk::k_reduce_serial<C>, dim3((uint32_t)((gp.nchunks + 63) / 64)), dim3(64), 0, sS, (const uint32_t*)sc.partial.p,
+                                   (const uint32_t*)sc.woff.p, (const uint32_t*)sc.offsets.p, (uint32_t)gp.nchunks, gp.serial_L, gp.nb, gp.chunks_per_win,
+                                   (uint32_t*)sc.pairs.p);
+                reduced = true;
+            }
         }
+        if (!reduced) {
+            if (gp.serial_reduce) throw HipFail{"serial reduce requested for a curve without it"};
+            hipLaunchKernelGGL(msmk::k_reduce_coop<RS>, dim3((uint32_t)gp.nchunks), dim3(64), 0, sS, (const uint32_t*)sc.partial.p,
+                               (const uint32_t*)sc.woff.p, (const uint32_t*)sc.offsets.p, (uint32_t*)sc.pairs.p, gp.coop_L, gp.nb, gp.chunks_per_win);
+        }
+        if (phases) HIP_TRY(hipEventRecord(sc.ev[5], sS));
+        uint32_t* jac_dev = (uint32_t*)((char*)sc.pairs2.p + sc.pairs2.cap - (size_t)gp.bwin * jac_bytes<C>());
+        {
+            uint32_t cpw = gp.chunks_per_win;
+            uint32_t* in = (uint32_t*)sc.pairs.p;
+            uint32_t* out = (uint32_t*)sc.pairs2.p;
+            for (;;) {
+                uint32_t cpw_out = (cpw + (1u << CS::LOG_LL) - 1) >> CS::LOG_LL;
+                const bool last = cpw_out == 1;
+                hipLaunchKernelGGL(msmk::k_combine<CS>, dim3(gp.bwin * cpw_out), dim3(64), 0, sS, (const uint32_t*)in, cpw, cpw_out, out,
+                                   last ? jac_dev : (uint32_t*)nullptr);
+                if (last) break;
+                std::swap(in, out);   // the levels shrink by 2^LOG_LL: ping-pong between the two pair buffers
+                cpw = cpw_out;
+            }
+        }
+        if (phases) HIP_TRY(hipEventRecord(sc.ev[6], sS));
+        // window sums of the group, in their place among the call's windows (window 0 first; shared bucket sets: the one sum)
+        const size_t at = shared ? 0 : (size_t)gp.win0 * jac_bytes<C>();
+        if (wo)   // ... they stay on the device (the caller exchanges them: mi_msm_g1_device_windows); no fold here
+            HIP_TRY(hipMemcpyAsync((char*)wo->d_out + at, jac_dev, (size_t)gp.bwin * jac_bytes<C>(), hipMemcpyDeviceToDevice, sS));
+        else
+            HIP_TRY(hipMemcpyAsync((char*)d.h_pairs + at, jac_dev, (size_t)gp.bwin * jac_bytes<C>(), hipMemcpyDeviceToHost, sS));
+        if (phases || piped) HIP_TRY(hipEventRecord(sc.ev[7], sS));
     }
-    if (phases) HIP_TRY(hipEventRecord(d.ev[ev0 + 6], s));
-    if (wo) {   // the window sums stay on the device (the caller exchanges them: mi_msm_g1_device_windows); no fold here
-        HIP_TRY(hipMemcpyAsync(wo->d_out, jac_dev, (size_t)pl.bwin * jac_bytes<C>(), hipMemcpyDeviceToDevice, s));
+    if (wo) {
         wo->info.window_bits = pl.c;
         wo->info.num_windows = pl.bwin;
-    } else {
-        HIP_TRY(hipMemcpyAsync(d.h_pairs, jac_dev, (size_t)pl.bwin * jac_bytes<C>(), hipMemcpyDeviceToHost, s));
     }
-    if (phases) HIP_TRY(hipEventRecord(d.ev[ev0 + 7], s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // ---- phase 3: the host tail.  Horner fold over the window sums (top window first), group by group as they arrive
+    J r = J::inf();
+    double fold_ms = 0;
+    const J* win = static_cast<const J*>(d.h_pairs);   // pinned bytes the D2H copies write
+    for (size_t g = 0; g < G; g++) {
+        const Plan& gp = groups[g];
+        if (piped) HIP_TRY(hipEventSynchronize(d.sc[g].ev[7]));
+        else HIP_TRY(hipStreamSynchronize(sS));
+        if (wo) continue;
+        auto t0 = std::chrono::steady_clock::now();
+        for (int w = (int)(gp.win0 + gp.bwin) - 1; w >= (int)gp.win0; w--) r = r.dbl_n(pl.c).add(win[w]);
+        fold_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
     HIP_TRY(hipGetLastError());
 
-    if (phases) {
-        d.prof.digits_ms += ev_ms(d.ev[ev0], d.ev[ev0 + 1]);      // digits + coarse partition (4 kernels)
-        d.prof.scatter_ms += ev_ms(d.ev[ev0 + 1], d.ev[ev0 + 2]);  // fine sort in LDS
-        d.prof.scan_ms += ev_ms(d.ev[ev0 + 2], d.ev[ev0 + 3]);     // schedule (3 kernels)
-        d.prof.reduce_ms += ev_ms(d.ev[ev0 + 4], d.ev[ev0 + 5]);
-        d.prof.combine_ms += ev_ms(d.ev[ev0 + 5], d.ev[ev0 + 6]);
-        d.prof.d2h_ms += ev_ms(d.ev[ev0 + 6], d.ev[ev0 + 7]);
+    for (size_t g = 0; g < G; g++) {
+        Scratch& sc = d.sc[g];
+        if (phases) {
+            d.prof.digits_ms += ev_ms(sc.ev[0], sc.ev[1]);      // digits + coarse partition (4 kernels)
+            d.prof.scatter_ms += ev_ms(sc.ev[1], sc.ev[2]);     // fine sort in LDS
+            d.prof.scan_ms += ev_ms(sc.ev[2], sc.ev[3]);        // schedule (3 kernels)
+            d.prof.reduce_ms += ev_ms(sc.ev[4], sc.ev[5]);   // pipelined: from the end of the group's accumulate kernel, waits behind earlier groups included
+            d.prof.combine_ms += ev_ms(sc.ev[5], sc.ev[6]);
+            d.prof.d2h_ms += ev_ms(sc.ev[6], sc.ev[7]);
+        }
+        d.prof.accumulate_adds += so[g].entries;
+        d.prof.work_items += so[g].nitems;
+        d.prof.max_items_per_bucket = std::max(d.prof.max_items_per_bucket, so[g].max_items);
     }
-    if (d.prof_level >= 1) d.prof.accumulate_ms += ev_ms(d.ev[ev0 + 3], d.ev[ev0 + 4]);   // the accumulate kernel and the merges of split buckets
-    d.prof.accumulate_adds += so.entries;
-    d.prof.work_items = nitems;
-    d.prof.max_items_per_bucket = max_items;
-
-    if (wo) return J::inf();
-    auto t0 = std::chrono::steady_clock::now();
-    J r = horner<J>(static_cast<const J*>(d.h_pairs), pl);   // pinned bytes the D2H copy just wrote
-    d.prof.host_fold_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    // the accumulate kernel(s): one group = the kernel and the merges of split buckets; pipelined = from the first group's schedule (its
+    // accumulate kernel starts there) to the end of the LAST accumulate kernel to finish — the launches overlap, their sum would count twice
+    if (piped) {
+        double span = 0;
+        for (size_t g = 0; g < G; g++) span = std::max(span, ev_ms(d.sc[0].ev[3], d.sc[g].ev[4]));
+        d.prof.accumulate_ms += span;
+    } else if (d.prof_level >= 1) {
+        d.prof.accumulate_ms += ev_ms(d.sc[0].ev[3], d.sc[0].ev[4]);
+    }
+    d.prof.host_fold_ms += fold_ms;
     return r;
 }
 
@@ -298,6 +356,8 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
             if (std::uncaught_exceptions() > live) {
                 (void)hipStreamSynchronize(d.copy_stream);
                 (void)hipStreamSynchronize(d.stream);
+                if (d.acc2_stream) (void)hipStreamSynchronize(d.acc2_stream);   // a pipelined call has work on all of them
+                if (d.aux_stream) (void)hipStreamSynchronize(d.aux_stream);
                 (void)hipGetLastError();
             }
         }
@@ -350,7 +410,7 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
         }
         // sign fold (one window fewer at c = 15 / 17) only over a resident set whose every point passed the subgroup check on this
         // context; bases handed over with the call are multiplied by the integer s, as the reference does (src/g1.rs:614-617)
-        J r = run_msm<C>(ctx, d, d_bases, d_flags, d_scalars, m, fmt, shared, res.table_c, res.n, 2, !bases && res.validated, wo, host_scalars);
+        J r = run_msm<C>(ctx, d, d_bases, d_flags, d_scalars, m, fmt, shared, res.table_c, res.n, !bases && res.validated, wo, host_scalars);
         total = lo == 0 ? r : total.add(r);
         // h2d_ms: bases (their chunks interleave with k_ingest on the main stream) + scalars (copy stream, first to last chunk; the
         // sort's count pass runs underneath, so digits_ms of a host-scalar call includes waiting for the chunks)

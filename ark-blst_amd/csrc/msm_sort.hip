@@ -6,6 +6,61 @@
 
 namespace mi {
 
+namespace {
+struct ReduceCost { double coop_steps = 0, coop_rounds = 0, serial_steps = 0, serial_rounds = 0; };
+
+// Reduce geometry of a plan whose c, nb, bwin and nbuckets are set (a whole call, or one window group of a pipelined call: fewer bucket
+// windows, hence fewer buckets per logical lane and a shorter latency chain).  false: c is too small for the reduce's lane scheme.
+bool reduce_geometry(Plan& p, const CurveCost& cc, ReduceCost& rc) {
+    const uint32_t c = p.c;
+    // L buckets per logical lane, ANY value up to 64 (round 4; a power of two before): the L that costs the fewest
+    // (rounds of max_chunks wave slots) x (steps of the wave's latency chain).  2^16 points at c = 15 (17 windows of 2^14 buckets):
+    // L = 9, 1938 waves of 31 steps; the power-of-two geometry needed L = 16 (L = 8 gives 2176 waves, a second round) and 45 steps.
+    const uint32_t log_ll = (uint32_t)cc.log_ll;
+    if (c - 1 < log_ll) return false;
+    {
+        double best = 1e300;
+        const uint32_t max_L = std::min<uint32_t>(64, std::max<uint32_t>(1, p.nb >> log_ll));
+        for (uint32_t L = 1; L <= max_L; L++) {
+            const uint64_t chunks = (uint64_t)((p.nb + (L << log_ll) - 1) / (L << log_ll)) * p.bwin;
+            const double rounds = (double)((chunks + cc.max_chunks - 1) / cc.max_chunks);
+            uint32_t bits = 0, ones = 0;
+            for (uint32_t v = L; v; v >>= 1) { bits++; ones += v & 1u; }
+            const double steps = 2.0 * L + 2.0 * log_ll + (bits - 1) + (ones - 1) + 1.0;
+            if (rounds * steps < best) { best = rounds * steps; p.coop_L = L; rc.coop_steps = steps; rc.coop_rounds = rounds; }
+        }
+    }
+    p.chunk_buckets = p.coop_L << log_ll;
+    p.serial_reduce = cc.serial_buckets != 0 && p.nbuckets >= cc.serial_buckets && c - 1 >= 6;
+    uint32_t serial_L_lo = 8, serial_L_hi = 64;
+#if defined(MI_TEST_HOOKS)
+    // experiment switches of the test build (tools/sweep_sizes.py --test-hooks): force the single-lane reduce from a bucket count on, pin its L
+    if (const char* e = getenv("MI_TEST_SERIAL_MIN_BUCKETS")) p.serial_reduce = cc.serial_buckets != 0 && p.nbuckets >= (uint64_t)atoll(e) && c - 1 >= 6;
+    if (const char* e = getenv("MI_TEST_SERIAL_L")) serial_L_lo = serial_L_hi = (uint32_t)std::min(64, std::max(1, atoi(e)));
+#endif
+    p.chunks_per_win = (p.nb + p.chunk_buckets - 1) / p.chunk_buckets;
+    p.serial_L = 0;
+    if (p.serial_reduce) {
+        // one lane per L consecutive buckets of a window, L <= 64 and NOT necessarily a power of two: the L that costs the fewest
+        // (rounds of wave slots) x (2 L running-sum steps + the double-and-add chain that turns S into L S).  2^24 points at c = 20:
+        // L = 53 fills 2010 of the 2048 slots with 114 steps, where L = 64 left 1664 waves walking 134 (3.0 -> 2.6 ms).
+        double best = 1e300;
+        for (uint32_t L = serial_L_lo; L <= serial_L_hi; L++) {
+            const uint64_t lanes = (uint64_t)((p.nb + L - 1) / L) * p.bwin;
+            const double rounds = std::ceil(std::ceil((double)lanes / 64.0) / (double)cc.max_chunks);
+            uint32_t bits = 0, ones = 0;
+            for (uint32_t v = L; v; v >>= 1) { bits++; ones += v & 1u; }
+            const double steps = 2.0 * L + (bits - 1) + (ones - 1);
+            if (rounds * steps < best) { best = rounds * steps; p.serial_L = L; rc.serial_steps = steps; rc.serial_rounds = rounds; }
+        }
+        p.chunk_buckets = p.serial_L; p.coop_L = 0;
+        p.chunks_per_win = (p.nb + p.serial_L - 1) / p.serial_L;
+    }
+    p.nchunks = (uint64_t)p.chunks_per_win * p.bwin;
+    return true;
+}
+}  // namespace
+
 // Window size c by a time model of the pipeline on one MI355X (microseconds; constants measured, see DESIGN_HISTORY.md §8):
 //   accumulate  max(throughput: N W mixed additions at cc.add_per_us,  latency: one lane walks an item of T entries)
 //   merge       one launch per binary-tree level when the short top window overfills its buckets
@@ -18,6 +73,7 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         if (forced_c && c != forced_c) continue;
         Plan p{};
         p.c = c;
+        p.win0 = 0;
         p.fold = fold;
         p.nwin = num_windows(c, fold);
         // sort geometry: lo bits share a 32-bit entry with the point index and the sign; the coarse bins of one
@@ -33,51 +89,9 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
         p.nb = 1u << (c - 1);
         p.bwin = shared ? 1 : p.nwin;
         p.nbuckets = (uint64_t)p.nb * p.bwin;
-        // reduce geometry: L buckets per logical lane, ANY value up to 64 (round 4; a power of two before): the L that costs the fewest
-        // (rounds of max_chunks wave slots) x (steps of the wave's latency chain).  2^16 points at c = 15 (17 windows of 2^14 buckets):
-        // L = 9, 1938 waves of 31 steps; the power-of-two geometry needed L = 16 (L = 8 gives 2176 waves, a second round) and 45 steps.
-        const uint32_t log_ll = (uint32_t)cc.log_ll;
-        if (c - 1 < log_ll) continue;
-        double coop_steps = 0, coop_rounds = 0;
-        {
-            double best = 1e300;
-            const uint32_t max_L = std::min<uint32_t>(64, std::max<uint32_t>(1, p.nb >> log_ll));
-            for (uint32_t L = 1; L <= max_L; L++) {
-                const uint64_t chunks = (uint64_t)((p.nb + (L << log_ll) - 1) / (L << log_ll)) * p.bwin;
-                const double rounds = (double)((chunks + cc.max_chunks - 1) / cc.max_chunks);
-                uint32_t bits = 0, ones = 0;
-                for (uint32_t v = L; v; v >>= 1) { bits++; ones += v & 1u; }
-                const double steps = 2.0 * L + 2.0 * log_ll + (bits - 1) + (ones - 1) + 1.0;
-                if (rounds * steps < best) { best = rounds * steps; p.coop_L = L; coop_steps = steps; coop_rounds = rounds; }
-            }
-        }
-        p.chunk_buckets = p.coop_L << log_ll;
-        p.serial_reduce = cc.serial_buckets != 0 && p.nbuckets >= cc.serial_buckets && c - 1 >= 6;
-        uint32_t serial_L_lo = 8, serial_L_hi = 64;
-#if defined(MI_TEST_HOOKS)
-        // experiment switches of the test build (tools/sweep_sizes.py --test-hooks): force the single-lane reduce from a bucket count on, pin its L
-        if (const char* e = getenv("MI_TEST_SERIAL_MIN_BUCKETS")) p.serial_reduce = cc.serial_buckets != 0 && p.nbuckets >= (uint64_t)atoll(e) && c - 1 >= 6;
-        if (const char* e = getenv("MI_TEST_SERIAL_L")) serial_L_lo = serial_L_hi = (uint32_t)std::min(64, std::max(1, atoi(e)));
-#endif
-        p.chunks_per_win = (p.nb + p.chunk_buckets - 1) / p.chunk_buckets;
-        double serial_steps = 0, serial_rounds = 0;
-        if (p.serial_reduce) {
-            // one lane per L consecutive buckets of a window, L <= 64 and NOT necessarily a power of two: the L that costs the fewest
-            // (rounds of wave slots) x (2 L running-sum steps + the double-and-add chain that turns S into L S).  2^24 points at c = 20:
-            // L = 53 fills 2010 of the 2048 slots with 114 steps, where L = 64 left 1664 waves walking 134 (3.0 -> 2.6 ms).
-            double best = 1e300;
-            for (uint32_t L = serial_L_lo; L <= serial_L_hi; L++) {
-                const uint64_t lanes = (uint64_t)((p.nb + L - 1) / L) * p.bwin;
-                const double rounds = std::ceil(std::ceil((double)lanes / 64.0) / (double)cc.max_chunks);
-                uint32_t bits = 0, ones = 0;
-                for (uint32_t v = L; v; v >>= 1) { bits++; ones += v & 1u; }
-                const double steps = 2.0 * L + (bits - 1) + (ones - 1);
-                if (rounds * steps < best) { best = rounds * steps; p.serial_L = L; serial_steps = steps; serial_rounds = rounds; }
-            }
-            p.chunk_buckets = p.serial_L; p.coop_L = 0;
-            p.chunks_per_win = (p.nb + p.serial_L - 1) / p.serial_L;
-        }
-        p.nchunks = (uint64_t)p.chunks_per_win * p.bwin;
+        ReduceCost rc;
+        if (!reduce_geometry(p, cc, rc)) continue;
+        const double coop_steps = rc.coop_steps, coop_rounds = rc.coop_rounds, serial_steps = rc.serial_steps, serial_rounds = rc.serial_rounds;
         // The top window holds only 254 (fold) or 255 - c (nwin - 1) significant bits (0: the carry-only window of c = 15 / 17 without the fold): its n entries share 2^top_bits buckets (on top of the
         // others' entries when all windows share one bucket set)
         const double entries = (double)n * p.nwin;
@@ -151,6 +165,56 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
     return best;
 }
 
+// Window groups of a pipelined call (run_msm), TOP windows first: group plans share c, the item geometry (logT / logS / class width) and
+// the sort's bit split with the whole-call plan `pl`; each has its own bucket windows and reduce geometry.  weights: relative sizes of the
+// groups (empty = the built-in choice, {1} = one group); a weight list longer than the window count is cut.
+std::vector<Plan> split_plan(const Plan& pl, const CurveCost& cc, size_t n, bool shared, const std::vector<unsigned>& weights) {
+    std::vector<unsigned> w = weights;
+    if (w.empty()) {
+        // built-in: one group until the overlap pays on this hardware (measurements: DESIGN.md)
+        w = {1};
+    }
+    if (w.size() > (size_t)MAX_GROUPS) w.resize(MAX_GROUPS);
+    if (w.size() > pl.nwin) w.resize(pl.nwin);
+    if (shared || w.size() <= 1 || pl.bwin != pl.nwin) return {pl};
+    // window counts by largest remainder, at least one window per group
+    const size_t G = w.size();
+    uint64_t sum = 0;
+    for (unsigned& x : w) { x = std::max(1u, x); sum += x; }
+    std::vector<uint32_t> cnt(G);
+    std::vector<double> frac(G);
+    uint32_t used = 0;
+    for (size_t g = 0; g < G; g++) {
+        const double exact = (double)pl.nwin * w[g] / (double)sum;
+        cnt[g] = std::max<uint32_t>(1, (uint32_t)exact);
+        frac[g] = exact - (double)cnt[g];
+        used += cnt[g];
+    }
+    while (used < pl.nwin) {
+        size_t b = 0;
+        for (size_t g = 1; g < G; g++) if (frac[g] > frac[b]) b = g;
+        cnt[b]++; frac[b] -= 1.0; used++;
+    }
+    while (used > pl.nwin) {
+        size_t b = 0;
+        for (size_t g = 1; g < G; g++) if (cnt[g] > cnt[b]) b = g;
+        cnt[b]--; used--;
+    }
+    std::vector<Plan> out;
+    uint32_t top = pl.nwin;
+    for (size_t g = 0; g < G; g++) {
+        Plan p = pl;
+        p.nwin = p.bwin = cnt[g];
+        top -= cnt[g];
+        p.win0 = top;
+        p.nbuckets = (uint64_t)p.nb * p.bwin;
+        ReduceCost rc;
+        if (!reduce_geometry(p, cc, rc)) return {pl};
+        out.push_back(p);
+    }
+    return out;
+}
+
 namespace {
 
 // k_coarse is compiled per window size (static digit extraction): dispatch on c = 7..22
@@ -168,15 +232,15 @@ void launch_coarse(uint32_t c, dim3 grid, dim3 block, hipStream_t s, const uint3
 }
 // level A of the three-level sort (c = 17..22)
 template <bool SCATTER, int CB = 17>
-void launch_coarseA(uint32_t c, dim3 grid, hipStream_t s, const uint32_t* scalars, const uint8_t* flags, const msmk::SortGeom& g,
+void launch_coarseA(uint32_t c, dim3 grid, dim3 block, hipStream_t s, const uint32_t* scalars, const uint8_t* flags, const msmk::SortGeom& g,
                     uint32_t* tilecnt, const uint32_t* tileoff, const uint32_t* binA_base, uint2* coarseA) {
     if constexpr (CB > 22) {
         throw HipFail{"three-level sort: window_bits out of range"};
     } else {
         if (c == CB)
-            hipLaunchKernelGGL((msmk::k_coarseA<SCATTER, CB>), grid, dim3(1024), 0, s, scalars, flags, g, tilecnt, tileoff, binA_base, coarseA);
+            hipLaunchKernelGGL((msmk::k_coarseA<SCATTER, CB>), grid, block, 0, s, scalars, flags, g, tilecnt, tileoff, binA_base, coarseA);
         else
-            launch_coarseA<SCATTER, CB + 1>(c, grid, s, scalars, flags, g, tilecnt, tileoff, binA_base, coarseA);
+            launch_coarseA<SCATTER, CB + 1>(c, grid, block, s, scalars, flags, g, tilecnt, tileoff, binA_base, coarseA);
     }
 }
 // the LDS-staged scatter exists for the window sizes whose coarse bins allow it (H <= 128: c <= 16)
@@ -187,7 +251,7 @@ void launch_coarse_staged(uint32_t c, dim3 grid, hipStream_t s, const uint32_t* 
         throw HipFail{"staged coarse scatter: window_bits out of range"};
     } else {
         if (c == CB)
-            hipLaunchKernelGGL((msmk::k_coarse_staged<CB>), grid, dim3(512), 0, s, scalars, flags, g, tilecnt, tileoff, bin_base, coarse);
+            hipLaunchKernelGGL((msmk::k_coarse_staged<CB>), grid, dim3(256), 0, s, scalars, flags, g, tilecnt, tileoff, bin_base, coarse);
         else
             launch_coarse_staged<CB + 1>(c, grid, s, scalars, flags, g, tilecnt, tileoff, bin_base, coarse);
     }
@@ -195,20 +259,23 @@ void launch_coarse_staged(uint32_t c, dim3 grid, hipStream_t s, const uint32_t* 
 
 }  // namespace
 
-void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, const uint8_t* d_flags, size_t n, unsigned fmt, bool shared_buckets,
-                       size_t stride, int ev0, SortOut& out, const uint8_t* host_scalars) {
+void sort_and_schedule(DevState& d, Scratch& sc, hipStream_t s, const Plan& pl, const uint32_t* d_scalars, const uint8_t* d_flags, size_t n, unsigned fmt,
+                       bool shared_buckets, size_t stride, SortOut& out, const uint8_t* host_scalars, bool under_accumulate) {
+    // Workgroups of a pipelined call's sort must find room BESIDE the two resident waves of an accumulate kernel (2 x 216 of a SIMD's 512
+    // registers per lane: 80 are left): 256 lanes = one wave per SIMD of <= 80 registers does, the 1024-lane blocks of the digit passes
+    // (4 x 56) would wait until a whole compute unit drains — which an accumulate kernel with queued waves never lets happen
+    const dim3 digit_block_big(under_accumulate ? 256 : 1024);
     const size_t entries_cap = (size_t)n * pl.nwin;
-    d.hist.ensure(pl.nbuckets * 4);
-    d.offsets.ensure((pl.nbuckets + 1) * 4);
-    d.woff.ensure((pl.nbuckets + 1) * 4);
-    d.meta.ensure(msmk::MERGE_META * 4);
-    d.sorted.ensure(entries_cap * 4);
-    if (!d.h_meta) HIP_TRY(hipHostMalloc((void**)&d.h_meta, 32, hipHostMallocDefault));
+    sc.hist.ensure(pl.nbuckets * 4);
+    sc.offsets.ensure((pl.nbuckets + 1) * 4);
+    sc.woff.ensure((pl.nbuckets + 1) * 4);
+    sc.meta.ensure(msmk::MERGE_META * 4);
+    sc.sorted.ensure(entries_cap * 4);
+    if (!sc.h_meta) HIP_TRY(hipHostMalloc((void**)&sc.h_meta, 32, hipHostMallocDefault));
 
-    hipStream_t s = d.stream;
     // phase events only on request (profile level 2): each record leaves the device idle for ~6 us between two kernels
     const bool phases = d.prof_level >= 2;
-    if (phases) HIP_TRY(hipEventRecord(d.ev[ev0], s));
+    if (phases) HIP_TRY(hipEventRecord(sc.ev[0], s));
     // ---- two-level LDS-staged bucket sort (geometry in msmk::SortGeom)
     // The count pass, per chunk of tiles: with host scalars chunk j is copied on the copy stream and counted as soon as it has
     // landed, while chunk j + 1 is still crossing PCIe; device-resident scalars are one chunk.
@@ -234,14 +301,14 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
         }
     };
     msmk::SortGeom g{};
-    g.n = (uint32_t)n; g.fmt = fmt | (pl.fold ? 2u : 0u); g.c = pl.c; g.nwin = pl.nwin;
+    g.n = (uint32_t)n; g.fmt = fmt | (pl.fold ? 2u : 0u); g.c = pl.c; g.nwin = pl.nwin; g.win0 = pl.win0;
     g.shared = shared_buckets ? 1u : 0u;
     g.stride = (uint32_t)stride;
     g.lo_bits = pl.lo_bits;
     g.H = pl.nb >> g.lo_bits;
     g.nbins = pl.bwin * g.H;
-    d.bin_base.ensure((size_t)(g.nbins + 1) * 4);
-    d.coarse.ensure(entries_cap * 4);
+    sc.bin_base.ensure((size_t)(g.nbins + 1) * 4);
+    sc.coarse.ensure(entries_cap * 4);
     // fine-level scratch (upper bound on the segment count: one per bin plus one per FINE_SEG entries); sized here, with the needs of
     // level B below, so that no buffer grows between two launches of a call
     const uint32_t segs_cap = g.nbins + (uint32_t)(entries_cap / msmk::FINE_SEG) + 1;
@@ -254,10 +321,10 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
             seg_words = std::max(seg_words, segs_capA << ((pl.c - 1 - msmk::A_BITS) - pl.lo_bits));
             bins = std::max<size_t>(bins, nbinsA);
         }
-        d.seg_cnt.ensure(bins * 4);
-        d.seg_base.ensure((bins + 1) * 4);
-        d.segcnt.ensure(seg_words * 4);
-        d.segoff.ensure(seg_words * 4);
+        sc.seg_cnt.ensure(bins * 4);
+        sc.seg_base.ensure((bins + 1) * 4);
+        sc.segcnt.ensure(seg_words * 4);
+        sc.segoff.ensure(seg_words * 4);
     }
     if (three_level) {
         // ---- c >= 17: level A (window, top 5 bits: all windows in one pass, 8-byte entries), level B (LDS-staged split by the next
@@ -269,30 +336,30 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
         g.tile_pts = (uint32_t)std::min<size_t>(8192, (n + 1023) / 1024 * 1024);
         g.tiles = (uint32_t)((n + g.tile_pts - 1) / g.tile_pts);
         const uint32_t segs_capA = nbinsA + (uint32_t)(entries_cap / msmk::FINE_SEG) + 1;
-        d.tilecnt.ensure((size_t)g.tiles * nbinsA * 4);
-        d.tileoff.ensure((size_t)g.tiles * nbinsA * 4);
-        d.bin_tot.ensure((size_t)nbinsA * 4);
-        d.binA_base.ensure((size_t)(nbinsA + 1) * 4);
-        d.coarseA.ensure(entries_cap * 8);
+        sc.tilecnt.ensure((size_t)g.tiles * nbinsA * 4);
+        sc.tileoff.ensure((size_t)g.tiles * nbinsA * 4);
+        sc.bin_tot.ensure((size_t)nbinsA * 4);
+        sc.binA_base.ensure((size_t)(nbinsA + 1) * 4);
+        sc.coarseA.ensure(entries_cap * 8);
         feed_and_count(g, [&](uint32_t ntiles) {
-            launch_coarseA<false>(pl.c, dim3(ntiles), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p, (const uint32_t*)nullptr,
+            launch_coarseA<false>(pl.c, dim3(ntiles), digit_block_big, s, d_scalars, d_flags, g, (uint32_t*)sc.tilecnt.p, (const uint32_t*)nullptr,
                                   (const uint32_t*)nullptr, (uint2*)nullptr);
         });
-        hipLaunchKernelGGL(msmk::k_colscan, dim3((nbinsA + 255) / 256), dim3(256), 0, s, (const uint32_t*)d.tilecnt.p, nbinsA, g.tiles,
-                           (uint32_t*)d.tileoff.p, (uint32_t*)d.bin_tot.p);
-        hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.bin_tot.p, nbinsA, (uint32_t*)d.binA_base.p);
-        launch_coarseA<true>(pl.c, dim3(g.tiles), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p, (const uint32_t*)d.tileoff.p,
-                             (const uint32_t*)d.binA_base.p, (uint2*)d.coarseA.p);
-        hipLaunchKernelGGL(msmk::k_seg_count, dim3((nbinsA + 255) / 256), dim3(256), 0, s, (const uint32_t*)d.binA_base.p, nbinsA,
-                           (uint32_t*)d.seg_cnt.p);
-        hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.seg_cnt.p, nbinsA, (uint32_t*)d.seg_base.p);
-        hipLaunchKernelGGL(msmk::k_mid_count, dim3(segs_capA), dim3(256), 0, s, (const uint2*)d.coarseA.p, (const uint32_t*)d.binA_base.p,
-                           (const uint32_t*)d.seg_base.p, nbinsA, pl.lo_bits, mid_bits, (uint32_t*)d.segcnt.p);
-        hipLaunchKernelGGL(msmk::k_mid_scan, dim3(nbinsA), dim3(512), 0, s, (const uint32_t*)d.binA_base.p, (const uint32_t*)d.seg_base.p, mid_bits,
-                           (const uint32_t*)d.segcnt.p, (uint32_t*)d.segoff.p, (uint32_t*)d.bin_base.p, nbinsA);
-        hipLaunchKernelGGL(msmk::k_mid_scatter, dim3(segs_capA), dim3(256), 0, s, (const uint2*)d.coarseA.p, (const uint32_t*)d.binA_base.p,
-                           (const uint32_t*)d.seg_base.p, nbinsA, pl.lo_bits, mid_bits, (const uint32_t*)d.segcnt.p, (const uint32_t*)d.segoff.p,
-                           (uint32_t*)d.coarse.p);
+        hipLaunchKernelGGL(msmk::k_colscan, dim3((nbinsA + 255) / 256), dim3(256), 0, s, (const uint32_t*)sc.tilecnt.p, nbinsA, g.tiles,
+                           (uint32_t*)sc.tileoff.p, (uint32_t*)sc.bin_tot.p);
+        hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)sc.bin_tot.p, nbinsA, (uint32_t*)sc.binA_base.p);
+        launch_coarseA<true>(pl.c, dim3(g.tiles), digit_block_big, s, d_scalars, d_flags, g, (uint32_t*)sc.tilecnt.p, (const uint32_t*)sc.tileoff.p,
+                             (const uint32_t*)sc.binA_base.p, (uint2*)sc.coarseA.p);
+        hipLaunchKernelGGL(msmk::k_seg_count, dim3((nbinsA + 255) / 256), dim3(256), 0, s, (const uint32_t*)sc.binA_base.p, nbinsA,
+                           (uint32_t*)sc.seg_cnt.p);
+        hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)sc.seg_cnt.p, nbinsA, (uint32_t*)sc.seg_base.p);
+        hipLaunchKernelGGL(msmk::k_mid_count, dim3(segs_capA), dim3(256), 0, s, (const uint2*)sc.coarseA.p, (const uint32_t*)sc.binA_base.p,
+                           (const uint32_t*)sc.seg_base.p, nbinsA, pl.lo_bits, mid_bits, (uint32_t*)sc.segcnt.p);
+        hipLaunchKernelGGL(msmk::k_mid_scan, dim3(nbinsA), dim3(512), 0, s, (const uint32_t*)sc.binA_base.p, (const uint32_t*)sc.seg_base.p, mid_bits,
+                           (const uint32_t*)sc.segcnt.p, (uint32_t*)sc.segoff.p, (uint32_t*)sc.bin_base.p, nbinsA);
+        hipLaunchKernelGGL(msmk::k_mid_scatter, dim3(segs_capA), dim3(256), 0, s, (const uint2*)sc.coarseA.p, (const uint32_t*)sc.binA_base.p,
+                           (const uint32_t*)sc.seg_base.p, nbinsA, pl.lo_bits, mid_bits, (const uint32_t*)sc.segcnt.p, (const uint32_t*)sc.segoff.p,
+                           (uint32_t*)sc.coarse.p);
     } else {
     // A tile contributes tile_pts / H entries to each coarse bin of a window, written as one contiguous run: keep
     // runs >= 64 entries (256 B) or the 4-byte scatter is write-amplified (9.5 ms at n = 2^24 with 16-entry runs).
@@ -301,85 +368,91 @@ void sort_and_schedule(DevState& d, const Plan& pl, const uint32_t* d_scalars, c
     const bool staged = !shared_buckets && g.H <= 128 && pl.c <= 16 && n >= 4096;
     uint32_t coarse_block;
     if (staged) {
-        g.wgroup = std::min<uint32_t>(std::min<uint32_t>(pl.nwin, 16), msmk::COARSE_STAGE_BINS / g.H);
+        // runs of (tile, bin): tile_pts / H entries.  Beside an accumulate kernel, whose gathers turn the L2 over several times per launch, a
+        // 32-entry run (128 B, two partial lines) is evicted before its neighbours complete the lines and reaches HBM as read-modify-writes
+        // (k_coarse_staged: 45 -> 430 us); fewer windows per workgroup keep the runs at >= 64 entries
+        uint32_t stage_bins = msmk::COARSE_STAGE_BINS;
+        if (under_accumulate) stage_bins = 256;
+        if (const char* e = getenv("MI_EXP_STAGE_BINS")) stage_bins = (uint32_t)atoi(e);
+        g.wgroup = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(pl.nwin, 16), stage_bins / g.H));
         g.tile_pts = (msmk::COARSE_STAGE / g.wgroup) / 512 * 512;   // >= 1024 points; tile_pts * wgroup entries fit the staging buffer
-        coarse_block = 512;
+        coarse_block = 256;   // as k_coarse_staged
     } else {
         size_t want = std::max<size_t>(std::max<size_t>(4096, n / 512), (size_t)64 * g.H / (shared_buckets ? pl.nwin : 1));
         g.tile_pts = (uint32_t)((std::min(want, n) + 1023) / 1024 * 1024);
-        coarse_block = g.tile_pts >= 16384 ? 1024 : 256;
+        coarse_block = g.tile_pts >= 16384 && !under_accumulate ? 1024 : 256;
         g.wgroup = shared_buckets ? pl.nwin : std::max<uint32_t>(1, std::min<uint32_t>(pl.nwin, msmk::SORT_MAX_COUNTERS / g.H));
     }
     g.tiles = (uint32_t)((n + g.tile_pts - 1) / g.tile_pts);
     g.ngroups = (pl.nwin + g.wgroup - 1) / g.wgroup;
-    d.tilecnt.ensure((size_t)g.tiles * g.nbins * 4);
-    d.tileoff.ensure((size_t)g.tiles * g.nbins * 4);
-    d.bin_tot.ensure((size_t)g.nbins * 4);
+    sc.tilecnt.ensure((size_t)g.tiles * g.nbins * 4);
+    sc.tileoff.ensure((size_t)g.tiles * g.nbins * 4);
+    sc.bin_tot.ensure((size_t)g.nbins * 4);
     feed_and_count(g, [&](uint32_t ntiles) {
-        launch_coarse<false>(pl.c, dim3(ntiles, g.ngroups), dim3(coarse_block), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
+        launch_coarse<false>(pl.c, dim3(ntiles, g.ngroups), dim3(coarse_block), s, d_scalars, d_flags, g, (uint32_t*)sc.tilecnt.p,
                              (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     });
-    hipLaunchKernelGGL(msmk::k_colscan, dim3((g.nbins + 255) / 256), dim3(256), 0, s, (const uint32_t*)d.tilecnt.p, g.nbins, g.tiles,
-                       (uint32_t*)d.tileoff.p, (uint32_t*)d.bin_tot.p);
-    hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.bin_tot.p, g.nbins, (uint32_t*)d.bin_base.p);
+    hipLaunchKernelGGL(msmk::k_colscan, dim3((g.nbins + 255) / 256), dim3(256), 0, s, (const uint32_t*)sc.tilecnt.p, g.nbins, g.tiles,
+                       (uint32_t*)sc.tileoff.p, (uint32_t*)sc.bin_tot.p);
+    hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)sc.bin_tot.p, g.nbins, (uint32_t*)sc.bin_base.p);
     if (staged)
-        launch_coarse_staged(pl.c, dim3(g.tiles, g.ngroups), s, d_scalars, d_flags, g, (const uint32_t*)d.tilecnt.p, (const uint32_t*)d.tileoff.p,
-                             (const uint32_t*)d.bin_base.p, (uint32_t*)d.coarse.p);
+        launch_coarse_staged(pl.c, dim3(g.tiles, g.ngroups), s, d_scalars, d_flags, g, (const uint32_t*)sc.tilecnt.p, (const uint32_t*)sc.tileoff.p,
+                             (const uint32_t*)sc.bin_base.p, (uint32_t*)sc.coarse.p);
     else
-        launch_coarse<true>(pl.c, dim3(g.tiles, g.ngroups), dim3(coarse_block), s, d_scalars, d_flags, g, (uint32_t*)d.tilecnt.p,
-                            (const uint32_t*)d.tileoff.p, (const uint32_t*)d.bin_base.p, (uint32_t*)d.coarse.p);
+        launch_coarse<true>(pl.c, dim3(g.tiles, g.ngroups), dim3(coarse_block), s, d_scalars, d_flags, g, (uint32_t*)sc.tilecnt.p,
+                            (const uint32_t*)sc.tileoff.p, (const uint32_t*)sc.bin_base.p, (uint32_t*)sc.coarse.p);
     }
-    if (phases) HIP_TRY(hipEventRecord(d.ev[ev0 + 1], s));
+    if (phases) HIP_TRY(hipEventRecord(sc.ev[1], s));
     // fine sort over bin segments
-    hipLaunchKernelGGL(msmk::k_seg_count, dim3((g.nbins + 255) / 256), dim3(256), 0, s, (const uint32_t*)d.bin_base.p, g.nbins,
-                       (uint32_t*)d.seg_cnt.p);
-    hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)d.seg_cnt.p, g.nbins, (uint32_t*)d.seg_base.p);
-    hipLaunchKernelGGL(msmk::k_fine_count, dim3(segs_cap), dim3(256), 0, s, (const uint32_t*)d.coarse.p, (const uint32_t*)d.bin_base.p,
-                       (const uint32_t*)d.seg_base.p, g, (uint32_t*)d.segcnt.p);
-    hipLaunchKernelGGL(msmk::k_fine_scan, dim3(g.nbins), dim3(256), 0, s, (const uint32_t*)d.seg_base.p, g, (const uint32_t*)d.segcnt.p,
-                       (uint32_t*)d.segoff.p, (uint32_t*)d.hist.p);
-    hipLaunchKernelGGL(msmk::k_fine_scatter, dim3(segs_cap), dim3(256), 0, s, (const uint32_t*)d.coarse.p, (const uint32_t*)d.bin_base.p,
-                       (const uint32_t*)d.seg_base.p, g, (const uint32_t*)d.segcnt.p, (const uint32_t*)d.segoff.p, (uint32_t*)d.sorted.p);
-    if (phases) HIP_TRY(hipEventRecord(d.ev[ev0 + 2], s));
-    // ---- schedule: <= SCHED_MAX_BLK blocks of 1024 lanes, each lane owning per_blk/1024 consecutive buckets
-    uint32_t per_blk = 4096;   // fewer buckets per block (1024: one per lane) measured slower below 2^23 points: 0.073 against 0.043 ms
+    hipLaunchKernelGGL(msmk::k_seg_count, dim3((g.nbins + 255) / 256), dim3(256), 0, s, (const uint32_t*)sc.bin_base.p, g.nbins,
+                       (uint32_t*)sc.seg_cnt.p);
+    hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)sc.seg_cnt.p, g.nbins, (uint32_t*)sc.seg_base.p);
+    hipLaunchKernelGGL(msmk::k_fine_count, dim3(segs_cap), dim3(256), 0, s, (const uint32_t*)sc.coarse.p, (const uint32_t*)sc.bin_base.p,
+                       (const uint32_t*)sc.seg_base.p, g, (uint32_t*)sc.segcnt.p);
+    hipLaunchKernelGGL(msmk::k_fine_scan, dim3(g.nbins), dim3(256), 0, s, (const uint32_t*)sc.seg_base.p, g, (const uint32_t*)sc.segcnt.p,
+                       (uint32_t*)sc.segoff.p, (uint32_t*)sc.hist.p);
+    hipLaunchKernelGGL(msmk::k_fine_scatter, dim3(segs_cap), dim3(256), 0, s, (const uint32_t*)sc.coarse.p, (const uint32_t*)sc.bin_base.p,
+                       (const uint32_t*)sc.seg_base.p, g, (const uint32_t*)sc.segcnt.p, (const uint32_t*)sc.segoff.p, (uint32_t*)sc.sorted.p);
+    if (phases) HIP_TRY(hipEventRecord(sc.ev[2], s));
+    // ---- schedule: <= SCHED_MAX_BLK blocks of SCHED_NT lanes, each lane owning per_blk / SCHED_NT consecutive buckets
+    uint32_t per_blk = 4 * msmk::SCHED_NT;   // four buckets per lane (one per lane measured slower below 2^23 points: 0.073 against 0.043 ms)
     while ((pl.nbuckets + per_blk - 1) / per_blk > msmk::SCHED_MAX_BLK) per_blk <<= 1;
     uint32_t nblk = (uint32_t)((pl.nbuckets + per_blk - 1) / per_blk);
     // every bucket has at least one item (an empty bucket's item leaves infinity for the reduce), plus one per S entries of the split ones
     const size_t items_cap = pl.nbuckets + (entries_cap >> pl.logS) + 1;
     out.items_cap = items_cap;
-    d.sched.ensure((size_t)(3 + msmk::SCHED_CLASSES) * nblk * 4);
-    d.order.ensure(items_cap * 4);
-    d.item_bucket.ensure(items_cap * 4);
+    sc.sched.ensure((size_t)(3 + msmk::SCHED_CLASSES) * nblk * 4);
+    sc.order.ensure(items_cap * 4);
+    sc.item_bucket.ensure(items_cap * 4);
     // level 0 of the merge tree lists every FAN-th item of the split buckets: sum ceil(items_b / FAN) <= items / FAN + 3/4 per split bucket; a split
     // bucket has at least 3 items (more than T >= 2 S entries), so the list never exceeds items / 2.  The levels ping-pong between two lists.
-    d.merge_list.ensure((items_cap / 2 + 1) * 4);
-    d.merge_list2.ensure((items_cap / 2 + 1) * 4);
-    uint32_t* blk_e = (uint32_t*)d.sched.p;
+    sc.merge_list.ensure((items_cap / 2 + 1) * 4);
+    sc.merge_list2.ensure((items_cap / 2 + 1) * 4);
+    uint32_t* blk_e = (uint32_t*)sc.sched.p;
     uint32_t* blk_i = blk_e + nblk;
     uint32_t* blk_max = blk_i + nblk;
     uint32_t* blk_cls = blk_max + nblk;
-    hipLaunchKernelGGL(msmk::k_sched1, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT | (pl.cls_shift << 8) | (pl.logS << 16),
+    hipLaunchKernelGGL(msmk::k_sched1, dim3(nblk), dim3(msmk::SCHED_NT), 0, s, (const uint32_t*)sc.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT | (pl.cls_shift << 8) | (pl.logS << 16),
                        nblk, blk_e, blk_i, blk_cls, blk_max);
-    hipLaunchKernelGGL(msmk::k_sched2, dim3(1), dim3(1024), 0, s, nblk, blk_e, blk_i, blk_cls, (const uint32_t*)blk_max,
-                       (uint32_t*)d.meta.p);
-    hipLaunchKernelGGL(msmk::k_sched3, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)d.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT | (pl.cls_shift << 8) | (pl.logS << 16),
-                       nblk, (const uint32_t*)blk_e, (const uint32_t*)blk_i, (const uint32_t*)blk_cls, (uint32_t*)d.offsets.p,
-                       (uint32_t*)d.woff.p, (uint32_t*)d.order.p, (uint32_t*)d.item_bucket.p, (uint32_t*)d.merge_list.p,
-                       (uint32_t*)d.meta.p);
+    hipLaunchKernelGGL(msmk::k_sched2, dim3(1), dim3(msmk::SCHED_NT), 0, s, nblk, blk_e, blk_i, blk_cls, (const uint32_t*)blk_max,
+                       (uint32_t*)sc.meta.p);
+    hipLaunchKernelGGL(msmk::k_sched3, dim3(nblk), dim3(msmk::SCHED_NT), 0, s, (const uint32_t*)sc.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT | (pl.cls_shift << 8) | (pl.logS << 16),
+                       nblk, (const uint32_t*)blk_e, (const uint32_t*)blk_i, (const uint32_t*)blk_cls, (uint32_t*)sc.offsets.p,
+                       (uint32_t*)sc.woff.p, (uint32_t*)sc.order.p, (uint32_t*)sc.item_bucket.p, (uint32_t*)sc.merge_list.p,
+                       (uint32_t*)sc.meta.p);
     // the merge launches are sized by the schedule's counts: one small read-back into pinned memory, waited for by read_schedule
-    HIP_TRY(hipMemcpyAsync(d.h_meta, d.meta.p, 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(d.ev[ev0 + 3], s));
+    HIP_TRY(hipMemcpyAsync(sc.h_meta, sc.meta.p, 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(sc.ev[3], s));
 }
 
-void read_schedule(DevState& d, int ev0, SortOut& out) {
-    HIP_TRY(hipEventSynchronize(d.ev[ev0 + 3]));
+void read_schedule(Scratch& sc, SortOut& out) {
+    HIP_TRY(hipEventSynchronize(sc.ev[3]));
     HIP_TRY(hipGetLastError());
-    out.nitems = d.h_meta[0];
-    out.max_items = d.h_meta[1];
-    out.entries = d.h_meta[2];
-    out.nlist = d.h_meta[3];
-    out.nsplit = d.h_meta[4];
+    out.nitems = sc.h_meta[0];
+    out.max_items = sc.h_meta[1];
+    out.entries = sc.h_meta[2];
+    out.nlist = sc.h_meta[3];
+    out.nsplit = sc.h_meta[4];
     if ((uint64_t)out.nlist > out.items_cap / 2 + 1) throw HipFail{"schedule produced a longer merge list than its bound"};
     if (out.nitems > out.items_cap) throw HipFail{"schedule produced more work items than its bound"};
 }

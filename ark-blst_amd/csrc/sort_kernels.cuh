@@ -17,7 +17,8 @@ namespace msmk {
 //                                               -> sorted[] in (window, bucket) order and hist[window][bucket]
 // Windows are processed in groups of `wgroup` so that wgroup * H counters fit LDS (<= 16384 counters, 64 KB).
 struct SortGeom {
-    uint32_t n, fmt, c, nwin;
+    uint32_t n, fmt, c, nwin;     // nwin digit windows starting at window win0 (a whole call: win0 = 0, every window)
+    uint32_t win0;
     uint32_t lo_bits, H;          // fine bits, coarse bins per window
     uint32_t tiles, tile_pts;     // point tiles (grid.x) and points per tile (multiple of 1024)
     uint32_t tile0;               // first tile of this launch (count passes run per chunk of tiles while host scalars still arrive)
@@ -33,10 +34,12 @@ template <bool SCATTER, int CB>
 __global__ void __launch_bounds__(1024) k_coarse(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flags, SortGeom g,
                                                  uint32_t* __restrict__ tilecnt, const uint32_t* __restrict__ tileoff,
                                                  const uint32_t* __restrict__ bin_base, uint32_t* __restrict__ coarse) {
+    aux_priority();
     __shared__ uint32_t cnt[SORT_MAX_COUNTERS];
     const uint32_t tile = blockIdx.x + g.tile0, grp = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
-    uint32_t w0 = grp * g.wgroup, w1 = w0 + g.wgroup < g.nwin ? w0 + g.wgroup : g.nwin;
-    const uint32_t bin0 = g.shared ? 0u : w0 * g.H;
+    const uint32_t wend = g.win0 + g.nwin;
+    uint32_t w0 = g.win0 + grp * g.wgroup, w1 = w0 + g.wgroup < wend ? w0 + g.wgroup : wend;
+    const uint32_t bin0 = g.shared ? 0u : (w0 - g.win0) * g.H;
     uint32_t ncnt = (g.shared ? 1u : (w1 - w0)) * g.H;
     for (uint32_t k = t; k < ncnt; k += nt) {
         if (SCATTER) {
@@ -73,34 +76,45 @@ __global__ void __launch_bounds__(1024) k_coarse(const uint32_t* __restrict__ sc
 constexpr uint32_t COARSE_STAGE = 16384;
 constexpr uint32_t COARSE_STAGE_BINS = 512;
 template <int CB>
-__global__ void __launch_bounds__(512) k_coarse_staged(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flags, SortGeom g,
+__global__ void __launch_bounds__(256) k_coarse_staged(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flags, SortGeom g,
                                                        const uint32_t* __restrict__ tilecnt, const uint32_t* __restrict__ tileoff,
                                                        const uint32_t* __restrict__ bin_base, uint32_t* __restrict__ coarse) {
+    aux_priority();
+    // 256 lanes, two bins per lane (round 6; it was 512 lanes): one wave per SIMD with 56 registers finds room beside the two resident waves
+    // of an accumulate kernel (2 x 216 of 512 registers per lane), two did not — in a pipelined call this kernel runs under one (see AUX_BLOCK)
     __shared__ uint32_t stage[COARSE_STAGE];
     __shared__ uint32_t lstart[COARSE_STAGE_BINS + 1], cur[COARSE_STAGE_BINS], goff[COARSE_STAGE_BINS];
-    const uint32_t tile = blockIdx.x, grp = blockIdx.y, t = threadIdx.x, nt = 512;
-    const uint32_t w0 = grp * g.wgroup, w1 = w0 + g.wgroup < g.nwin ? w0 + g.wgroup : g.nwin;
-    const uint32_t bin0 = w0 * g.H, ncnt = (w1 - w0) * g.H;   // ncnt <= COARSE_STAGE_BINS
-    const uint32_t mine = t < ncnt ? tilecnt[(size_t)tile * g.nbins + bin0 + t] : 0u;
-    goff[t] = t < ncnt ? bin_base[bin0 + t] + tileoff[(size_t)tile * g.nbins + bin0 + t] : 0u;
-    cur[t] = mine;
+    constexpr uint32_t NT = 256;
+    static_assert(COARSE_STAGE_BINS == 2 * NT, "two bins per lane");
+    const uint32_t tile = blockIdx.x, grp = blockIdx.y, t = threadIdx.x;
+    const uint32_t wend = g.win0 + g.nwin;
+    const uint32_t w0 = g.win0 + grp * g.wgroup, w1 = w0 + g.wgroup < wend ? w0 + g.wgroup : wend;
+    const uint32_t bin0 = (w0 - g.win0) * g.H, ncnt = (w1 - w0) * g.H;   // ncnt <= COARSE_STAGE_BINS
+    uint32_t mine[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const uint32_t k = t + NT * r;
+        mine[r] = k < ncnt ? tilecnt[(size_t)tile * g.nbins + bin0 + k] : 0u;
+        goff[k] = k < ncnt ? bin_base[bin0 + k] + tileoff[(size_t)tile * g.nbins + bin0 + k] : 0u;
+        cur[k] = mine[r];
+    }
     __syncthreads();
-    for (uint32_t d = 1; d < COARSE_STAGE_BINS; d <<= 1) {   // inclusive scan of the counts
-        uint32_t v = t >= d ? cur[t - d] : 0;
+    for (uint32_t d = 1; d < COARSE_STAGE_BINS; d <<= 1) {   // inclusive scan of the counts, two per lane
+        uint32_t v0 = t >= d ? cur[t - d] : 0, v1 = cur[t + NT - d];
         __syncthreads();
-        cur[t] += v;
+        cur[t] += v0; cur[t + NT] += v1;
         __syncthreads();
     }
-    const uint32_t excl = cur[t] - mine;
+    const uint32_t e0 = cur[t] - mine[0], e1 = cur[t + NT] - mine[1];
     __syncthreads();
-    lstart[t] = excl;
-    cur[t] = excl;
-    if (t == COARSE_STAGE_BINS - 1) lstart[COARSE_STAGE_BINS] = excl + mine;
+    lstart[t] = e0; lstart[t + NT] = e1;
+    cur[t] = e0; cur[t + NT] = e1;
+    if (t == NT - 1) lstart[COARSE_STAGE_BINS] = e1 + mine[1];
     __syncthreads();
     const uint32_t total = lstart[COARSE_STAGE_BINS];
     const uint32_t lo_mask = (1u << g.lo_bits) - 1u;
     const uint32_t p0 = tile * g.tile_pts, p1 = p0 + g.tile_pts < g.n ? p0 + g.tile_pts : g.n;
-    for (uint32_t i = p0 + t; i < p1; i += nt) {
+    for (uint32_t i = p0 + t; i < p1; i += NT) {
         if (inf_flags[i] != 0) continue;
         uint32_t s[8];
         const bool flip = load_scalar(s, scalars, i, g.fmt);
@@ -111,7 +125,7 @@ __global__ void __launch_bounds__(512) k_coarse_staged(const uint32_t* __restric
         });
     }
     __syncthreads();
-    for (uint32_t j = t; j < total; j += nt) {
+    for (uint32_t j = t; j < total; j += NT) {
         uint32_t k = 0;   // the bin whose run holds position j
 #pragma unroll
         for (uint32_t step = COARSE_STAGE_BINS / 2; step >= 1; step >>= 1)
@@ -124,6 +138,7 @@ __global__ void __launch_bounds__(512) k_coarse_staged(const uint32_t* __restric
 // bin: coalesced across bins; eight tiles' loads in flight per lane.
 __global__ void __launch_bounds__(256) k_colscan(const uint32_t* __restrict__ tilecnt, uint32_t nbins, uint32_t tiles,
                                                  uint32_t* __restrict__ tileoff, uint32_t* __restrict__ bin_tot) {
+    aux_priority();
     uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nbins) return;
     uint32_t run = 0, k = 0;
@@ -147,6 +162,7 @@ __global__ void __launch_bounds__(256) k_colscan(const uint32_t* __restrict__ ti
 
 // exclusive scan of m <= ~100k values by one workgroup; out[m] = total
 __global__ void __launch_bounds__(1024) k_binscan(const uint32_t* __restrict__ in, uint32_t m, uint32_t* __restrict__ out) {
+    aux_priority();
     __shared__ uint32_t part[1024];
     uint32_t t = threadIdx.x;
     uint32_t per = (m + 1023) / 1024;
@@ -181,6 +197,7 @@ __global__ void __launch_bounds__(1024) k_binscan(const uint32_t* __restrict__ i
 constexpr uint32_t FINE_SEG = 8192;
 
 __global__ void __launch_bounds__(256) k_seg_count(const uint32_t* __restrict__ bin_base, uint32_t nbins, uint32_t* __restrict__ seg_cnt) {
+    aux_priority();
     uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nbins) return;
     uint32_t sz = bin_base[b + 1] - bin_base[b];
@@ -210,6 +227,7 @@ __device__ __forceinline__ bool seg_locate(uint32_t seg, const uint32_t* seg_bas
 
 __global__ void __launch_bounds__(256) k_fine_count(const uint32_t* __restrict__ coarse, const uint32_t* __restrict__ bin_base,
                                                     const uint32_t* __restrict__ seg_base, SortGeom g, uint32_t* __restrict__ segcnt) {
+    aux_priority();
     __shared__ uint32_t cnt[256];
     __shared__ uint32_t sb[3];
     uint32_t t = threadIdx.x, seg = blockIdx.x;
@@ -231,6 +249,7 @@ __global__ void __launch_bounds__(256) k_fine_count(const uint32_t* __restrict__
 // one workgroup per bin, lane = lo.  segoff[seg][lo] <- offset of (seg, lo) relative to the bin start.
 __global__ void __launch_bounds__(256) k_fine_scan(const uint32_t* __restrict__ seg_base, SortGeom g, const uint32_t* __restrict__ segcnt,
                                                    uint32_t* __restrict__ segoff, uint32_t* __restrict__ hist) {
+    aux_priority();
     __shared__ uint32_t scan[256];
     uint32_t bin = blockIdx.x, t = threadIdx.x;
     uint32_t F = 1u << g.lo_bits;
@@ -265,6 +284,7 @@ __global__ void __launch_bounds__(256) k_fine_scatter(const uint32_t* __restrict
                                                       const uint32_t* __restrict__ seg_base, SortGeom g,
                                                       const uint32_t* __restrict__ segcnt, const uint32_t* __restrict__ segoff,
                                                       uint32_t* __restrict__ sorted) {
+    aux_priority();
     __shared__ uint32_t stage[FINE_SEG];
     __shared__ uint32_t lstart[257], cur[256], goff[256];
     __shared__ uint32_t sb[4];
@@ -329,6 +349,7 @@ template <bool SCATTER, int CB>
 __global__ void __launch_bounds__(1024) k_coarseA(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flags, SortGeom g,
                                                   uint32_t* __restrict__ tilecnt, const uint32_t* __restrict__ tileoff,
                                                   const uint32_t* __restrict__ binA_base, uint2* __restrict__ coarseA) {
+    aux_priority();
     __shared__ uint32_t cnt[512];
     const uint32_t tile = blockIdx.x + g.tile0, t = threadIdx.x, nt = blockDim.x;
     const uint32_t nbinsA = g.nwin * A_BINS;
@@ -340,8 +361,8 @@ __global__ void __launch_bounds__(1024) k_coarseA(const uint32_t* __restrict__ s
         if (inf_flags[i] != 0) continue;
         uint32_t s[8];
         const bool flip = load_scalar(s, scalars, i, g.fmt);
-        for_each_digit_static<CB>(s, flip, 0, g.nwin, [&](uint32_t w, uint32_t b, bool neg) {
-            uint32_t pos = atomicAdd(&cnt[w * A_BINS + (b >> REM)], 1u);
+        for_each_digit_static<CB>(s, flip, g.win0, g.win0 + g.nwin, [&](uint32_t w, uint32_t b, bool neg) {
+            uint32_t pos = atomicAdd(&cnt[(w - g.win0) * A_BINS + (b >> REM)], 1u);
             if (SCATTER) coarseA[pos] = make_uint2(i, ((neg ? 1u : 0u) << 31) | (b & ((1u << REM) - 1u)));
         });
     }
@@ -355,6 +376,7 @@ __global__ void __launch_bounds__(1024) k_coarseA(const uint32_t* __restrict__ s
 __global__ void __launch_bounds__(256) k_mid_count(const uint2* __restrict__ coarseA, const uint32_t* __restrict__ binA_base,
                                                    const uint32_t* __restrict__ segA_base, uint32_t nbinsA, uint32_t lo_bits, uint32_t mid_bits,
                                                    uint32_t* __restrict__ segcnt) {
+    aux_priority();
     __shared__ uint32_t cnt[MID_MAX];
     __shared__ uint32_t sb[3];
     uint32_t t = threadIdx.x, seg = blockIdx.x;
@@ -377,6 +399,7 @@ __global__ void __launch_bounds__(256) k_mid_count(const uint2* __restrict__ coa
 __global__ void __launch_bounds__(512) k_mid_scan(const uint32_t* __restrict__ binA_base, const uint32_t* __restrict__ segA_base,
                                                   uint32_t mid_bits, const uint32_t* __restrict__ segcnt, uint32_t* __restrict__ segoff,
                                                   uint32_t* __restrict__ bin_base, uint32_t nbinsA) {
+    aux_priority();
     __shared__ uint32_t scan[MID_MAX];
     const uint32_t a = blockIdx.x, t = threadIdx.x, M = 1u << mid_bits;
     const uint32_t s0 = segA_base[a], s1 = segA_base[a + 1];
@@ -429,6 +452,7 @@ __global__ void __launch_bounds__(256) k_mid_scatter(const uint2* __restrict__ c
                                                      const uint32_t* __restrict__ segA_base, uint32_t nbinsA, uint32_t lo_bits, uint32_t mid_bits,
                                                      const uint32_t* __restrict__ segcnt, const uint32_t* __restrict__ segoff,
                                                      uint32_t* __restrict__ coarse) {
+    aux_priority();
     __shared__ uint32_t stage[FINE_SEG];
     __shared__ uint32_t lstart[MID_MAX + 1], cur[MID_MAX], goff[MID_MAX];
     __shared__ uint32_t sb[4];
@@ -487,9 +511,12 @@ __global__ void __launch_bounds__(256) k_mid_scatter(const uint2* __restrict__ c
 //   * order[] lists item ids by DESCENDING length class (65 classes): the 64 lanes of a wave then run the same
 //     number of additions (bucket loads are Poisson distributed: unsorted, a wave waits for its longest lane,
 //     ~70 % lane efficiency at a mean of 32) and the longest items start first.
-// Layout: nblk <= 256 blocks of 1024 lanes; block k owns `per_blk` consecutive buckets, lane t owns
-// per_blk/1024 consecutive ones.  item id of (bucket b, chunk k) = woff[b] + k.
+// Layout: nblk <= SCHED_MAX_BLK blocks of SCHED_NT lanes; block k owns `per_blk` consecutive buckets, lane t owns
+// per_blk / SCHED_NT consecutive ones.  item id of (bucket b, chunk k) = woff[b] + k.
+// SCHED_NT = 512 (round 6; 1024 before): two waves per SIMD of <= 32 registers find room beside the two resident waves of an accumulate
+// kernel (80 of 512 registers per lane are left), four did not — in a pipelined call the schedule of group g + 1 runs under accumulate(g).
 constexpr int SCHED_CLASSES = 65;
+constexpr uint32_t SCHED_NT = 512, SCHED_LOG_NT = 9;
 
 // A bucket of up to T = 2^logT entries is ONE item; a fuller one is split into items of S = 2^logS entries, S = max(16, T / 4) (round 4: it
 // was T).  Skewed scalars (witness bits: half the scalars are 0 or 1) put 10^5..10^6 entries into one bucket; with items of T = 64 a lane
@@ -506,16 +533,17 @@ __device__ __forceinline__ uint32_t last_len(uint32_t cnt, uint32_t it, uint32_t
 // or the lanes of a wave walk items of visibly different lengths (measured +8 % on the accumulate kernel at 2^24).
 __device__ __forceinline__ uint32_t class_of(uint32_t len, uint32_t cls_shift) { uint32_t c = len >> cls_shift; return c < 64 ? c : 64; }
 
-__global__ void __launch_bounds__(1024) k_sched1(const uint32_t* __restrict__ hist, uint32_t m, uint32_t per_blk, uint32_t logT,
+__global__ void __launch_bounds__(SCHED_NT) k_sched1(const uint32_t* __restrict__ hist, uint32_t m, uint32_t per_blk, uint32_t logT,
                                                  uint32_t nblk, uint32_t* __restrict__ blk_e, uint32_t* __restrict__ blk_i,
                                                  uint32_t* __restrict__ blk_cls, uint32_t* __restrict__ blk_max) {
+    aux_priority();
     __shared__ uint32_t cls[SCHED_CLASSES];
     __shared__ uint32_t se, si, smax;
     uint32_t t = threadIdx.x, blk = blockIdx.x;
     if (t < SCHED_CLASSES) cls[t] = 0;
     if (t == 0) { se = 0; si = 0; smax = 1; }
     __syncthreads();
-    uint32_t per_t = per_blk >> 10;
+    uint32_t per_t = per_blk >> SCHED_LOG_NT;
     uint32_t lo = blk * per_blk + t * per_t, hi = lo + per_t < m ? lo + per_t : m;
     const uint32_t cls_shift = (logT >> 8) & 0xffu, logS = (logT >> 16) & 0xffu;   // the launch packs log2 T | class shift << 8 | log2 S << 16
     logT &= 0xffu;
@@ -540,27 +568,33 @@ __global__ void __launch_bounds__(1024) k_sched1(const uint32_t* __restrict__ hi
 // (1024 blocks since round 5: at 2^24 points the 6.8 M buckets were spread over 208 blocks, 32 consecutive buckets per lane — one lane per
 // 128-byte line, one block per CU — and k_sched1 / k_sched3 took 0.12 + 0.50 ms)
 constexpr uint32_t SCHED_MAX_BLK = 1024;
-__global__ void __launch_bounds__(1024) k_sched2(uint32_t nblk, uint32_t* __restrict__ blk_e, uint32_t* __restrict__ blk_i,
+__global__ void __launch_bounds__(SCHED_NT) k_sched2(uint32_t nblk, uint32_t* __restrict__ blk_e, uint32_t* __restrict__ blk_i,
                                                  uint32_t* __restrict__ blk_cls, const uint32_t* __restrict__ blk_max,
                                                  uint32_t* __restrict__ meta) {
+    aux_priority();
     __shared__ uint32_t a[SCHED_MAX_BLK], b[SCHED_MAX_BLK], ctot[SCHED_CLASSES], cbase[SCHED_CLASSES];
     uint32_t t = threadIdx.x;
+    static_assert(SCHED_MAX_BLK == 2 * SCHED_NT, "two block sums per lane");
+    const uint32_t t2 = t + SCHED_NT;
     const uint32_t ve = t < nblk ? blk_e[t] : 0, vi = t < nblk ? blk_i[t] : 0;
-    a[t] = ve;
-    b[t] = vi;
+    const uint32_t ve2 = t2 < nblk ? blk_e[t2] : 0, vi2 = t2 < nblk ? blk_i[t2] : 0;
+    a[t] = ve; a[t2] = ve2;
+    b[t] = vi; b[t2] = vi2;
     __syncthreads();
     for (uint32_t d = 1; d < SCHED_MAX_BLK; d <<= 1) {
         uint32_t xa = 0, xb = 0;
         if (t >= d) { xa = a[t - d]; xb = b[t - d]; }
+        const uint32_t xa2 = a[t2 - d], xb2 = b[t2 - d];   // d <= SCHED_NT <= t2
         __syncthreads();
-        a[t] += xa;
-        b[t] += xb;
+        a[t] += xa; a[t2] += xa2;
+        b[t] += xb; b[t2] += xb2;
         __syncthreads();
     }
     if (t < nblk) { blk_e[t] = a[t] - ve; blk_i[t] = b[t] - vi; }
-    // class rows: wave w handles classes w, w+16, ...; exclusive scan of each row in chunks of 64 lanes
+    if (t2 < nblk) { blk_e[t2] = a[t2] - ve2; blk_i[t2] = b[t2] - vi2; }
+    // class rows: wave w handles classes w, w+8, ...; exclusive scan of each row in chunks of 64 lanes
     uint32_t wave = t >> 6, lane = t & 63;
-    for (uint32_t c = wave; c < SCHED_CLASSES; c += 16) {
+    for (uint32_t c = wave; c < SCHED_CLASSES; c += SCHED_NT / 64) {
         uint32_t run = 0;
         for (uint32_t base = 0; base < nblk; base += 64) {
             uint32_t idx = base + lane;
@@ -581,7 +615,7 @@ __global__ void __launch_bounds__(1024) k_sched2(uint32_t nblk, uint32_t* __rest
         cbase[t] = above;
     }
     __syncthreads();
-    for (uint32_t idx = t; idx < SCHED_CLASSES * nblk; idx += 1024) blk_cls[idx] += cbase[idx / nblk];
+    for (uint32_t idx = t; idx < SCHED_CLASSES * nblk; idx += SCHED_NT) blk_cls[idx] += cbase[idx / nblk];
     if (t == 0) {
         uint32_t mx = 1;
         for (uint32_t k = 0; k < nblk; k++) mx = blk_max[k] > mx ? blk_max[k] : mx;
@@ -595,13 +629,14 @@ __global__ void __launch_bounds__(1024) k_sched2(uint32_t nblk, uint32_t* __rest
 }
 
 // per block: bucket-level exclusive scans -> offsets / cursor / woff; every item gets its slot in order[]
-__global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hist, uint32_t m, uint32_t per_blk, uint32_t logT,
+__global__ void __launch_bounds__(SCHED_NT) k_sched3(const uint32_t* __restrict__ hist, uint32_t m, uint32_t per_blk, uint32_t logT,
                                                  uint32_t nblk, const uint32_t* __restrict__ blk_e, const uint32_t* __restrict__ blk_i,
                                                  const uint32_t* __restrict__ blk_cls, uint32_t* __restrict__ offsets,
                                                  uint32_t* __restrict__ woff,
                                                  uint32_t* __restrict__ order, uint32_t* __restrict__ item_bucket,
                                                  uint32_t* __restrict__ merge_list, uint32_t* __restrict__ meta) {
-    __shared__ uint32_t pe[1024], pi[1024], cur[SCHED_CLASSES];
+    aux_priority();
+    __shared__ uint32_t pe[SCHED_NT], pi[SCHED_NT], cur[SCHED_CLASSES];
     // buckets split into many items (skewed scalars: one bucket can hold all N entries) are written out by the whole
     // workgroup after the per-lane pass; one lane doing it alone cost 0.65 ms for a bucket of 2^20 entries
     constexpr uint32_t HV_CAP = 512, HV_MIN = 64;   // (64 slots until round 4: the 128 buckets of a 7-bit top window overflowed them, and a lone lane wrote 4096 items each — 1.2 ms)
@@ -609,7 +644,7 @@ __global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hi
     uint32_t t = threadIdx.x, blk = blockIdx.x;
     if (t == 0) hv_n = 0;
     if (t < SCHED_CLASSES) cur[t] = blk_cls[t * nblk + blk];
-    uint32_t per_t = per_blk >> 10;
+    uint32_t per_t = per_blk >> SCHED_LOG_NT;
     uint32_t lo = blk * per_blk + t * per_t, hi = lo + per_t < m ? lo + per_t : m;
     const uint32_t cls_shift = (logT >> 8) & 0xffu, logS = (logT >> 16) & 0xffu;
     logT &= 0xffu;
@@ -622,7 +657,7 @@ __global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hi
     pe[t] = sum_e;
     pi[t] = sum_i;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
+    for (uint32_t d = 1; d < SCHED_NT; d <<= 1) {
         uint32_t xe = t >= d ? pe[t - d] : 0, xi = t >= d ? pi[t - d] : 0;
         __syncthreads();
         pe[t] += xe;
@@ -654,12 +689,12 @@ __global__ void __launch_bounds__(1024) k_sched3(const uint32_t* __restrict__ hi
         run_e += h;
         run_i += it;
     }
-    if (blk == nblk - 1 && t == 1023) { offsets[m] = run_e; woff[m] = run_i; }
+    if (blk == nblk - 1 && t == SCHED_NT - 1) { offsets[m] = run_e; woff[m] = run_i; }
     __syncthreads();
     const uint32_t nh = hv_n < HV_CAP ? hv_n : HV_CAP;
     for (uint32_t s = 0; s < nh; s++) {
         const uint32_t k = hv_k[s], r0 = hv_run[s], it = hv_it[s], pos = hv_pos[s], mp = hv_mp[s];
-        for (uint32_t j = t; j < it; j += 1024) {
+        for (uint32_t j = t; j < it; j += SCHED_NT) {
             if (j + 1 < it) { order[pos + j] = r0 + j; item_bucket[r0 + j] = k; }
             if (j % MERGE_FAN == 0) merge_list[mp + j / MERGE_FAN] = r0 + j;
         }

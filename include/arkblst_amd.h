@@ -83,6 +83,11 @@ typedef struct {
     uint64_t accumulate_adds; /* mixed additions executed by the accumulate kernel */
     uint32_t work_items;      /* lanes of the accumulate kernel: buckets, heavy ones split into chunks */
     uint32_t max_items_per_bucket; /* 1 = no bucket was split */
+    uint32_t window_groups;   /* 1 = one pass of the pipeline on one stream; > 1 = the digit windows were processed as that many groups whose sort /
+                                 accumulate / reduce phases overlap on the lane's streams (mi_msm_set_pipeline).  The phase times above are then
+                                 sums over the groups of intervals that overlap in time; accumulate_ms is the span from the first accumulate kernel's
+                                 start to the last one's end */
+    uint32_t reserved;
 } mi_profile;
 
 /* Replaces Device::all()[0] + ec_gpu_gen::program! + SingleMultiexpKernel::create (src/gpu.rs:233-237,101-119),
@@ -250,6 +255,14 @@ int mi_g2_fold_windows(const mi_g2 *windows, size_t n_ranks, size_t rank_stride,
 
 /* Tuning / introspection. window_bits = 0 restores the built-in heuristic (cf. calc_window_size, src/gpu.rs:218-223). */
 int mi_msm_set_window_bits(mi_ctx *ctx, unsigned window_bits);
+/* Window groups of a pipelined call.  From 2^17 points on, a call over plain (not precomputed) bases processes its digit windows in groups, top
+ * windows first, each group with its own scratch: the sort of group g + 1 and the bucket reduction of group g - 1 run under the accumulate kernel
+ * of group g on separate streams, and the host folds the window sums of a group while the GPU works on the next.  n_groups = 0
+ * restores the built-in choice; n_groups = 1 switches the pipelining off (one pass on one stream, the behaviour before round 6); otherwise
+ * weights[0..n_groups) are the relative sizes of the groups, top windows first (at most 4 groups; every group gets at least one window).
+ * Results do not depend on it.  The environment variable ARKBLST_AMD_PIPELINE ("0" / "off", "auto", or a comma-separated weight list such as
+ * "3,5,5,3"), read by mi_msm_init, sets the initial value.  No counterpart in the reference (one launch, src/gpu.rs:172-183). */
+int mi_msm_set_pipeline(mi_ctx *ctx, const unsigned *weights, unsigned n_groups);
 /* Which timing events an MSM call records (every record leaves the device idle for ~6 us between two kernels — 5 % of a 2^16-point call):
  * 0 = none beyond the one the pipeline itself waits on; 1 (default) = the accumulate kernel's interval (mi_profile.accumulate_ms, total_ms,
  * host_fold_ms and the counters are filled, the other phase times are 0); 2 = every phase (digits, scatter, scan, reduce, combine, d2h, h2d).
