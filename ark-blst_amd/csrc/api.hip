@@ -1,5 +1,6 @@
 // extern "C" entry points of include/arkblst_amd.h: context lifetime, argument checks, dispatch into the curve / pairing /
 // codec translation units.  Nothing throws across this boundary (every body below either cannot throw or runs in guarded()).
+#include <random>
 #include "internal.hpp"
 #if defined(MI_TEST_HOOKS)
 #include "test_hooks.h"
@@ -78,6 +79,7 @@ int mi_msm_init(mi_ctx** out, const int* device_ids, int n_devices) {
                     for (auto& e : sc.ev) HIP_TRY(hipEventCreate(&e));
             }
         }
+        if (const char* e = getenv("ARKBLST_AMD_TRACE")) ctx->trace = atoi(e) != 0;
         if (const char* e = getenv("ARKBLST_AMD_PIPELINE")) {   // window groups of a pipelined call (mi_msm_set_pipeline): "0" / "off", "auto", or weights "3,5,5,3"
             std::vector<unsigned> w;
             if (!strcmp(e, "0") || !strcmp(e, "off") || !strcmp(e, "1")) w = {1};
@@ -92,6 +94,11 @@ int mi_msm_init(mi_ctx** out, const int* device_ids, int n_devices) {
                 }
             if (w.size() > (size_t)MAX_GROUPS) w.resize(MAX_GROUPS);
             ctx->pipe_weights = w;
+        }
+        {   // key of the base-set cache's fingerprint (common.hpp HashKey): per context, from the system's entropy source
+            std::random_device rd;
+            ctx->hash_seed = ((uint64_t)rd() << 32) | rd();
+            ctx->hash_mult = (((uint64_t)rd() << 32) | rd()) | 0x8000000000000001ull;   // odd, top bit set
         }
         if (const char* e = getenv("ARKBLST_AMD_BASE_CACHE")) {   // the operator's switch: overrides mi_msm_set_base_cache
             long v = strtol(e, nullptr, 10);

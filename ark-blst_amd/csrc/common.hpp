@@ -106,13 +106,20 @@ struct Resident {
     bool validated = false;   // every point passed Valid::check on the GPU (mi_msm_g{1,2}_validate_bases): MSMs over this set may fold signs
 };
 
+// 128-bit fingerprint of EVERY byte of a host base vector (content_fingerprint below)
+struct Fp128 {
+    uint64_t a = 0, b = 0;
+    bool operator==(const Fp128& o) const { return a == o.a && b == o.b; }
+    bool operator!=(const Fp128& o) const { return !(*this == o); }
+};
+
 // One cached base set of the stateless call shape (mi_msm_set_base_cache): the device-form shards of a host base vector the context has
-// seen, keyed by (host pointer, length, fingerprint of a fixed sample of its points).  Lanes hold a shared_ptr while they use it, so an
+// seen, keyed by (host pointer, length, fingerprint of its whole content).  Lanes hold a shared_ptr while they use it, so an
 // eviction by the other lane frees the memory only when the last user is done.
 struct BaseCacheEntry {
     const void* ptr = nullptr;
     size_t n = 0;
-    uint64_t fp = 0;
+    Fp128 fp;
     uint64_t stamp = 0;             // LRU clock
     std::vector<Resident> shard;    // one per device of the context
     std::vector<int> devs;          // their HIP ordinals (the buffers are freed on the right device)
@@ -195,6 +202,7 @@ struct DevState {
 };
 
 constexpr int NLANES = 2;
+class HashPool;   // defined below mi_ctx
 
 // One persistent host thread per device of a multi-device context: the calling thread posts one job per device and
 // waits; nothing is spawned per call (a std::thread per device per call cost 1.4 ms for 0.2 ms of work).
@@ -270,12 +278,15 @@ struct mi_ctx {
     // window groups of a pipelined call (run_msm): 0 entries = the built-in choice; {1} = never pipeline; otherwise relative weights of the
     // groups, top windows first (mi_msm_set_pipeline / ARKBLST_AMD_PIPELINE)
     std::vector<unsigned> pipe_weights;
+    bool trace = false;   // ARKBLST_AMD_TRACE=1: MSM calls at profile level 2 print their phase boundaries to stderr (run_msm)
     // base-set cache of the stateless call shape (api.hip mi_msm_set_base_cache); [0] = G1, [1] = G2
     std::mutex cache_mu;
     unsigned cache_entries = 0;       // 0 = off
     bool cache_env = false;           // ARKBLST_AMD_BASE_CACHE was set: it overrides mi_msm_set_base_cache
     uint64_t cache_clock = 0, cache_hits = 0, cache_misses = 0;
     std::vector<std::shared_ptr<mi::BaseCacheEntry>> cache[2];
+    uint64_t hash_seed = 0, hash_mult = 0xD6E8FEB86659FD93ull;   // per-context key of the fingerprint (mi_msm_init: std::random_device)
+    std::shared_ptr<mi::HashPool> hash_pool[mi::NLANES];   // fingerprint helpers of the base-set cache, one pool per lane, created on first use
     int profile_level = 1;   // 0: no timing events beyond the one the pipeline waits on; 1: + the accumulate kernel's interval; 2: every phase
     mi_profile prof{};
     mi_pairing_profile pprof{};
@@ -290,37 +301,139 @@ struct mi_ctx {
 
 namespace mi {
 
-// 64-bit fingerprint of a host base vector: every byte of K = min(n, 1024) points spread evenly over the vector (the first and the last
-// included), mixed with the length.  ~100 KB of strided reads from DRAM, software-prefetched, four independent multiply-xor chains:
-// ~25 us measured for 2^20 G1 points with cold caches (4096 samples: 120 us — a page walk per sample — for no better protection).  A vector
-// REWRITTEN under the same pointer and length changes it with probability ~1; a sparse in-place edit of points outside the sample does
-// not — the cache is for immutable base sets (an SRS), which is why it is opt-in (include/arkblst_amd.h).
-inline uint64_t base_fingerprint(const uint8_t* p, size_t n, size_t aff) {
-    const size_t K = std::min<size_t>(n, 1024);
-    uint64_t h[4] = {0x9E3779B97F4A7C15ull ^ (uint64_t)n, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
-    auto at = [&](size_t j) { return p + ((K > 1 ? (j * (n - 1)) / (K - 1) : 0) * aff); };
-    for (size_t j = 0; j < K; j++) {
-        if (j + 8 < K) {
-            const uint8_t* q = at(j + 8);
-            __builtin_prefetch(q);
-            __builtin_prefetch(q + 64);
-            if (aff > 128) __builtin_prefetch(q + 128);
+// Fingerprint of a host base vector: EVERY byte (round 6; rounds 4-5 sampled 1024 points, and an in-place edit of a point outside the
+// sample was a silent hit on stale device data).  The vector is cut into slices hashed in parallel (HashPool, below); a slice is four
+// independent 64-bit chains h <- xorshift((h ^ w) * K) over interleaved 8-byte words.  Every step is a bijection of the chain's state
+// for a fixed word and of the word for a fixed state, so a change confined to ONE 8-byte word (one limb of one coordinate) always changes
+// the chain it feeds, and the folds below are bijections of each state they take in: such an edit is detected with certainty, any other
+// edit with probability 1 - 2^-64 or better.  ~10 GB/s per core (memory-bound): 96 MiB (2^20 G1 points) on five helper threads in ~2 ms,
+// under the ~3 ms of GPU work the call queues first.
+// The chains start from, and multiply by, values drawn per context from std::random_device (HashKey): the fingerprint is not a
+// cryptographic hash, but whoever fills a base vector cannot aim for a collision without knowing them.
+struct HashKey { uint64_t seed = 0, mult = 0xD6E8FEB86659FD93ull; };   // mult is odd
+struct SliceHash { uint64_t h[4]; };
+inline SliceHash hash_slice(const uint8_t* p, size_t bytes, uint64_t slice, const HashKey& key) {
+    const uint64_t K = key.mult | 1u, seed = key.seed + slice * 0x9E3779B97F4A7C15ull;
+    SliceHash s{{0x9E3779B97F4A7C15ull ^ seed, 0xC2B2AE3D27D4EB4Full + seed, 0x165667B19E3779F9ull ^ (seed << 1), 0x27D4EB2F165667C5ull + (seed << 2)}};
+    size_t i = 0;
+    for (; i + 32 <= bytes; i += 32) {
+        uint64_t w[4];
+        memcpy(w, p + i, 32);
+        for (int t = 0; t < 4; t++) {
+            s.h[t] = (s.h[t] ^ w[t]) * K;
+            s.h[t] ^= s.h[t] >> 32;
         }
-        const uint8_t* q = at(j);
-        for (size_t b = 0; b < aff; b += 32) {   // aff = 96 or 192: whole 32-byte groups
-            uint64_t w[4];
-            memcpy(w, q + b, 32);
-            for (int t = 0; t < 4; t++) {
-                h[t] = (h[t] ^ w[t]) * 0xD6E8FEB86659FD93ull;
-                h[t] ^= h[t] >> 32;
+    }
+    if (i < bytes) {   // tail of under 32 bytes (never for point vectors: 96 / 192 B per point), zero-padded, its length mixed in
+        uint64_t w[4] = {0, 0, 0, 0};
+        memcpy(w, p + i, bytes - i);
+        for (int t = 0; t < 4; t++) {
+            s.h[t] = (s.h[t] ^ w[t] ^ (uint64_t)(bytes - i)) * K;
+            s.h[t] ^= s.h[t] >> 32;
+        }
+    }
+    return s;
+}
+// slices folded in order: two different bijective folds of the same states give the two halves of the fingerprint
+inline Fp128 fold_slices(const SliceHash* s, size_t count, uint64_t total_bytes) {
+    Fp128 r{0x243F6A8885A308D3ull ^ total_bytes, 0x13198A2E03707344ull + total_bytes};
+    for (size_t k = 0; k < count; k++)
+        for (int t = 0; t < 4; t++) {
+            r.a = (r.a ^ s[k].h[t]) * 0xD6E8FEB86659FD93ull;
+            r.a ^= r.a >> 29;
+            r.b = (r.b + s[k].h[t]) * 0x9FB21C651E98DF25ull;
+            r.b ^= r.b >> 31;
+        }
+    return r;
+}
+constexpr size_t HASH_SLICE_MIN = (size_t)1 << 20;   // a slice is at least 1 MiB (smaller vectors are one slice)
+inline size_t hash_slices(size_t bytes, size_t threads) { return std::max<size_t>(1, std::min(threads, bytes / HASH_SLICE_MIN)); }
+// the fingerprint computed on the calling thread (what HashPool computes in parallel: same slicing, same value)
+inline Fp128 content_fingerprint(const uint8_t* p, size_t bytes, size_t threads, const HashKey& key = HashKey{}) {
+    const size_t S = hash_slices(bytes, threads);
+    std::vector<SliceHash> part(S);
+    for (size_t k = 0; k < S; k++) {
+        const size_t lo = (bytes / 32 * k / S) * 32, hi = k + 1 == S ? bytes : (bytes / 32 * (k + 1) / S) * 32;
+        part[k] = hash_slice(p + lo, hi - lo, (uint64_t)k, key);
+    }
+    return fold_slices(part.data(), S, bytes);
+}
+
+// Persistent helper threads that fingerprint a host base vector WHILE the calling thread queues the GPU work of the call (one pool per
+// lane of the context, created on the lane's first cached call; nothing is spawned per call — rounds 4-5 used std::async).  One job at a
+// time: start() hands out the job, finish() waits for it.  The threads only READ the caller's bases; finish() is called on every path
+// out of the MSM call, so none of them touches the vector after the call returned.
+class HashPool {
+public:
+    explicit HashPool(size_t threads, const HashKey& key = HashKey{}) : key_(key), part_(std::max<size_t>(1, threads)) {
+        for (size_t k = 0; k < part_.size(); k++) threads_.emplace_back([this, k] { loop(k); });
+    }
+    ~HashPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    HashPool(const HashPool&) = delete;
+    HashPool& operator=(const HashPool&) = delete;
+    size_t threads() const { return part_.size(); }
+    bool busy() const { return busy_; }
+    void start(const uint8_t* p, size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu_);
+        p_ = p; bytes_ = bytes;
+        slices_ = hash_slices(bytes, part_.size());
+        pending_ = slices_;
+        gen_++;
+        busy_ = true;
+        cv_.notify_all();
+    }
+    Fp128 finish() {   // start() must have been called; idempotent until the next start()
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+        busy_ = false;
+        return fold_slices(part_.data(), slices_, bytes_);
+    }
+
+private:
+    void loop(size_t k) {
+        uint64_t seen = 0;
+        for (;;) {
+            const uint8_t* p;
+            size_t bytes, S;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                p = p_; bytes = bytes_; S = slices_;
+            }
+            if (k >= S) continue;   // fewer slices than threads: nothing for this one in this job
+            const size_t lo = (bytes / 32 * k / S) * 32, hi = k + 1 == S ? bytes : (bytes / 32 * (k + 1) / S) * 32;
+            const SliceHash h = hash_slice(p + lo, hi - lo, (uint64_t)k, key_);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                part_[k] = h;
+                if (--pending_ == 0) done_cv_.notify_all();
             }
         }
     }
-    uint64_t r = h[0];
-    for (int t = 1; t < 4; t++) r = (r ^ h[t]) * 0xD6E8FEB86659FD93ull + (r >> 29);
-    return r;
+    const HashKey key_;
+    std::vector<SliceHash> part_;
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    const uint8_t* p_ = nullptr;
+    size_t bytes_ = 0, slices_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false, busy_ = false;
+};
+// helper threads per pool: a third of the host's hardware threads, 1..6 (ARKBLST_AMD_HASH_THREADS overrides, 1..16)
+inline size_t hash_pool_threads() {
+    if (const char* e = getenv("ARKBLST_AMD_HASH_THREADS")) return (size_t)std::min(16l, std::max(1l, atol(e)));
+    return std::min<size_t>(6, std::max<size_t>(1, std::thread::hardware_concurrency() / 3));
 }
-
 
 // ---- bookkeeping of the base-set cache (mi_ctx::cache, guarded by cache_mu).  Host-only and free of HIP calls, so that
 // tests/host/workers_test.cpp can run it under ThreadSanitizer / AddressSanitizer.
@@ -333,7 +446,7 @@ inline bool cache_begin(mi_ctx* ctx, int idx, const void* ptr, size_t n, std::sh
         if (e->ptr == ptr && e->n == n && (!candidate || e->stamp > candidate->stamp)) candidate = e;
     return true;
 }
-inline std::shared_ptr<BaseCacheEntry> cache_find(mi_ctx* ctx, int idx, const void* ptr, size_t n, uint64_t fp) {
+inline std::shared_ptr<BaseCacheEntry> cache_find(mi_ctx* ctx, int idx, const void* ptr, size_t n, const Fp128& fp) {
     std::lock_guard<std::mutex> lk(ctx->cache_mu);
     for (auto& e : ctx->cache[idx])
         if (e->ptr == ptr && e->n == n && e->fp == fp) return e;
@@ -342,7 +455,7 @@ inline std::shared_ptr<BaseCacheEntry> cache_find(mi_ctx* ctx, int idx, const vo
 // cache_finish: a confirmed hit is stamped; a filled entry gets its key and is published (unless the other lane published the same
 // key first, or the cache was switched off meanwhile), the least recently used entries beyond the limit leave the list — their
 // memory is freed when the last lane that still reads them drops its reference.
-inline void cache_finish(mi_ctx* ctx, int idx, const std::shared_ptr<BaseCacheEntry>& hit, const std::shared_ptr<BaseCacheEntry>& fill, uint64_t fp) {
+inline void cache_finish(mi_ctx* ctx, int idx, const std::shared_ptr<BaseCacheEntry>& hit, const std::shared_ptr<BaseCacheEntry>& fill, const Fp128& fp) {
     std::vector<std::shared_ptr<BaseCacheEntry>> dropped;   // destroyed after the lock is released
     std::lock_guard<std::mutex> lk(ctx->cache_mu);
     auto& v = ctx->cache[idx];

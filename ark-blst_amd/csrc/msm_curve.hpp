@@ -2,7 +2,6 @@
 // in msm_g1.hip and msm_g2.hip.  Replaces crate::gpu::msm + SingleMultiexpKernel::multiexp of the reference
 // (/root/reference/src/gpu.rs:126-241) behind <G{1,2}Projective as VariableBaseMSM>::msm (src/g1.rs:602-632, src/g2.rs:582-612).
 #pragma once
-#include <future>
 #include <exception>
 #include "internal.hpp"
 #include "curve_kernels.cuh"
@@ -156,16 +155,24 @@ void launch_accumulate(hipStream_t s, const uint32_t* bases, const uint32_t* sor
 
 // The pipeline on one device.  d_bases: device-form points (tables of `stride` points when shared); d_scalars: n x 32 B on device.
 //
-// A call is ONE window group on the lane's stream (small inputs, shared bucket sets), or — from 2^17 points on — up to MAX_GROUPS groups of
-// digit windows, top windows first, each with its own scratch set, PIPELINED over three streams of the lane:
-//     aux stream (high priority)   sort(0) sort(1) .. sort(G-1)  [acc(0) done] merge / reduce / combine(0)  [acc(1) done] reduce(1) ..
-//     lane stream                  [sort(0) done] accumulate(0)   [sort(2) done] accumulate(2)
-//     second accumulate stream     [sort(1) done] accumulate(1)   [sort(3) done] accumulate(3)
-// so that the sort of the later groups and the bucket reduction of the earlier ones — LDS-atomic / latency-chain work that leaves the
-// VALUs idle — run under an accumulate kernel, and the accumulate kernels of consecutive groups overlap at their ends (the waves of
-// group g + 1 take the slots the last, short items of group g give back).  What stays exposed is the sort of the first group, the
-// reduction of the last and a Horner tail of that group's windows only: the host folds the window sums of group g while the GPU still
-// works on g + 1.  The reference runs one launch and folds on the host (/root/reference/src/gpu.rs:172-209).
+// A call is ONE window group on the lane's stream (small inputs, shared bucket sets), or — from 2^17 points on — TWO groups of digit
+// windows (top windows first; up to MAX_GROUPS on request), each with its own scratch set, with the SORT of the second group hidden
+// under the accumulate kernel of the first:
+//     aux stream (high priority)   sort(0) sort(1)
+//     lane stream                  [sort(0) done] accumulate(0)   [accumulate(1) done] merge / reduce / combine(0), window sums out
+//     second accumulate stream     [sort(1) done] accumulate(1)   [accumulate(0) done] merge / reduce / combine(1), window sums out
+// What overlaps and what does not was measured, not assumed (tools/ubench_coresidency.hip, tools/pipe_scan.py):
+//   * the accumulate kernel keeps two waves of 216 registers on every SIMD and the multiply-add port busy; a workgroup fits BESIDE them when
+//     its waves need at most 80 registers per lane and SIMD — the sort and schedule kernels do (256-lane workgroups of <= 56 registers,
+//     dynamic LDS so that the compiler does not pad the allocation), their work is LDS atomics and memory, and they run at wave priority 3:
+//     the sort of group 1 costs the accumulate kernel of group 0 nothing measurable;
+//   * the bucket reduction does NOT overlap usefully: its waves (184 registers) each take the place of an accumulate wave and its additions
+//     compete for the same multiply-add port — run under accumulate(1), reduce(0) lengthened that kernel by what it takes alone.  The
+//     groups' reductions therefore start together after the last accumulate kernel, on the two accumulate streams, with the whole call's
+//     geometry: the tail is the one-group call's;
+//   * the accumulate kernels of the two groups overlap at their ends (the waves of group 1 take the slots the last, short items of group 0
+//     give back): two launches on two streams run as fast as one (tools/ubench_two_queues.hip).
+// The reference runs one launch and folds on the host (/root/reference/src/gpu.rs:172-209).
 template <class C>
 typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bases, const uint8_t* d_flags, const uint32_t* d_scalars,
                                  size_t n, unsigned fmt, bool shared, unsigned table_c, size_t stride, bool fold, WinOut* wo = nullptr,
@@ -186,15 +193,18 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     d.ensure_host((size_t)pl.bwin * jac_bytes<C>());
 
     hipStream_t sS = d.stream, sAcc[2] = {d.stream, d.stream};
+    const bool phases = d.prof_level >= 2;   // see sort_and_schedule
+    const bool trace = ctx->trace && phases;
     if (piped) {
         d.ensure_pipeline_streams();
         sS = d.aux_stream;
         sAcc[1] = d.acc2_stream;
+    }
+    if (piped || trace) {
         // the aux stream starts behind what the caller queued on the lane's stream (base conversion, a staged scalar shard)
         HIP_TRY(hipEventRecord(d.ev[10], d.stream));
-        HIP_TRY(hipStreamWaitEvent(sS, d.ev[10], 0));
+        if (piped) HIP_TRY(hipStreamWaitEvent(sS, d.ev[10], 0));
     }
-    const bool phases = d.prof_level >= 2;   // see sort_and_schedule
     std::vector<SortOut> so(G);
     // ---- phase 1: every group's sort + schedule (aux stream, in group order) and, behind its schedule, its accumulate kernel.  The
     // accumulate kernel is queued BEFORE the host learns the item count (only the merge launches need it): the read-back's latency is
@@ -213,12 +223,16 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
                              (uint32_t*)sc.partial.p);
         if (piped) HIP_TRY(hipEventRecord(sc.ev[4], sa));
     }
-    // ---- phase 2: per group, once its schedule's counts are on the host: merges of split buckets, bucket reduction, combine, window sums out
+    // ---- phase 2: per group, on ITS accumulate stream and behind EVERY group's accumulate kernel: merges of split buckets, bucket
+    // reduction, combine, window sums out.  (The host needs the schedule's counts only for the merge launches.)
     for (size_t g = 0; g < G; g++) {
         Scratch& sc = d.sc[g];
         const Plan& gp = groups[g];
+        hipStream_t sr = sAcc[g & 1];
         read_schedule(sc, so[g]);
-        if (piped) HIP_TRY(hipStreamWaitEvent(sS, sc.ev[4], 0));
+        if (piped)
+            for (size_t q = 0; q < G; q++)
+                if (sAcc[q & 1] != sr) HIP_TRY(hipStreamWaitEvent(sr, d.sc[q].ev[4], 0));   // the same stream's kernels precede anyway
         const uint32_t max_items = so[g].max_items;
         if (max_items > 1 && so[g].nlist) {
             // the fan-in tree over the items of split buckets: one launch per level; level l reads list l and appends list l + 1 (device
@@ -229,18 +243,18 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
             for (uint32_t l = 0; dd < max_items; l++, dd *= msmk::MERGE_FAN, shrink *= msmk::MERGE_FAN) {
                 if (8 + l + 1 >= msmk::MERGE_META) throw HipFail{"merge tree deeper than its counters"};
                 const uint64_t bound = std::min<uint64_t>(so[g].nlist, so[g].nlist / shrink + so[g].nsplit);
-                hipLaunchKernelGGL(msmk::k_merge<CS>, dim3((uint32_t)((bound + (1u << CS::LOG_LL) - 1) >> CS::LOG_LL)), dim3(64), 0, sS, (uint32_t*)sc.partial.p,
+                hipLaunchKernelGGL(msmk::k_merge<CS>, dim3((uint32_t)((bound + (1u << CS::LOG_LL) - 1) >> CS::LOG_LL)), dim3(64), 0, sr, (uint32_t*)sc.partial.p,
                                    (const uint32_t*)sc.item_bucket.p, (const uint32_t*)sc.woff.p, (const uint32_t*)lists[l & 1],
                                    (const uint32_t*)(l == 0 ? meta + 3 : meta + 8 + l), lists[(l + 1) & 1], meta + 8 + l + 1, (uint32_t)dd);
             }
         }
-        if (!piped && d.prof_level >= 1) HIP_TRY(hipEventRecord(sc.ev[4], sS));   // one group: the interval covers the merges as well
+        if (!piped && d.prof_level >= 1) HIP_TRY(hipEventRecord(sc.ev[4], sr));   // one group: the interval covers the merges as well
         // bucket reduction: one wave per chunk of chunk_buckets buckets -> (K S, T) pairs; then the per-window combine, 2^LOG_LL pairs per
         // wave and level, down to one Jacobian point per window
         bool reduced = false;
         if constexpr (std::is_same<C, msmk::G1C>::value) {   // the throughput form exists for G1 only (HostCurve<G2C>::cost() never asks for it)
             if (gp.serial_reduce) {
-                hipLaunchKernelGGL(msmk::k_reduce_serial<C>, dim3((uint32_t)((gp.nchunks + 63) / 64)), dim3(64), 0, sS, (const uint32_t*)sc.partial.p,
+                hipLaunchKernelGGL(msmk::k_reduce_serial<C>, dim3((uint32_t)((gp.nchunks + 63) / 64)), dim3(64), 0, sr, (const uint32_t*)sc.partial.p,
                                    (const uint32_t*)sc.woff.p, (const uint32_t*)sc.offsets.p, (uint32_t)gp.nchunks, gp.serial_L, gp.nb, gp.chunks_per_win,
                                    (uint32_t*)sc.pairs.p);
                 reduced = true;
@@ -248,10 +262,10 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
         }
         if (!reduced) {
             if (gp.serial_reduce) throw HipFail{"serial reduce requested for a curve without it"};
-            hipLaunchKernelGGL(msmk::k_reduce_coop<RS>, dim3((uint32_t)gp.nchunks), dim3(64), 0, sS, (const uint32_t*)sc.partial.p,
+            hipLaunchKernelGGL(msmk::k_reduce_coop<RS>, dim3((uint32_t)gp.nchunks), dim3(64), 0, sr, (const uint32_t*)sc.partial.p,
                                (const uint32_t*)sc.woff.p, (const uint32_t*)sc.offsets.p, (uint32_t*)sc.pairs.p, gp.coop_L, gp.nb, gp.chunks_per_win);
         }
-        if (phases) HIP_TRY(hipEventRecord(sc.ev[5], sS));
+        if (phases) HIP_TRY(hipEventRecord(sc.ev[5], sr));
         uint32_t* jac_dev = (uint32_t*)((char*)sc.pairs2.p + sc.pairs2.cap - (size_t)gp.bwin * jac_bytes<C>());
         {
             uint32_t cpw = gp.chunks_per_win;
@@ -260,21 +274,21 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
             for (;;) {
                 uint32_t cpw_out = (cpw + (1u << CS::LOG_LL) - 1) >> CS::LOG_LL;
                 const bool last = cpw_out == 1;
-                hipLaunchKernelGGL(msmk::k_combine<CS>, dim3(gp.bwin * cpw_out), dim3(64), 0, sS, (const uint32_t*)in, cpw, cpw_out, out,
+                hipLaunchKernelGGL(msmk::k_combine<CS>, dim3(gp.bwin * cpw_out), dim3(64), 0, sr, (const uint32_t*)in, cpw, cpw_out, out,
                                    last ? jac_dev : (uint32_t*)nullptr);
                 if (last) break;
                 std::swap(in, out);   // the levels shrink by 2^LOG_LL: ping-pong between the two pair buffers
                 cpw = cpw_out;
             }
         }
-        if (phases) HIP_TRY(hipEventRecord(sc.ev[6], sS));
+        if (phases) HIP_TRY(hipEventRecord(sc.ev[6], sr));
         // window sums of the group, in their place among the call's windows (window 0 first; shared bucket sets: the one sum)
         const size_t at = shared ? 0 : (size_t)gp.win0 * jac_bytes<C>();
         if (wo)   // ... they stay on the device (the caller exchanges them: mi_msm_g1_device_windows); no fold here
-            HIP_TRY(hipMemcpyAsync((char*)wo->d_out + at, jac_dev, (size_t)gp.bwin * jac_bytes<C>(), hipMemcpyDeviceToDevice, sS));
+            HIP_TRY(hipMemcpyAsync((char*)wo->d_out + at, jac_dev, (size_t)gp.bwin * jac_bytes<C>(), hipMemcpyDeviceToDevice, sr));
         else
-            HIP_TRY(hipMemcpyAsync((char*)d.h_pairs + at, jac_dev, (size_t)gp.bwin * jac_bytes<C>(), hipMemcpyDeviceToHost, sS));
-        if (phases || piped) HIP_TRY(hipEventRecord(sc.ev[7], sS));
+            HIP_TRY(hipMemcpyAsync((char*)d.h_pairs + at, jac_dev, (size_t)gp.bwin * jac_bytes<C>(), hipMemcpyDeviceToHost, sr));
+        if (phases || piped) HIP_TRY(hipEventRecord(sc.ev[7], sr));
     }
     if (wo) {
         wo->info.window_bits = pl.c;
@@ -293,6 +307,7 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
         for (int w = (int)(gp.win0 + gp.bwin) - 1; w >= (int)gp.win0; w--) r = r.dbl_n(pl.c).add(win[w]);
         fold_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
+    if (piped) HIP_TRY(hipStreamSynchronize(sS));   // nothing of this call is left on any stream (the aux stream ended with the last schedule)
     HIP_TRY(hipGetLastError());
 
     for (size_t g = 0; g < G; g++) {
@@ -301,7 +316,6 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
             d.prof.digits_ms += ev_ms(sc.ev[0], sc.ev[1]);      // digits + coarse partition (4 kernels)
             d.prof.scatter_ms += ev_ms(sc.ev[1], sc.ev[2]);     // fine sort in LDS
             d.prof.scan_ms += ev_ms(sc.ev[2], sc.ev[3]);        // schedule (3 kernels)
-            d.prof.reduce_ms += ev_ms(sc.ev[4], sc.ev[5]);   // pipelined: from the end of the group's accumulate kernel, waits behind earlier groups included
             d.prof.combine_ms += ev_ms(sc.ev[5], sc.ev[6]);
             d.prof.d2h_ms += ev_ms(sc.ev[6], sc.ev[7]);
         }
@@ -309,16 +323,38 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
         d.prof.work_items += so[g].nitems;
         d.prof.max_items_per_bucket = std::max(d.prof.max_items_per_bucket, so[g].max_items);
     }
-    // the accumulate kernel(s): one group = the kernel and the merges of split buckets; pipelined = from the first group's schedule (its
-    // accumulate kernel starts there) to the end of the LAST accumulate kernel to finish — the launches overlap, their sum would count twice
+    // accumulate_ms — one group: the kernel and the merges of split buckets; pipelined: from the first group's schedule (its accumulate
+    // kernel starts there) to the end of the LAST accumulate kernel to finish (the launches overlap: their sum would count twice; the sort
+    // of the later groups runs inside this span).  reduce_ms — pipelined: from there to the last reduce kernel's end (they run together).
     if (piped) {
-        double span = 0;
-        for (size_t g = 0; g < G; g++) span = std::max(span, ev_ms(d.sc[0].ev[3], d.sc[g].ev[4]));
+        double span = 0, red = 0;
+        size_t last = 0;
+        for (size_t g = 0; g < G; g++) {
+            const double e = ev_ms(d.sc[0].ev[3], d.sc[g].ev[4]);
+            if (e > span) { span = e; last = g; }
+        }
         d.prof.accumulate_ms += span;
-    } else if (d.prof_level >= 1) {
-        d.prof.accumulate_ms += ev_ms(d.sc[0].ev[3], d.sc[0].ev[4]);
+        if (phases) {
+            for (size_t g = 0; g < G; g++) red = std::max(red, ev_ms(d.sc[last].ev[4], d.sc[g].ev[5]));
+            d.prof.reduce_ms += red;
+        }
+    } else {
+        if (d.prof_level >= 1) d.prof.accumulate_ms += ev_ms(d.sc[0].ev[3], d.sc[0].ev[4]);
+        if (phases) d.prof.reduce_ms += ev_ms(d.sc[0].ev[4], d.sc[0].ev[5]);
     }
     d.prof.host_fold_ms += fold_ms;
+    if (trace) {   // ARKBLST_AMD_TRACE=1 with profile level 2: the call's phase boundaries on the GPU, microseconds from the call's entry
+        std::string line = "[arkblst trace] n=" + std::to_string(n) + " c=" + std::to_string(pl.c) + " groups=" + std::to_string(G) + "\n";
+        for (size_t g = 0; g < G; g++) {
+            char b[256];
+            Scratch& sc = d.sc[g];
+            auto at = [&](int k) { return ev_ms(d.ev[10], sc.ev[k]) * 1e3; };
+            snprintf(b, sizeof b, "  group %zu windows [%u,%u): sort %.0f..%.0f..%.0f sched %.0f | acc ..%.0f | reduce ..%.0f combine ..%.0f out %.0f\n", g, groups[g].win0,
+                     groups[g].win0 + groups[g].nwin, at(0), at(1), at(2), at(3), at(4), at(5), at(6), at(7));
+            line += b;
+        }
+        fputs(line.c_str(), stderr);
+    }
     return r;
 }
 
@@ -520,20 +556,22 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
             if (n > have) return fail(ctx, MI_E_INVALID, "n exceeds the resident base set");
         }
         // base-set cache (opt-in): a host base vector this context has converted before is read from HBM instead of crossing PCIe again.
-        // The fingerprint (~25-100 us of strided DRAM reads) runs on a helper thread UNDER the GPU work: an entry with the same (pointer,
-        // n) is used speculatively and confirmed before the result leaves; a miss fills its entry first and learns its key at the end.
+        // The fingerprint covers EVERY byte of the vector (round 6) and runs on the lane's persistent helper threads UNDER the GPU work: an
+        // entry with the same (pointer, n) is used speculatively and confirmed before the result leaves; a miss fills its entry first and
+        // learns its key at the end.
         constexpr size_t CACHE_MIN_POINTS = 1u << 12;   // below that the upload is cheaper than the bookkeeping is worth
         std::shared_ptr<BaseCacheEntry> hit, fill;
-        std::future<uint64_t> fp_job;
+        std::shared_ptr<HashPool> pool;
         if (bases && n >= CACHE_MIN_POINTS && cache_begin(ctx, HostCurve<C>::IDX, bases, n, hit)) {
-            try {
-                fp_job = std::async(std::launch::async, base_fingerprint, bases, n, aff_bytes<C>());
-            } catch (const std::system_error&) {   // no thread to be had: compute it here, as a ready future
-                std::promise<uint64_t> pr;
-                pr.set_value(base_fingerprint(bases, n, aff_bytes<C>()));
-                fp_job = pr.get_future();
-            }
+            std::shared_ptr<HashPool>& slot = ctx->hash_pool[lane.lane == 1 ? 1 : 0];   // this call holds the lane: the pool is its own
+            if (!slot) slot = std::make_shared<HashPool>(hash_pool_threads(), HashKey{ctx->hash_seed, ctx->hash_mult});
+            pool = slot;
+            pool->start(bases, n * aff_bytes<C>());
         }
+        struct JoinFp {   // the helper threads read the caller's bases: the job is waited for on every path out of this call
+            std::shared_ptr<HashPool>& p;
+            ~JoinFp() { if (p && p->busy()) (void)p->finish(); }
+        } join_fp{pool};
         // device-resident scalars: the shard of device k is read by device k — in place when the vector lives there, through ONE peer
         // copy of the shard otherwise (can_read)
         int owner = -1;
@@ -573,15 +611,11 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
             for (auto& d : devs) e->devs.push_back(d.dev);
             return e;
         };
-        struct JoinFp {   // the helper thread reads the caller's bases: it is joined on every path out of this call
-            std::future<uint64_t>& f;
-            ~JoinFp() { if (f.valid()) f.wait(); }
-        } join_fp{fp_job};
-        if (fp_job.valid() && !hit) fill = new_entry();
+        if (pool && !hit) fill = new_entry();
         int rc = run();
         if (rc != MI_OK) return rc;
-        if (fp_job.valid()) {
-            const uint64_t fp = fp_job.get();
+        if (pool) {
+            const Fp128 fp = pool->finish();
             if (hit && hit->fp != fp) {
                 // mis-speculation: the vector under this pointer changed since the candidate was built.  Another entry may hold the
                 // new content (a buffer that alternates between two sets); otherwise convert it now.

@@ -165,14 +165,19 @@ Plan make_plan(size_t n, unsigned forced_c, const CurveCost& cc, bool shared, si
     return best;
 }
 
-// Window groups of a pipelined call (run_msm), TOP windows first: group plans share c, the item geometry (logT / logS / class width) and
-// the sort's bit split with the whole-call plan `pl`; each has its own bucket windows and reduce geometry.  weights: relative sizes of the
+// Window groups of a pipelined call (run_msm), TOP windows first: group plans share c, the item geometry (logT / logS / class width), the
+// sort's bit split and the reduce geometry with the whole-call plan `pl`; each has its own bucket windows.  weights: relative sizes of the
 // groups (empty = the built-in choice, {1} = one group); a weight list longer than the window count is cut.
 std::vector<Plan> split_plan(const Plan& pl, const CurveCost& cc, size_t n, bool shared, const std::vector<unsigned>& weights) {
+    (void)cc;
     std::vector<unsigned> w = weights;
     if (w.empty()) {
-        // built-in: one group until the overlap pays on this hardware (measurements: DESIGN.md)
-        w = {1};
+        // built-in: two groups from 2^20 points on, the first with a quarter (c <= 16) or a third (three-level sort, c >= 17) of the windows —
+        // its sort is the exposed one, and its accumulate kernel is long enough to cover the sort of the rest.  Same-box A/B
+        // (profiles/r06_pipe_scan_*.jsonl): 2^20 -2 %, 2^22 -3 %, 2^24 -3..4 %; below 2^20 the call is a sum of latency chains that more
+        // launches only lengthen (2^18: +4 %)
+        if (n >= ((size_t)1 << 20) && pl.nwin >= 8) w = pl.c >= 17 ? std::vector<unsigned>{1, 2} : std::vector<unsigned>{1, 3};
+        else w = {1};
     }
     if (w.size() > (size_t)MAX_GROUPS) w.resize(MAX_GROUPS);
     if (w.size() > pl.nwin) w.resize(pl.nwin);
@@ -208,8 +213,9 @@ std::vector<Plan> split_plan(const Plan& pl, const CurveCost& cc, size_t n, bool
         top -= cnt[g];
         p.win0 = top;
         p.nbuckets = (uint64_t)p.nb * p.bwin;
-        ReduceCost rc;
-        if (!reduce_geometry(p, cc, rc)) return {pl};
+        // the reduce geometry (buckets per lane, chunk size) stays the whole call's: the groups' reductions run TOGETHER after the last
+        // accumulate kernel (run_msm), and all their waves together fill one round of wave slots, as the single launch of a one-group call does
+        p.nchunks = (uint64_t)p.chunks_per_win * p.bwin;
         out.push_back(p);
     }
     return out;
@@ -251,7 +257,7 @@ void launch_coarse_staged(uint32_t c, dim3 grid, hipStream_t s, const uint32_t* 
         throw HipFail{"staged coarse scatter: window_bits out of range"};
     } else {
         if (c == CB)
-            hipLaunchKernelGGL((msmk::k_coarse_staged<CB>), grid, dim3(256), 0, s, scalars, flags, g, tilecnt, tileoff, bin_base, coarse);
+            hipLaunchKernelGGL((msmk::k_coarse_staged<CB>), grid, dim3(256), msmk::COARSE_STAGED_LDS, s, scalars, flags, g, tilecnt, tileoff, bin_base, coarse);
         else
             launch_coarse_staged<CB + 1>(c, grid, s, scalars, flags, g, tilecnt, tileoff, bin_base, coarse);
     }
@@ -357,7 +363,7 @@ void sort_and_schedule(DevState& d, Scratch& sc, hipStream_t s, const Plan& pl, 
                            (const uint32_t*)sc.seg_base.p, nbinsA, pl.lo_bits, mid_bits, (uint32_t*)sc.segcnt.p);
         hipLaunchKernelGGL(msmk::k_mid_scan, dim3(nbinsA), dim3(512), 0, s, (const uint32_t*)sc.binA_base.p, (const uint32_t*)sc.seg_base.p, mid_bits,
                            (const uint32_t*)sc.segcnt.p, (uint32_t*)sc.segoff.p, (uint32_t*)sc.bin_base.p, nbinsA);
-        hipLaunchKernelGGL(msmk::k_mid_scatter, dim3(segs_capA), dim3(256), 0, s, (const uint2*)sc.coarseA.p, (const uint32_t*)sc.binA_base.p,
+        hipLaunchKernelGGL(msmk::k_mid_scatter, dim3(segs_capA), dim3(256), msmk::MID_SCATTER_LDS, s, (const uint2*)sc.coarseA.p, (const uint32_t*)sc.binA_base.p,
                            (const uint32_t*)sc.seg_base.p, nbinsA, pl.lo_bits, mid_bits, (const uint32_t*)sc.segcnt.p, (const uint32_t*)sc.segoff.p,
                            (uint32_t*)sc.coarse.p);
     } else {
@@ -368,14 +374,8 @@ void sort_and_schedule(DevState& d, Scratch& sc, hipStream_t s, const Plan& pl, 
     const bool staged = !shared_buckets && g.H <= 128 && pl.c <= 16 && n >= 4096;
     uint32_t coarse_block;
     if (staged) {
-        // runs of (tile, bin): tile_pts / H entries.  Beside an accumulate kernel, whose gathers turn the L2 over several times per launch, a
-        // 32-entry run (128 B, two partial lines) is evicted before its neighbours complete the lines and reaches HBM as read-modify-writes
-        // (k_coarse_staged: 45 -> 430 us); fewer windows per workgroup keep the runs at >= 64 entries
-        uint32_t stage_bins = msmk::COARSE_STAGE_BINS;
-        if (under_accumulate) stage_bins = 256;
-        if (const char* e = getenv("MI_EXP_STAGE_BINS")) stage_bins = (uint32_t)atoi(e);
-        g.wgroup = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(pl.nwin, 16), stage_bins / g.H));
-        g.tile_pts = (msmk::COARSE_STAGE / g.wgroup) / 512 * 512;   // >= 1024 points; tile_pts * wgroup entries fit the staging buffer
+        g.wgroup = std::min<uint32_t>(std::min<uint32_t>(pl.nwin, 16), msmk::COARSE_STAGE_BINS / g.H);
+        g.tile_pts = (msmk::COARSE_STAGE / g.wgroup) / 256 * 256;   // >= 768 points; tile_pts * wgroup entries fit the staging buffer
         coarse_block = 256;   // as k_coarse_staged
     } else {
         size_t want = std::max<size_t>(std::max<size_t>(4096, n / 512), (size_t)64 * g.H / (shared_buckets ? pl.nwin : 1));
@@ -411,7 +411,7 @@ void sort_and_schedule(DevState& d, Scratch& sc, hipStream_t s, const Plan& pl, 
                        (const uint32_t*)sc.seg_base.p, g, (uint32_t*)sc.segcnt.p);
     hipLaunchKernelGGL(msmk::k_fine_scan, dim3(g.nbins), dim3(256), 0, s, (const uint32_t*)sc.seg_base.p, g, (const uint32_t*)sc.segcnt.p,
                        (uint32_t*)sc.segoff.p, (uint32_t*)sc.hist.p);
-    hipLaunchKernelGGL(msmk::k_fine_scatter, dim3(segs_cap), dim3(256), 0, s, (const uint32_t*)sc.coarse.p, (const uint32_t*)sc.bin_base.p,
+    hipLaunchKernelGGL(msmk::k_fine_scatter, dim3(segs_cap), dim3(256), msmk::FINE_SCATTER_LDS, s, (const uint32_t*)sc.coarse.p, (const uint32_t*)sc.bin_base.p,
                        (const uint32_t*)sc.seg_base.p, g, (const uint32_t*)sc.segcnt.p, (const uint32_t*)sc.segoff.p, (uint32_t*)sc.sorted.p);
     if (phases) HIP_TRY(hipEventRecord(sc.ev[2], s));
     // ---- schedule: <= SCHED_MAX_BLK blocks of SCHED_NT lanes, each lane owning per_blk / SCHED_NT consecutive buckets

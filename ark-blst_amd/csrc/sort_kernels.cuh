@@ -73,8 +73,14 @@ __global__ void __launch_bounds__(1024) k_coarse(const uint32_t* __restrict__ sc
 // group of windows small enough that ALL its entries fit in LDS (<= 16384 entries, 64 KB), counting-sorts them by bin there
 // (positions from the tile's own counts) and writes them out in order: every (tile, bin) run — >= 32 entries — leaves as
 // consecutive words instead of one 4-byte store per entry through an LDS cursor.
-constexpr uint32_t COARSE_STAGE = 16384;
+// LDS of the staged kernels below is DYNAMIC (extern __shared__, the size passed at launch; round 6).  With a large static array the
+// compiler derives the kernel's maximum occupancy from it and PADS the register allocation up to the most that occupancy allows (72 KB
+// and 256 lanes: two waves per SIMD, so 176 registers are allocated for a kernel that uses 52; 36 KB: 104 for one that uses 20 — read off the
+// kernel descriptors, tools/kernel_resources.py).  Alone that costs nothing; beside an accumulate kernel, which leaves 80 registers per
+// lane and SIMD, such a workgroup waits for accumulate waves to retire on all four SIMDs of a compute unit (tools/ubench_coresidency.hip).
+constexpr uint32_t COARSE_STAGE = 14336;   // entries staged per workgroup; with the three bin arrays below 62 KB, under the 64 KB a launch may ask for without a function attribute
 constexpr uint32_t COARSE_STAGE_BINS = 512;
+constexpr uint32_t COARSE_STAGED_LDS = (COARSE_STAGE + 3 * COARSE_STAGE_BINS + 1) * 4;
 template <int CB>
 __global__ void __launch_bounds__(256) k_coarse_staged(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flags, SortGeom g,
                                                        const uint32_t* __restrict__ tilecnt, const uint32_t* __restrict__ tileoff,
@@ -82,8 +88,11 @@ __global__ void __launch_bounds__(256) k_coarse_staged(const uint32_t* __restric
     aux_priority();
     // 256 lanes, two bins per lane (round 6; it was 512 lanes): one wave per SIMD with 56 registers finds room beside the two resident waves
     // of an accumulate kernel (2 x 216 of 512 registers per lane), two did not — in a pipelined call this kernel runs under one (see AUX_BLOCK)
-    __shared__ uint32_t stage[COARSE_STAGE];
-    __shared__ uint32_t lstart[COARSE_STAGE_BINS + 1], cur[COARSE_STAGE_BINS], goff[COARSE_STAGE_BINS];
+    extern __shared__ uint32_t dyn_lds[];
+    uint32_t* const stage = dyn_lds;                                  // [COARSE_STAGE]
+    uint32_t* const lstart = stage + COARSE_STAGE;                    // [COARSE_STAGE_BINS + 1]
+    uint32_t* const cur = lstart + COARSE_STAGE_BINS + 1;             // [COARSE_STAGE_BINS]
+    uint32_t* const goff = cur + COARSE_STAGE_BINS;                   // [COARSE_STAGE_BINS]
     constexpr uint32_t NT = 256;
     static_assert(COARSE_STAGE_BINS == 2 * NT, "two bins per lane");
     const uint32_t tile = blockIdx.x, grp = blockIdx.y, t = threadIdx.x;
@@ -195,6 +204,7 @@ __global__ void __launch_bounds__(1024) k_binscan(const uint32_t* __restrict__ i
 //                 bin; emits hist[window][bucket]
 //   k_fine_scatter per segment: LDS cursors seeded from segcnt -> sorted[]
 constexpr uint32_t FINE_SEG = 8192;
+constexpr uint32_t FINE_SCATTER_LDS = (FINE_SEG + 257 + 256 + 256 + 4) * 4;
 
 __global__ void __launch_bounds__(256) k_seg_count(const uint32_t* __restrict__ bin_base, uint32_t nbins, uint32_t* __restrict__ seg_cnt) {
     aux_priority();
@@ -285,9 +295,12 @@ __global__ void __launch_bounds__(256) k_fine_scatter(const uint32_t* __restrict
                                                       const uint32_t* __restrict__ segcnt, const uint32_t* __restrict__ segoff,
                                                       uint32_t* __restrict__ sorted) {
     aux_priority();
-    __shared__ uint32_t stage[FINE_SEG];
-    __shared__ uint32_t lstart[257], cur[256], goff[256];
-    __shared__ uint32_t sb[4];
+    extern __shared__ uint32_t dyn_lds[];   // dynamic: see COARSE_STAGE
+    uint32_t* const stage = dyn_lds;        // [FINE_SEG]
+    uint32_t* const lstart = stage + FINE_SEG;   // [257]
+    uint32_t* const cur = lstart + 257;     // [256]
+    uint32_t* const goff = cur + 256;       // [256]
+    uint32_t* const sb = goff + 256;        // [4]
     uint32_t t = threadIdx.x, seg = blockIdx.x;
     if (t == 0) {
         uint32_t bin = 0, beg = 0, end = 0;
@@ -344,6 +357,7 @@ __global__ void __launch_bounds__(256) k_fine_scatter(const uint32_t* __restrict
 //             the one-step coarse pass leaves them.
 constexpr uint32_t A_BITS = 5, A_BINS = 1u << A_BITS;
 constexpr uint32_t MID_MAX = 512;
+constexpr uint32_t MID_SCATTER_LDS = (8192 + 3 * MID_MAX + 1 + 4) * 4;   // FINE_SEG entries + the three sub-bin arrays
 
 template <bool SCATTER, int CB>
 __global__ void __launch_bounds__(1024) k_coarseA(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flags, SortGeom g,
@@ -453,9 +467,12 @@ __global__ void __launch_bounds__(256) k_mid_scatter(const uint2* __restrict__ c
                                                      const uint32_t* __restrict__ segcnt, const uint32_t* __restrict__ segoff,
                                                      uint32_t* __restrict__ coarse) {
     aux_priority();
-    __shared__ uint32_t stage[FINE_SEG];
-    __shared__ uint32_t lstart[MID_MAX + 1], cur[MID_MAX], goff[MID_MAX];
-    __shared__ uint32_t sb[4];
+    extern __shared__ uint32_t dyn_lds[];   // dynamic: see COARSE_STAGE
+    uint32_t* const stage = dyn_lds;                 // [FINE_SEG]
+    uint32_t* const lstart = stage + FINE_SEG;       // [MID_MAX + 1]
+    uint32_t* const cur = lstart + MID_MAX + 1;      // [MID_MAX]
+    uint32_t* const goff = cur + MID_MAX;            // [MID_MAX]
+    uint32_t* const sb = goff + MID_MAX;             // [4]
     const uint32_t t = threadIdx.x, seg = blockIdx.x;
     if (t == 0) {
         uint32_t bin = 0, beg = 0, end = 0;

@@ -77,8 +77,9 @@ inline mi_ctx* context() {
         if (rc != MI_OK) throw std::runtime_error(std::string("Cannot initialize MI355X MSM context: ") + mi_msm_strerror(rc));
         // The trait call is stateless (`msm(&[G1Affine], &[Scalar])`, src/g1.rs:604) while a prover's base vectors are a fixed SRS: keep the
         // device form of the last two base vectors per group, so that the second call with the same slice runs the resident path
-        // (include/arkblst_amd.h, mi_msm_set_base_cache, with its contract: base vectors are not edited in place between calls).
-        // ARKBLST_AMD_BASE_CACHE=0 in the environment switches it off (read by mi_msm_init; it overrides this call).
+        // (include/arkblst_amd.h, mi_msm_set_base_cache).  The cache is keyed by a fingerprint of EVERY byte of the vector (round 6), computed
+        // on helper threads under the GPU work and confirmed before the result leaves: the call stays a function of its arguments, also for a
+        // caller that edits single points in place.  ARKBLST_AMD_BASE_CACHE=0 in the environment switches it off (read by mi_msm_init).
         mi_msm_set_base_cache(c, 2);
         return c;
     }();

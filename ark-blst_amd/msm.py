@@ -17,8 +17,9 @@ def default_context() -> Context:
     global _default_ctx
     if _default_ctx is None:
         _default_ctx = Context()
-        # the trait call carries no handle: keep the device form of the last two base vectors (mi_msm_set_base_cache and its contract,
-        # include/arkblst_amd.h); ARKBLST_AMD_BASE_CACHE=0 in the environment switches it off
+        # the trait call carries no handle: keep the device form of the last two base vectors (mi_msm_set_base_cache, include/arkblst_amd.h:
+        # keyed by a fingerprint of every byte of the vector, so msm() stays a function of its arguments); ARKBLST_AMD_BASE_CACHE=0 in the
+        # environment switches it off
         _default_ctx.set_base_cache(2)
     return _default_ctx
 

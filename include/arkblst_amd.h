@@ -138,15 +138,17 @@ int mi_msm_g2(mi_ctx *ctx, const mi_g2_affine *bases, const uint8_t *scalars, si
  * prover with a fixed SRS passes the same host base vector on every call, and the call above converts and uploads it every time (as the
  * reference does, src/gpu.rs:149: 6.2 ms instead of 4.1 ms at 2^20 points).  With `entries` > 0 the context keeps the device form of the
  * last `entries` base vectors per group it was given (mi_msm_g{1,2} with bases != NULL, n >= 4096; least recently used out first), keyed
- * by (host pointer, n, a 64-bit fingerprint of every byte of 1024 points spread evenly over the vector — ~25 us, computed on a helper thread
- * under the GPU work: an entry with the same pointer and n is used speculatively and confirmed before the result leaves).  A
- * hit runs the resident path: the bases do not cross PCIe.  A miss costs what the uncached call costs (the conversion writes into the new
- * entry).  CONTRACT: the fingerprint catches a vector that was rewritten or reallocated under the same address with probability ~1; it
- * does NOT see an in-place edit of a few points outside the sample.  A caller that edits single points of a base vector between calls
- * keeps the cache off or calls mi_msm_invalidate_base_cache.  Default: off (entries = 0).  The environment variable
- * ARKBLST_AMD_BASE_CACHE=<entries> (0 = off), read by mi_msm_init, overrides this call: an operator can switch the cache of a shim that
- * enables it (INTEGRATION.md §2 does) off without rebuilding anything.  Memory: 128 B (G1) / 256 B (G2) of HBM per cached point.
- * No counterpart in the reference. */
+ * by (host pointer, n, a 128-bit fingerprint of EVERY byte of the vector).  The fingerprint runs on a few persistent helper threads of the
+ * context (a third of the host's hardware threads, at most 6; ARKBLST_AMD_HASH_THREADS overrides) UNDER the GPU work of the call: an entry with
+ * the same pointer and n is used speculatively and confirmed before the result leaves — 96 MiB (2^20 G1 points) take ~2 ms on five threads, the
+ * call ~3 ms.  A hit runs the resident path: the bases do not cross PCIe.  A miss costs what the uncached call costs (the conversion writes
+ * into the new entry).  EXACTNESS: an in-place change confined to one 8-byte word (one limb of one coordinate) changes the fingerprint with
+ * certainty, any other change with probability 1 - 2^-64 or better; the chains are keyed per context from std::random_device, so whoever
+ * supplies base vectors cannot aim for a collision (rounds 4-5 fingerprinted a 1024-point sample and could serve stale bases after an edit
+ * outside it).  The call therefore stays a function of its arguments, as the reference's is (src/g1.rs:604).  Default: off (entries = 0); the
+ * trait shims (host/ark_blst_amd.hpp, msm.py) switch it on.  The environment variable ARKBLST_AMD_BASE_CACHE=<entries>
+ * (0 = off), read by mi_msm_init, overrides this call: an operator can switch the cache of a shim off without rebuilding anything.
+ * Memory: 128 B (G1) / 256 B (G2) of HBM per cached point.  No counterpart in the reference. */
 #define MI_BASE_CACHE_MAX 4
 int mi_msm_set_base_cache(mi_ctx *ctx, unsigned entries);
 int mi_msm_invalidate_base_cache(mi_ctx *ctx);

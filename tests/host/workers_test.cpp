@@ -118,27 +118,54 @@ int main() {
             CHECK(next == n);
         }
     }
-    // 6. base-set cache (round 5): the fingerprint and the bookkeeping that msm_impl drives from two lanes at once
+    // 6. base-set cache: the fingerprint (round 6: EVERY byte) and the bookkeeping that msm_impl drives from two lanes at once
     {
-        // fingerprint: equal content -> equal value; any byte of a SAMPLED point, the length, or the first / last point changes it
+        // equal content -> equal value; the length and ANY single byte change it (a change inside one 8-byte word: with certainty)
         const size_t n = 50000, aff = 96;
         std::vector<uint8_t> a(n * aff), b;
         for (size_t i = 0; i < a.size(); i++) a[i] = (uint8_t)(i * 131 + (i >> 7));
         b = a;
-        const uint64_t fa = base_fingerprint(a.data(), n, aff);
-        CHECK(fa == base_fingerprint(b.data(), n, aff));
-        CHECK(fa != base_fingerprint(a.data(), n - 1, aff));
-        b[0] ^= 1;                          CHECK(fa != base_fingerprint(b.data(), n, aff)); b = a;
-        b[(n - 1) * aff + 95] ^= 0x80;      CHECK(fa != base_fingerprint(b.data(), n, aff)); b = a;
-        const size_t K = 1024;
-        for (size_t j : {1ul, 511ul, 1022ul}) {   // sampled indices: floor(j (n - 1) / (K - 1))
-            b[(j * (n - 1) / (K - 1)) * aff + 40] += 3;
-            CHECK(fa != base_fingerprint(b.data(), n, aff));
-            b = a;
+        for (size_t threads : {1ul, 3ul, 6ul}) {
+            const Fp128 fa = content_fingerprint(a.data(), n * aff, threads);
+            CHECK(fa == content_fingerprint(b.data(), n * aff, threads));
+            CHECK(fa != content_fingerprint(a.data(), (n - 1) * aff, threads));
+            // one bit of one limb of points all over the vector, sampled by the old fingerprint or not (index 1 of 50000 was not)
+            for (size_t i : {0ul, 1ul, 2ul, 777ul, 24999ul, 25000ul, 33333ul, 49998ul, 49999ul}) {
+                for (size_t off : {0ul, 47ul, 48ul, 95ul}) {
+                    b[i * aff + off] ^= 0x10;
+                    CHECK(fa != content_fingerprint(b.data(), n * aff, threads));
+                    b[i * aff + off] ^= 0x10;
+                }
+            }
+            CHECK(fa == content_fingerprint(b.data(), n * aff, threads));
         }
-        CHECK(base_fingerprint(a.data(), 1, aff) != base_fingerprint(a.data() + aff, 1, aff));
-        std::vector<uint8_t> g2(3000 * 192, 7);
-        (void)base_fingerprint(g2.data(), 3000, 192);   // 192-byte points: whole 32-byte groups, no read past the end (ASan)
+        // two points exchanged: the same multiset of words in other positions
+        memcpy(&b[10 * aff], &a[20 * aff], aff); memcpy(&b[20 * aff], &a[10 * aff], aff);
+        CHECK(content_fingerprint(a.data(), n * aff, 4) != content_fingerprint(b.data(), n * aff, 4));
+        b = a;
+        CHECK(content_fingerprint(a.data(), aff, 4) != content_fingerprint(a.data() + aff, aff, 4));
+        std::vector<uint8_t> odd(1000 * 192 + 13, 7);   // a length that is not a multiple of 32: the tail is read, not overrun (ASan)
+        const Fp128 fo = content_fingerprint(odd.data(), odd.size(), 4);
+        odd.back() ^= 1;
+        CHECK(fo != content_fingerprint(odd.data(), odd.size(), 4));
+        // the persistent helper pool computes the same value, job after job, from whichever thread holds it (TSan: no race on its state)
+        {
+            HashPool pool(5);
+            std::vector<uint8_t> big(((size_t)7 << 20) + 96 * 5, 0);
+            for (size_t i = 0; i < big.size(); i++) big[i] = (uint8_t)(i * 2654435761u >> 13);
+            for (int round = 0; round < 40; round++) {
+                const size_t bytes = round % 3 == 0 ? big.size() : round % 3 == 1 ? (size_t)96 * 4096 : n * aff;
+                const uint8_t* src = round % 3 == 2 ? a.data() : big.data();
+                CHECK(!pool.busy());
+                pool.start(src, bytes);
+                CHECK(pool.busy());
+                const Fp128 got = pool.finish();
+                CHECK(got == content_fingerprint(src, bytes, pool.threads()));
+                big[(size_t)round * 1000] ^= 1;   // the caller may rewrite the vector between two jobs
+            }
+            std::thread other([&] { pool.start(a.data(), n * aff); (void)pool.finish(); });   // handed to another thread between jobs
+            other.join();
+        }
         // bookkeeping under contention: four threads, three base vectors, a two-entry cache, entries without device memory
         mi_ctx ctx;
         ctx.cache_entries = 2;
@@ -152,7 +179,7 @@ int main() {
                 const uint8_t* ptr = sets[k].data();
                 std::shared_ptr<BaseCacheEntry> hit, fill;
                 if (!cache_begin(&ctx, 0, ptr, 8192, hit)) { bad++; continue; }
-                const uint64_t fp = base_fingerprint(ptr, 8192, aff);
+                const Fp128 fp = content_fingerprint(ptr, 8192 * aff, 4);
                 if (hit && hit->fp != fp) hit = cache_find(&ctx, 0, ptr, 8192, fp);
                 if (hit && (hit->ptr != ptr || hit->fp != fp)) bad++;
                 if (!hit) {
@@ -175,7 +202,7 @@ int main() {
         sets[0][5] ^= 0xff;
         std::shared_ptr<BaseCacheEntry> cand;
         CHECK(cache_begin(&ctx, 0, sets[0].data(), 8192, cand));
-        if (cand) CHECK(cand->fp != base_fingerprint(sets[0].data(), 8192, aff));
+        if (cand) CHECK(cand->fp != content_fingerprint(sets[0].data(), 8192 * aff, 4));
         ctx.cache_entries = 0;
         std::shared_ptr<BaseCacheEntry> none;
         CHECK(!cache_begin(&ctx, 0, sets[1].data(), 8192, none));

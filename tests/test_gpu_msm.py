@@ -664,7 +664,8 @@ def test_validated_bases_fold_signs_with_identical_results(pkg, co, group):
 @pytest.mark.parametrize("group", ["g1", "g2"])
 def test_base_set_cache_for_the_stateless_call(pkg, co, group):
     """mi_msm_g{1,2} with host bases and the base-set cache on.  Second call with the same slice = a hit, same point as the
-    uncached context and the C oracle; a slice REWRITTEN in place (a sampled point: the first) misses and gives the new value; three
+    uncached context and the C oracle; a slice REWRITTEN in place misses and gives the new value (single-point edits anywhere:
+    test_base_set_cache_sees_every_byte); three
     slices through a two-entry cache evict the least recently used; invalidate empties it; below 4096 points nothing is cached;
     ARKBLST_AMD_BASE_CACHE=0 overrides the call."""
     import numpy as np
@@ -727,6 +728,58 @@ def test_base_set_cache_for_the_stateless_call(pkg, co, group):
         for x in th: x.join()
         assert _canon(co, group, res[0]) == want[1] and _canon(co, group, res[1]) == want[1]
         assert c.base_cache_stats()["entries"] == 1
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_base_set_cache_sees_every_byte(pkg, co, group):
+    """VERDICT r05 #4 / ADVICE r05 (high): the cache's fingerprint covers EVERY byte of the base vector (rounds 4-5 sampled 1024 points, and an
+    edit outside the sample was a silent hit on stale device data).  One limb of a point the old sample skipped (index 1 of 6000; one deep
+    inside a 2^16-point vector that is hashed in several slices) is changed in place between two calls: the call returns the oracle's NEW sum
+    and counts a miss; restoring the bytes is a hit on the first entry again.  Also through the trait mirror's default context (msm.py), whose
+    cache is on by default."""
+    import numpy as np
+
+    aff = 96 if group == "g1" else 192
+    for n, idx in ((6000, 1), (1 << 16, 40001)):
+        a = np.frombuffer(co.gen_bases(group, 911, n, 8), dtype=np.uint8).copy()
+        other = np.frombuffer(co.gen_bases(group, 912, n, 8), dtype=np.uint8)
+        sc = co.gen_scalars(913, n)
+        want = co.to_affine(group, co.msm(group, a.tobytes(), sc, n, 0, 8))
+        with pkg.Context([0]) as c:
+            c.set_base_cache(4)                                                  # room for the three versions of the vector below
+            for _ in range(2):
+                assert _canon(co, group, c.msm(group, a, sc, n, 0)) == want
+            assert c.base_cache_stats()["hits"] == 1
+            keep = a[idx * aff:(idx + 1) * aff].copy()
+            a[idx * aff:(idx + 1) * aff] = other[idx * aff:(idx + 1) * aff]     # another valid point, same address, same length
+            changed = co.to_affine(group, co.msm(group, a.tobytes(), sc, n, 0, 8))
+            assert changed != want
+            assert _canon(co, group, c.msm(group, a, sc, n, 0)) == changed
+            st = c.base_cache_stats()
+            assert (st["hits"], st["misses"]) == (1, 2), st
+            # ONE limb (8 bytes of x) of that point restored, the rest not: not a curve point any more, but the call must not serve either cached set —
+            # compare against the oracle on exactly these bytes
+            a[idx * aff:idx * aff + 8] = keep[:8]
+            if bytes(a[idx * aff:idx * aff + 8]) != bytes(other[idx * aff:idx * aff + 8]):
+                assert c.base_cache_stats()["misses"] == 2
+                c.msm(group, a, sc, n, 0)                                        # value undefined (off-curve input), the bookkeeping is not
+                assert c.base_cache_stats()["misses"] == 3
+            a[idx * aff:(idx + 1) * aff] = keep
+            assert _canon(co, group, c.msm(group, a, sc, n, 0)) == want
+            assert c.base_cache_stats()["hits"] == 2                              # the first entry, found again by content
+    # the trait mirror: msm(bases, scalars) is a pure function of its arguments, cache or not
+    from ark_blst_amd import msm as trait
+
+    cls = trait.G1Projective if group == "g1" else trait.G2Projective
+    n = 6000
+    a = np.frombuffer(co.gen_bases(group, 921, n, 8), dtype=np.uint8).copy()
+    other = np.frombuffer(co.gen_bases(group, 922, n, 8), dtype=np.uint8)
+    sc = co.gen_scalars(923, n)
+    for step in range(3):
+        got = cls.msm(a, sc, scalar_fmt=0)
+        assert _canon(co, group, got) == co.to_affine(group, co.msm(group, a.tobytes(), sc, n, 0, 8)), step
+        j = 1 + 37 * step
+        a[j * aff:(j + 1) * aff] = other[j * aff:(j + 1) * aff]
 
 
 @pytest.mark.parametrize("group", ["g1", "g2"])
@@ -1354,3 +1407,67 @@ def test_plain_set_bases_gives_back_the_table_allocation(pkg, co):
         assert free_plain - free_tables > 400 << 20, (free_tables, free_plain)
         sc = co.gen_scalars(SEED_S + 280, 1000)
         assert _canon(co, "g1", c.msm("g1", None, sc, 1000, pkg.SCALAR_CANONICAL)) == co.dlog_expected("g1", sc, SEED_B + 280, 1000)
+
+
+@pytest.mark.parametrize("group,n,c,weights", [
+    ("g1", 70000, 0, [1, 3]), ("g1", 70000, 0, [1, 1]), ("g1", 70000, 0, [2, 1, 1]), ("g1", 70000, 0, [1, 2, 2, 1]), ("g1", 70000, 0, [1, 100]),
+    ("g1", 9000, 11, [1, 3]), ("g1", 33000, 15, [3, 1]), ("g1", 150000, 18, [1, 2]), ("g1", 150000, 20, [1, 1, 1]),
+    ("g2", 20000, 0, [1, 3]), ("g2", 20000, 13, [1, 1, 1, 1])])
+def test_window_group_pipeline_is_bit_exact(pkg, co, group, n, c, weights):
+    """Round 6: a call processed as window groups — per-group scratch, the sort of group g + 1 under the accumulate
+    kernel of group g on a second stream, reductions together at the end — returns the point of the one-group call and of the oracle, for
+    every weighting (a group of one window included), window size (two- and three-level sort), resident or host bases, canonical or
+    Montgomery scalars, host or device scalars, a validated set (sign fold: one window fewer at c = 15), and scalars that overfill buckets
+    (merge launches inside the pipeline).  mi_profile.window_groups reports the groups."""
+    import torch
+
+    bases = co.gen_bases(group, 0x6A0 + n, n, 8)
+    sc = co.gen_scalars(0x6A1 + n, n)
+    want = co.to_affine(group, co.msm(group, bases, sc, n, 0, 8))
+    skew = bytearray(sc)                       # a quarter of the scalars share four values: buckets beyond T entries, split and merged
+    for i in range(0, n, 4):
+        skew[32 * i:32 * i + 32] = sc[32 * (i % 16):32 * (i % 16) + 32]
+    skew = bytes(skew)
+    want_skew = co.to_affine(group, co.msm(group, bases, skew, n, 0, 8))
+    with pkg.Context([0]) as cx:
+        cx.set_window_bits(c)
+        cx.set_bases(group, bases, n)
+        for w in ([1], weights):
+            cx.set_pipeline(w)
+            assert _canon(co, group, cx.msm(group, None, sc, n, 0)) == want                    # resident bases, host scalars (chunked H2D)
+            assert cx.profile()["window_groups"] == (1 if w == [1] else min(len(w), cx.profile()["num_windows"]))
+            assert _canon(co, group, cx.msm(group, bases, co.fr_to_mont(sc), n, 1)) == want     # host bases, Montgomery scalars
+            d = torch.frombuffer(bytearray(skew), dtype=torch.uint8).cuda()
+            torch.cuda.synchronize()
+            assert _canon(co, group, cx.msm_device(group, d.data_ptr(), n, 0)) == want_skew     # device scalars, overfull buckets
+            assert cx.profile()["max_items_per_bucket"] > 1
+        assert cx.validate_bases(group) == 0
+        assert _canon(co, group, cx.msm(group, None, sc, n, 0)) == want                        # pipelined + sign fold
+        cx.set_pipeline(None)
+        cx.set_window_bits(0)
+
+
+def test_window_group_pipeline_default_and_device_windows(pkg, co):
+    """The built-in choice pipelines from 2^20 points on (two groups), not below; the exchange path (device_windows: window sums left in device
+    memory, per group at its window offset) folds to the same point."""
+    import torch
+
+    n = 1 << 20
+    bases = co.gen_bases("g1", 0x6B0, n, 16)
+    sc = co.gen_scalars(0x6B1, n)
+    want = co.dlog_expected("g1", sc, 0x6B0, n)
+    d = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+    out = torch.zeros(37 * 144, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with pkg.Context([0]) as cx:
+        cx.set_bases("g1", bases, n)
+        assert _canon(co, "g1", cx.msm_device("g1", d.data_ptr(), n, 0)) == want and cx.profile()["window_groups"] == 2
+        assert _canon(co, "g1", cx.msm_device("g1", d.data_ptr(), 1 << 18, 0)) == co.dlog_expected("g1", sc[:32 << 18], 0x6B0, 1 << 18)
+        assert cx.profile()["window_groups"] == 1
+        info = cx.msm_device_windows("g1", d.data_ptr(), n, 0, out.data_ptr())
+        torch.cuda.synchronize()
+        assert cx.profile()["window_groups"] == 2
+        folded = pkg.fold_windows("g1", out.cpu().numpy().tobytes(), 1, pkg.MAX_WINDOWS, *info)
+        assert _canon(co, "g1", folded) == want
+        cx.set_pipeline([1])
+        assert _canon(co, "g1", cx.msm_device("g1", d.data_ptr(), n, 0)) == want and cx.profile()["window_groups"] == 1

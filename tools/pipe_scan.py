@@ -36,6 +36,8 @@ def weights(conf):
 
 with pkg.Context([0]) as ctx:
     ctx.set_bases(g, bases, nmax)
+    if "--level2" in flags:
+        ctx.set_profile_level(2)
     if validated:
         assert ctx.validate_bases(g) == 0
     for ln in sizes:
