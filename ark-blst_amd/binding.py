@@ -26,7 +26,8 @@ class Profile(C.Structure):
                                           "reduce_ms", "combine_ms", "d2h_ms", "host_fold_ms", "total_ms")] + [
         ("window_bits", C.c_uint32), ("num_windows", C.c_uint32), ("n", C.c_uint64), ("accumulate_adds", C.c_uint64),
         ("work_items", C.c_uint32), ("max_items_per_bucket", C.c_uint32),
-        ("window_groups", C.c_uint32), ("reserved", C.c_uint32)]
+        ("window_groups", C.c_uint32), ("reserved", C.c_uint32),
+        ("accumulate_clock_ghz", C.c_double), ("accumulate_clock_ticks", C.c_uint64), ("accumulate_ref_ticks", C.c_uint64)]
 
 
 def profile_dict(p: Profile) -> dict:
@@ -62,6 +63,12 @@ def load_library(test_hooks: bool = False):
         for g in ("g1", "g2"):
             getattr(L, f"mi_msm_{g}_set_bases").argtypes = [vp, vp, sz]
             getattr(L, f"mi_msm_{g}_set_bases_precomputed").argtypes = [vp, vp, sz, u]
+            getattr(L, f"mi_msm_{g}_set_bases_device").argtypes = [vp, vp, sz]
+            getattr(L, f"mi_msm_{g}_set_bases_from_jacobian").argtypes = [vp, vp, sz]
+            getattr(L, f"mi_msm_{g}_set_bases_from_compressed").argtypes = [vp, vp, sz, i, i, C.POINTER(sz)]
+            getattr(L, f"mi_{g}_normalize_batch_device").argtypes = [vp, vp, sz, vp]
+            getattr(L, f"mi_{g}_deserialize_batch_device").argtypes = [vp, vp, sz, i, i, vp, vp]
+            getattr(L, f"mi_{g}_check_batch_device").argtypes = [vp, vp, sz, vp]
             getattr(L, f"mi_msm_{g}_validate_bases").argtypes = [vp, C.POINTER(sz)]
             getattr(L, f"mi_msm_{g}").argtypes = [vp, vp, vp, sz, u, vp]
             getattr(L, f"mi_msm_{g}_device").argtypes = [vp, vp, sz, u, vp]
@@ -193,6 +200,36 @@ class Context:
         p, keep = _buf(bases)
         self._check(getattr(self._L, f"mi_msm_{group}_set_bases_precomputed")(self._h, p, n, window_bits),
                     f"mi_msm_{group}_set_bases_precomputed")
+
+    def set_bases_device(self, group: str, d_bases_ptr: int, n: int):
+        """Resident base set from affine points (reference form) already in device memory."""
+        self._check(getattr(self._L, f"mi_msm_{group}_set_bases_device")(self._h, C.c_void_p(d_bases_ptr), n), f"mi_msm_{group}_set_bases_device")
+
+    def set_bases_from_jacobian(self, group: str, jac, n: int):
+        """Resident base set from host Jacobian points: normalize_batch on the GPU on the way in."""
+        p, keep = _buf(jac)
+        self._check(getattr(self._L, f"mi_msm_{group}_set_bases_from_jacobian")(self._h, p, n), f"mi_msm_{group}_set_bases_from_jacobian")
+
+    def set_bases_from_compressed(self, group: str, data, n: int, compressed: bool = True, validate: bool = True) -> int:
+        """Resident base set from serialized points, decoded (and checked) on the GPU.  Returns the number of rejected encodings:
+        0 = installed; otherwise nothing was installed (the call's MI_E_INVALID is swallowed, every other error raises)."""
+        p, keep = _buf(data)
+        rej = C.c_size_t(0)
+        rc = getattr(self._L, f"mi_msm_{group}_set_bases_from_compressed")(self._h, p, n, 1 if compressed else 0, 1 if validate else 0, C.byref(rej))
+        if rc != 0 and not (rc == -1 and rej.value):
+            self._check(rc, f"mi_msm_{group}_set_bases_from_compressed")
+        return rej.value
+
+    def normalize_batch_device(self, group: str, d_in_ptr: int, n: int, d_out_ptr: int):
+        self._check(getattr(self._L, f"mi_{group}_normalize_batch_device")(self._h, C.c_void_p(d_in_ptr), n, C.c_void_p(d_out_ptr)), f"mi_{group}_normalize_batch_device")
+
+    def deserialize_batch_device(self, group: str, d_bytes_ptr: int, n: int, compressed: bool, validate: bool, d_out_ptr: int, d_status_ptr: int):
+        self._check(getattr(self._L, f"mi_{group}_deserialize_batch_device")(self._h, C.c_void_p(d_bytes_ptr), n, 1 if compressed else 0,
+                                                                              1 if validate else 0, C.c_void_p(d_out_ptr), C.c_void_p(d_status_ptr)),
+                    f"mi_{group}_deserialize_batch_device")
+
+    def check_batch_device(self, group: str, d_points_ptr: int, n: int, d_status_ptr: int):
+        self._check(getattr(self._L, f"mi_{group}_check_batch_device")(self._h, C.c_void_p(d_points_ptr), n, C.c_void_p(d_status_ptr)), f"mi_{group}_check_batch_device")
 
     def validate_bases(self, group: str) -> int:
         """Valid::check of the resident base set on the GPU; returns the number of points that fail (0 = the set is recorded as valid)"""

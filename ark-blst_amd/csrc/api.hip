@@ -77,9 +77,12 @@ int mi_msm_init(mi_ctx** out, const int* device_ids, int n_devices) {
                 for (auto& e : d->cev) HIP_TRY(hipEventCreate(&e));
                 for (Scratch& sc : d->sc)
                     for (auto& e : sc.ev) HIP_TRY(hipEventCreate(&e));
+                for (auto& row : d->iev)
+                    for (auto& e : row) HIP_TRY(hipEventCreate(&e));
             }
         }
         if (const char* e = getenv("ARKBLST_AMD_TRACE")) ctx->trace = atoi(e) != 0;
+        if (const char* e = getenv("ARKBLST_AMD_PIPELINE_ACC2")) ctx->pipe_two_acc_streams = atoi(e) != 0;
         if (const char* e = getenv("ARKBLST_AMD_PIPELINE")) {   // window groups of a pipelined call (mi_msm_set_pipeline): "0" / "off", "auto", or weights "3,5,5,3"
             std::vector<unsigned> w;
             if (!strcmp(e, "0") || !strcmp(e, "off") || !strcmp(e, "1")) w = {1};
@@ -155,6 +158,10 @@ void mi_msm_destroy(mi_ctx* ctx) {
                 for (auto& e : sc.ev)
                     if (e) (void)hipEventDestroy(e);
             }
+            for (auto& row : d.iev)
+                for (auto& e : row)
+                    if (e) (void)hipEventDestroy(e);
+            if (d.d2h_stream) { (void)hipStreamSynchronize(d.d2h_stream); (void)hipStreamDestroy(d.d2h_stream); }
             if (d.aux_stream) (void)hipStreamDestroy(d.aux_stream);
             if (d.acc2_stream) (void)hipStreamDestroy(d.acc2_stream);
             if (d.copy_stream) (void)hipStreamDestroy(d.copy_stream);
@@ -222,26 +229,54 @@ int mi_msm_g2_batch_device(mi_ctx* ctx, const void* const* d_scalars, size_t k, 
     return g2_msm_batch(ctx, reinterpret_cast<const uint8_t* const*>(d_scalars), true, k, n, scalar_fmt, out);
 }
 
-int mi_g1_normalize_batch(mi_ctx* ctx, const mi_g1* in, size_t n, mi_g1_affine* out) { return g1_normalize(ctx, in, n, out); }
-int mi_g2_normalize_batch(mi_ctx* ctx, const mi_g2* in, size_t n, mi_g2_affine* out) { return g2_normalize(ctx, in, n, out); }
+int mi_g1_normalize_batch(mi_ctx* ctx, const mi_g1* in, size_t n, mi_g1_affine* out) { return g1_normalize(ctx, in, false, n, out); }
+int mi_g2_normalize_batch(mi_ctx* ctx, const mi_g2* in, size_t n, mi_g2_affine* out) { return g2_normalize(ctx, in, false, n, out); }
+int mi_g1_normalize_batch_device(mi_ctx* ctx, const void* d_in, size_t n, void* d_out) {
+    return g1_normalize(ctx, static_cast<const mi_g1*>(d_in), true, n, static_cast<mi_g1_affine*>(d_out));
+}
+int mi_g2_normalize_batch_device(mi_ctx* ctx, const void* d_in, size_t n, void* d_out) {
+    return g2_normalize(ctx, static_cast<const mi_g2*>(d_in), true, n, static_cast<mi_g2_affine*>(d_out));
+}
+int mi_msm_g1_set_bases_device(mi_ctx* ctx, const void* d_bases, size_t n) { return g1_set_bases_device(ctx, d_bases, n); }
+int mi_msm_g2_set_bases_device(mi_ctx* ctx, const void* d_bases, size_t n) { return g2_set_bases_device(ctx, d_bases, n); }
+int mi_msm_g1_set_bases_from_jacobian(mi_ctx* ctx, const mi_g1* points, size_t n) { return g1_set_bases_from_jacobian(ctx, points, n); }
+int mi_msm_g2_set_bases_from_jacobian(mi_ctx* ctx, const mi_g2* points, size_t n) { return g2_set_bases_from_jacobian(ctx, points, n); }
+int mi_msm_g1_set_bases_from_compressed(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int validate, size_t* n_rejected) {
+    return g1_set_bases_from_compressed(ctx, bytes, n, compressed, validate, n_rejected);
+}
+int mi_msm_g2_set_bases_from_compressed(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int validate, size_t* n_rejected) {
+    return g2_set_bases_from_compressed(ctx, bytes, n, compressed, validate, n_rejected);
+}
 
 int mi_g1_deserialize_batch(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int validate, mi_g1_affine* out,
                             uint8_t* status) {
-    return g1_deserialize(ctx, bytes, n, compressed, validate, out, status);
+    return g1_deserialize(ctx, bytes, false, n, compressed, validate, out, status);
+}
+int mi_g1_deserialize_batch_device(mi_ctx* ctx, const void* d_bytes, size_t n, int compressed, int validate, void* d_out, void* d_status) {
+    return g1_deserialize(ctx, static_cast<const uint8_t*>(d_bytes), true, n, compressed, validate, static_cast<mi_g1_affine*>(d_out), static_cast<uint8_t*>(d_status));
+}
+int mi_g2_deserialize_batch_device(mi_ctx* ctx, const void* d_bytes, size_t n, int compressed, int validate, void* d_out, void* d_status) {
+    return g2_deserialize(ctx, static_cast<const uint8_t*>(d_bytes), true, n, compressed, validate, static_cast<mi_g2_affine*>(d_out), static_cast<uint8_t*>(d_status));
 }
 int mi_g1_serialize_batch(mi_ctx* ctx, const mi_g1_affine* points, size_t n, int compressed, uint8_t* bytes) {
     return g1_serialize(ctx, points, n, compressed, bytes);
 }
 int mi_g2_deserialize_batch(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int validate, mi_g2_affine* out,
                             uint8_t* status) {
-    return g2_deserialize(ctx, bytes, n, compressed, validate, out, status);
+    return g2_deserialize(ctx, bytes, false, n, compressed, validate, out, status);
 }
 int mi_g2_serialize_batch(mi_ctx* ctx, const mi_g2_affine* points, size_t n, int compressed, uint8_t* bytes) {
     return g2_serialize(ctx, points, n, compressed, bytes);
 }
 
-int mi_g1_check_batch(mi_ctx* ctx, const mi_g1_affine* points, size_t n, uint8_t* status) { return g1_check_batch(ctx, points, n, status); }
-int mi_g2_check_batch(mi_ctx* ctx, const mi_g2_affine* points, size_t n, uint8_t* status) { return g2_check_batch(ctx, points, n, status); }
+int mi_g1_check_batch(mi_ctx* ctx, const mi_g1_affine* points, size_t n, uint8_t* status) { return g1_check_batch(ctx, points, false, n, status); }
+int mi_g2_check_batch(mi_ctx* ctx, const mi_g2_affine* points, size_t n, uint8_t* status) { return g2_check_batch(ctx, points, false, n, status); }
+int mi_g1_check_batch_device(mi_ctx* ctx, const void* d_points, size_t n, void* d_status) {
+    return g1_check_batch(ctx, static_cast<const mi_g1_affine*>(d_points), true, n, static_cast<uint8_t*>(d_status));
+}
+int mi_g2_check_batch_device(mi_ctx* ctx, const void* d_points, size_t n, void* d_status) {
+    return g2_check_batch(ctx, static_cast<const mi_g2_affine*>(d_points), true, n, static_cast<uint8_t*>(d_status));
+}
 
 int mi_multi_miller_loop(mi_ctx* ctx, const mi_g1_affine* p, const mi_g2_affine* q, size_t n, mi_fp12* out) {
     return miller(ctx, p, q, n, out, false);

@@ -399,6 +399,14 @@ __global__ void __launch_bounds__(256, 2) k_serialize_g2(const uint32_t* __restr
     }
 }
 
+// rejected points of a decode pass (status != 0), for mi_msm_g{1,2}_set_bases_from_compressed: one counter per call
+__global__ void __launch_bounds__(256) k_count_rejected(const uint8_t* __restrict__ status, uint32_t n, uint32_t* __restrict__ counter) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const bool bad = i < n && status[i] != 0;
+    const uint64_t m = __ballot(bad);
+    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(counter, (uint32_t)__popcll(m));
+}
+
 // ---------------------------------------------------------------------------------------------- field test hook
 #if defined(MI_TEST_HOOKS)
 __global__ void __launch_bounds__(256, 2) k_test_fp_op(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,

@@ -162,8 +162,10 @@ struct DevState {
     // pipelined calls only, created on the lane's first one (ensure_pipeline_streams): the accumulate kernels of the odd groups, and the
     // sorts + reductions of every group (high priority: short latency-bound launches that must find wave slots under the accumulate kernels)
     hipStream_t acc2_stream = nullptr, aux_stream = nullptr;
+    hipStream_t d2h_stream = nullptr;    // rows (f): results of chunk j leave while chunk j + 1 is computed (created on first use, ensure_d2h_stream)
     hipEvent_t ev[12] = {};
     hipEvent_t cev[10] = {};             // copy stream: [0] first copy issued, [1..8] chunk landed, [9] last copy done
+    hipEvent_t iev[4][8] = {};           // rows (f), per chunk: [0] kernels start, [1] kernels done, [2] second-phase start, [3] second-phase done
     Resident* res = nullptr;   // -> mi_ctx::residents[device][2]
     // scratch
     DevBuf raw, call_bases, call_flags, scalars;
@@ -183,15 +185,26 @@ struct DevState {
         HIP_TRY(hipHostMalloc(&h_pairs, bytes, hipHostMallocDefault));
         h_pairs_cap = bytes;
     }
-    // the two extra streams of a pipelined call.  Stream priorities: the HIP runtime keeps one pool of hardware queues per priority level
-    // (GPU_MAX_HW_QUEUES = 4 each) and streams beyond a pool's size SHARE a queue, which serialises their kernels; the high-priority
-    // aux stream therefore never competes for a queue with the accumulate streams.
+    // Stream priorities decide which HARDWARE QUEUE a stream gets: the HIP runtime keeps one pool of queues per priority level
+    // (GPU_MAX_HW_QUEUES = 4 each) and streams beyond a pool's size SHARE a queue, which serialises their kernels.  Measured (round 6): with
+    // the second accumulate stream as the sixth normal-priority stream of the process it shared a queue with the lane's own stream whenever
+    // the runtime's bookkeeping fell that way — the pipelined bench.py step took 3.62 ms against 3.27 unpipelined while tools/pipe_scan.py,
+    // one stream fewer, showed a gain; on the LOW-priority pool its kernel starved behind the first group's (3.64 against 3.31).  So the
+    // NORMAL pool is kept for the streams whose kernels must overlap — the process's null stream, the two lanes' streams and their second
+    // accumulate streams (the fifth, lane 1's, exists only once two callers pipeline at the same time) — and everything short and latency-bound
+    // goes to the HIGH pool: copies (mi_msm_init creates the copy streams there), the sorts of a pipelined call, the D2H stream of rows (f).
+    static int high_priority() {
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi = greatest priority (numerically lower)
+        return hi;
+    }
     void ensure_pipeline_streams() {
         if (aux_stream) return;
-        int lo = 0, hi = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // numerically lower = higher priority
         HIP_TRY(hipStreamCreateWithFlags(&acc2_stream, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithPriority(&aux_stream, hipStreamNonBlocking, hi));
+        HIP_TRY(hipStreamCreateWithPriority(&aux_stream, hipStreamNonBlocking, high_priority()));
+    }
+    void ensure_d2h_stream() {
+        if (!d2h_stream) HIP_TRY(hipStreamCreateWithPriority(&d2h_stream, hipStreamNonBlocking, high_priority()));
     }
     template <class Fn> void for_each_buf(Fn fn) {
         for (DevBuf* b : {&raw, &call_bases, &call_flags, &scalars, &pr_p, &pr_q, &pr_lvl[0], &pr_lvl[1], &pr_raw, &pr_lines, &io_in, &io_out, &io_status,
@@ -278,6 +291,7 @@ struct mi_ctx {
     // window groups of a pipelined call (run_msm): 0 entries = the built-in choice; {1} = never pipeline; otherwise relative weights of the
     // groups, top windows first (mi_msm_set_pipeline / ARKBLST_AMD_PIPELINE)
     std::vector<unsigned> pipe_weights;
+    bool pipe_two_acc_streams = false;   // ARKBLST_AMD_PIPELINE_ACC2=1: accumulate kernels of odd groups on a second normal-priority stream (see DevState::ensure_pipeline_streams)
     bool trace = false;   // ARKBLST_AMD_TRACE=1: MSM calls at profile level 2 print their phase boundaries to stderr (run_msm)
     // base-set cache of the stateless call shape (api.hip mi_msm_set_base_cache); [0] = G1, [1] = G2
     std::mutex cache_mu;
@@ -606,6 +620,20 @@ void for_each_device(LaneLock& lane, size_t g, Fn fn) {
     }
 }
 
+// Device of a caller-supplied device pointer.  A pointer this runtime does not know — plain host memory, or memory of a second HIP
+// runtime loaded into the process (load order) — is the caller's error (MI_E_INVALID), not an opaque fault later.
+inline int device_of_ptr(const void* p, const char* what, size_t align = 16) {
+    // the kernels read scalars and write window sums as 16-byte vectors (points: 4-byte words): a misaligned device pointer would fault on the GPU
+    if (reinterpret_cast<uintptr_t>(p) & (align - 1))
+        throw HipFail{std::string(what) + " must be " + std::to_string(align) + "-byte aligned", false, true};
+    hipPointerAttribute_t a{};
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) (void)hipGetLastError();
+    if (e != hipSuccess || a.type == hipMemoryTypeUnregistered)
+        throw HipFail{std::string(what) + " is not device memory known to this HIP runtime (a host pointer, or memory allocated through a "
+                      "second HIP runtime in this process: see INTEGRATION.md, load order)", false, true};
+    return a.device;
+}
 // contiguous shard [lo, hi) of n items for device k of g
 inline void shard_range(size_t n, size_t g, size_t k, size_t& lo, size_t& hi) {
     size_t per = (n + g - 1) / g;

@@ -64,13 +64,14 @@ template <class C>
 __global__ void __launch_bounds__(64, C::OCC) k_accumulate(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                             const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ woff,
                                                             const uint32_t* __restrict__ order, const uint32_t* __restrict__ item_bucket,
-                                                            const uint32_t* __restrict__ meta, uint32_t logT, uint32_t* __restrict__ partial) {
+                                                            uint32_t* __restrict__ meta, uint32_t logT, uint32_t* __restrict__ partial) {
     using F = typename C::F;
     using FA = typename C::FA;
     using E = typename F::E;
     uint32_t j = blockIdx.x * 64 + threadIdx.x;
     if (j >= meta[0]) return;       // the item count stays on the device: the grid is the host's upper bound (run_msm), surplus waves leave here
     uint32_t i = order[j];          // items are processed longest class first; partial[] keeps natural item order
+    WaveClock::start(partial + (size_t)i * Geo<C>::BK_WORDS);
     uint32_t b = item_bucket[i];
     uint32_t k = i - woff[b];
     uint32_t e, end;
@@ -109,6 +110,7 @@ __global__ void __launch_bounds__(64, C::OCC) k_accumulate(const uint32_t* __res
         ec::proj_add<F>(out, q);  // shared-call multiplier: keeps the cold path out of the hot loop's register budget
         e++;
     }
+    WaveClock::stop(partial + (size_t)i * Geo<C>::BK_WORDS, meta);
     store_bucket<C>(partial + (size_t)i * Geo<C>::BK_WORDS, out);
 }
 
@@ -147,12 +149,13 @@ template <class C>   // C = G2C (a template so that only the G2 translation unit
 __global__ void __launch_bounds__(64, 2) k_accumulate_g2_coop(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                                const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ woff,
                                                                const uint32_t* __restrict__ order, const uint32_t* __restrict__ item_bucket,
-                                                               const uint32_t* __restrict__ meta, uint32_t logT, uint32_t* __restrict__ partial) {
+                                                               uint32_t* __restrict__ meta, uint32_t logT, uint32_t* __restrict__ partial) {
     using FA = CoopF2A;
     const uint32_t h = threadIdx.x & 1u;
     uint32_t j = (blockIdx.x * 64 + threadIdx.x) >> 1;
     if (j >= meta[0]) return;       // pairs never straddle the bound (even block size); the grid is an upper bound, as for k_accumulate
     uint32_t i = order[j];
+    WaveClock::start(partial + (size_t)i * G2_BK_WORDS);
     uint32_t b = item_bucket[i];
     uint32_t k = i - woff[b];
     uint32_t e, end;
@@ -191,6 +194,7 @@ __global__ void __launch_bounds__(64, 2) k_accumulate_g2_coop(const uint32_t* __
     // 2^20 points, profiles/r03_g2_2p20_* first take) although the code object reports no spill
     ec::Xyzz<CoopF2> fin;
     fin.x = acc.x; fin.y = acc.y; fin.zz = acc.zz; fin.zzz = acc.zzz;
+    WaveClock::stop(partial + (size_t)i * G2_BK_WORDS, meta);
     g2_coop_finish(bases, sorted, e, end, inf, fin, partial + (size_t)i * G2_BK_WORDS + 16 * h);
 }
 
@@ -726,8 +730,11 @@ __global__ void __launch_bounds__(64, 2) k_reduce_serial(const uint32_t* __restr
 // windows (/root/reference/src/gpu.rs:193-209 does the whole tail on the host).  grid = nwin * cpw_out waves.
 template <class CS>
 __global__ void __launch_bounds__(64, CS::MAX_OCC) k_combine(const uint32_t* __restrict__ pairs_in, uint32_t cpw_in, uint32_t cpw_out,
-                                                             uint32_t* __restrict__ pairs_out, uint32_t* __restrict__ jac_out) {
+                                                             uint32_t* __restrict__ pairs_out, uint32_t* __restrict__ jac_out,
+                                                             const uint32_t* __restrict__ meta) {
     aux_priority();
+    // last level: the accumulate kernel's clock sums travel to the host behind the window sums (4 words after the nwin Jacobian points)
+    if (jac_out && blockIdx.x == 0 && threadIdx.x < 4) jac_out[(size_t)gridDim.x * Geo<typename CS::C>::RAW_JAC + threadIdx.x] = meta[CLK_META + threadIdx.x];
     using Pt = typename CS::Pt;
     constexpr int NLL = 1 << CS::LOG_LL, BK = Geo<typename CS::C>::BK_WORDS, RJ = Geo<typename CS::C>::RAW_JAC;
     const uint32_t w = blockIdx.x / cpw_out, g = blockIdx.x % cpw_out, ll = CS::ll();

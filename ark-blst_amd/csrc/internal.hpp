@@ -53,24 +53,33 @@ std::vector<Plan> split_plan(const Plan& pl, const CurveCost& cc, size_t n, bool
 // ---- msm_g1.hip / msm_g2.hip
 int g1_set_bases(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute_c);
 int g2_set_bases(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute_c);
+int g1_set_bases_device(mi_ctx* ctx, const void* d_bases, size_t n);
+int g2_set_bases_device(mi_ctx* ctx, const void* d_bases, size_t n);
+int g1_set_bases_from_jacobian(mi_ctx* ctx, const void* jac, size_t n);
+int g2_set_bases_from_jacobian(mi_ctx* ctx, const void* jac, size_t n);
+// device slot k's shard of a new resident set from decoded points in device memory (points.hip, set_bases_from_compressed); may throw HipFail
+void g1_install_resident(mi_ctx* ctx, size_t k, const void* d_affine, size_t lo, size_t n, bool validated);
+void g2_install_resident(mi_ctx* ctx, size_t k, const void* d_affine, size_t lo, size_t n, bool validated);
 int g1_msm(mi_ctx* ctx, const void* bases, const uint8_t* scalars, bool scalars_on_device, size_t n, unsigned fmt, void* out);
 int g2_msm(mi_ctx* ctx, const void* bases, const uint8_t* scalars, bool scalars_on_device, size_t n, unsigned fmt, void* out);
 int g1_msm_windows(mi_ctx* ctx, const uint8_t* d_scalars, size_t n, unsigned fmt, void* d_out, mi_window_info* info);
 int g2_msm_windows(mi_ctx* ctx, const uint8_t* d_scalars, size_t n, unsigned fmt, void* d_out, mi_window_info* info);
 int g1_msm_batch(mi_ctx* ctx, const uint8_t* const* scalars, bool scalars_on_device, size_t k, size_t n, unsigned fmt, mi_g1* out);
 int g2_msm_batch(mi_ctx* ctx, const uint8_t* const* scalars, bool scalars_on_device, size_t k, size_t n, unsigned fmt, mi_g2* out);
-int g1_normalize(mi_ctx* ctx, const mi_g1* in, size_t n, mi_g1_affine* out);
+int g1_normalize(mi_ctx* ctx, const mi_g1* in, bool on_device, size_t n, mi_g1_affine* out);
 CurveCost g1_cost();
 CurveCost g2_cost();
-int g2_normalize(mi_ctx* ctx, const mi_g2* in, size_t n, mi_g2_affine* out);
+int g2_normalize(mi_ctx* ctx, const mi_g2* in, bool on_device, size_t n, mi_g2_affine* out);
 
 // ---- points.hip
-int g1_deserialize(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int validate, mi_g1_affine* out, uint8_t* status);
+int g1_deserialize(mi_ctx* ctx, const uint8_t* bytes, bool on_device, size_t n, int compressed, int validate, mi_g1_affine* out, uint8_t* status);
 int g1_serialize(mi_ctx* ctx, const mi_g1_affine* points, size_t n, int compressed, uint8_t* bytes);
-int g2_deserialize(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int validate, mi_g2_affine* out, uint8_t* status);
+int g2_deserialize(mi_ctx* ctx, const uint8_t* bytes, bool on_device, size_t n, int compressed, int validate, mi_g2_affine* out, uint8_t* status);
 int g2_serialize(mi_ctx* ctx, const mi_g2_affine* points, size_t n, int compressed, uint8_t* bytes);
-int g1_check_batch(mi_ctx* ctx, const mi_g1_affine* points, size_t n, uint8_t* status);
-int g2_check_batch(mi_ctx* ctx, const mi_g2_affine* points, size_t n, uint8_t* status);
+int g1_check_batch(mi_ctx* ctx, const mi_g1_affine* points, bool on_device, size_t n, uint8_t* status);
+int g2_check_batch(mi_ctx* ctx, const mi_g2_affine* points, bool on_device, size_t n, uint8_t* status);
+int g1_set_bases_from_compressed(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int validate, size_t* n_rejected);
+int g2_set_bases_from_compressed(mi_ctx* ctx, const uint8_t* bytes, size_t n, int compressed, int validate, size_t* n_rejected);
 int g1_validate_bases(mi_ctx* ctx, size_t* n_invalid);
 int g2_validate_bases(mi_ctx* ctx, size_t* n_invalid);
 #if defined(MI_TEST_HOOKS)

@@ -1,0 +1,115 @@
+// Rows (f) of SURVEY.md §8 — normalize_batch, bulk (de)serialisation, Valid::batch_check — as the CALLER sees them: the trait hands over host
+// slices and takes host slices back (/root/reference/src/g1.rs:537-543,386-431), so a call is H2D + kernels + D2H.  Round 5 allocated and
+// freed three to six device buffers per call and moved input and output as one copy each with nothing overlapped (VERDICT r05 weak #3:
+// normalize_batch of 2^20 points took 52.8 ms around 1.05 ms of kernels).  Here: the staging buffers live in the lane's DevState (nothing is
+// allocated in steady state), the input crosses PCIe in up to eight chunks on the copy stream, the kernels of a chunk start when it has
+// landed, and its results leave on a third stream while the next chunk is computed.  A NULL host pointer means "already / stays in device
+// memory" (the *_device entry points and the set_bases_from_* paths, where decode / normalize feed the resident set without returning to
+// the host).
+#pragma once
+#include "common.hpp"
+
+namespace mi {
+
+struct IoOut {
+    void* host;   // destination in host memory, or nullptr: the result stays in `dev`
+    void* dev;    // device buffer of n * unit bytes
+    size_t unit;  // bytes per element
+};
+
+constexpr size_t IO_MAX_CHUNKS = 8;   // DevState::cev / iev hold eight chunk events
+struct IoPlan {
+    size_t K, chunk;   // chunks, elements per chunk (a multiple of `align`; the last chunk is the remainder)
+};
+// min_chunk: the fewest elements a chunk's kernels need to fill the device — 65536 for light element-wise kernels, 262144 for the decoders and
+// the subgroup check (256-lane workgroups of ~250 registers: two per compute unit, so 131072 lanes are ONE round of the machine; a chunk of
+// 32768 points left three quarters of it idle and doubled the G2 decoder's time)
+inline IoPlan io_plan(size_t n, bool crosses_pcie, size_t align, size_t min_chunk = 65536) {
+    size_t K = crosses_pcie ? std::min<size_t>(IO_MAX_CHUNKS, std::max<size_t>(1, n / min_chunk)) : 1;
+    size_t chunk = (n + K - 1) / K;
+    chunk = (chunk + align - 1) / align * align;
+    K = std::max<size_t>(1, (n + chunk - 1) / chunk);
+    return IoPlan{K, chunk};
+}
+
+// An error between the first enqueued copy and the call's final synchronisation must not return while copies still read or write the
+// caller's host buffers: drain the lane's streams before the exception leaves.
+struct IoDrain {
+    DevState& d;
+    int live = std::uncaught_exceptions();
+    explicit IoDrain(DevState& dd) : d(dd) {}
+    ~IoDrain() {
+        if (std::uncaught_exceptions() > live) {
+            (void)hipStreamSynchronize(d.copy_stream);
+            (void)hipStreamSynchronize(d.stream);
+            if (d.d2h_stream) (void)hipStreamSynchronize(d.d2h_stream);
+            (void)hipGetLastError();
+        }
+    }
+};
+
+// chunk j of the input: [lo, lo + cnt)
+inline void io_range(const IoPlan& p, size_t n, size_t j, size_t& lo, size_t& cnt) {
+    lo = std::min(n, j * p.chunk);
+    cnt = std::min(p.chunk, n - lo);
+}
+
+// H2D of chunk j on the copy stream; the lane's stream waits for it.  h_in == nullptr: the input is in device memory already.
+inline void io_feed(DevState& d, const IoPlan& p, size_t n, size_t j, const void* h_in, void* d_in, size_t unit) {
+    if (!h_in) return;
+    size_t lo, cnt;
+    io_range(p, n, j, lo, cnt);
+    if (j == 0) HIP_TRY(hipEventRecord(d.cev[0], d.copy_stream));
+    HIP_TRY(hipMemcpyAsync((char*)d_in + lo * unit, (const char*)h_in + lo * unit, cnt * unit, hipMemcpyHostToDevice, d.copy_stream));
+    HIP_TRY(hipEventRecord(d.cev[1 + j], d.copy_stream));
+    HIP_TRY(hipStreamWaitEvent(d.stream, d.cev[1 + j], 0));
+}
+// D2H of chunk j's results on the d2h stream, behind the event `done` recorded on the lane's stream after the chunk's last kernel
+inline void io_drain_chunk(DevState& d, const IoPlan& p, size_t n, size_t j, hipEvent_t done, const IoOut* outs, int nouts) {
+    size_t lo, cnt;
+    io_range(p, n, j, lo, cnt);
+    bool any = false;
+    for (int k = 0; k < nouts; k++) any = any || outs[k].host != nullptr;
+    if (!any) return;
+    d.ensure_d2h_stream();
+    HIP_TRY(hipStreamWaitEvent(d.d2h_stream, done, 0));
+    for (int k = 0; k < nouts; k++)
+        if (outs[k].host)
+            HIP_TRY(hipMemcpyAsync((char*)outs[k].host + lo * outs[k].unit, (const char*)outs[k].dev + lo * outs[k].unit, cnt * outs[k].unit,
+                                   hipMemcpyDeviceToHost, d.d2h_stream));
+}
+// the call's final synchronisation: every stream that carried part of it
+inline void io_finish(DevState& d) {
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    if (d.d2h_stream) HIP_TRY(hipStreamSynchronize(d.d2h_stream));
+    HIP_TRY(hipStreamSynchronize(d.copy_stream));
+    HIP_TRY(hipGetLastError());
+}
+
+// One element-wise pass: launch(lo, cnt) enqueues the chunk's kernels on d.stream.  Returns the kernels' time (sum over the chunks of the
+// interval between the chunk's first and last kernel on the lane's stream), and through *h2d_ms the span of the input copies.
+template <class Launch>
+double io_stream_pass(DevState& d, size_t n, const void* h_in, void* d_in, size_t in_unit, const IoOut* outs, int nouts, Launch launch,
+                      double* h2d_ms, size_t min_chunk = 65536) {
+    bool crosses = h_in != nullptr;
+    for (int k = 0; k < nouts; k++) crosses = crosses || outs[k].host != nullptr;
+    const IoPlan p = io_plan(n, crosses, 256, min_chunk);
+    IoDrain drain(d);
+    for (size_t j = 0; j < p.K; j++) {
+        size_t lo, cnt;
+        io_range(p, n, j, lo, cnt);
+        io_feed(d, p, n, j, h_in, d_in, in_unit);
+        HIP_TRY(hipEventRecord(d.iev[0][j], d.stream));
+        launch(lo, cnt);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(d.iev[1][j], d.stream));
+        io_drain_chunk(d, p, n, j, d.iev[1][j], outs, nouts);
+    }
+    io_finish(d);
+    double k_ms = 0;
+    for (size_t j = 0; j < p.K; j++) k_ms += ev_ms(d.iev[0][j], d.iev[1][j]);
+    if (h2d_ms) *h2d_ms = h_in ? ev_ms(d.cev[0], d.cev[p.K]) : 0.0;
+    return k_ms;
+}
+
+}  // namespace mi

@@ -242,6 +242,31 @@ constexpr uint32_t MERGE_FAN = 4;   // fan-in of one level of the merge of split
 // the schedule's counters in device memory (words): [0] items, [1] max items of a bucket, [2] entries, [3] merge list length of level 0,
 // [4] split buckets, [8 + l] merge list length of level l >= 1
 constexpr uint32_t MERGE_META = 32;
+// [CLK_META .. CLK_META + 3]: two 64-bit sums the accumulate kernel leaves behind — shader-clock ticks (s_memtime) and 100-MHz ticks
+// (s_memrealtime) its waves spent inside it: their ratio x 0.1 GHz is the clock the kernel ACTUALLY ran at in this launch (bench.py prices
+// the roofline at it instead of a clock replayed from an old profile).  Zeroed with the rest by k_sched2, copied out by the last k_combine.
+constexpr uint32_t CLK_META = 24;
+
+// Nothing of it stays in registers across the kernel's hot loop (two 64-bit stamps held there cost k_accumulate<G1C> a register granule:
+// 217 instead of 215 VGPRs, 16 registers fewer left beside its two waves for the sort kernels of a pipelined call): lane 0 parks the
+// start stamps in the first 16 bytes of ITS OWN output slot, which nothing reads before the kernel's last store overwrites it.
+struct WaveClock {
+    static __device__ __forceinline__ void start(uint32_t* own_slot) {
+        if ((threadIdx.x & 63u) == 0) {
+            const unsigned long long t0 = clock64(), w0 = wall_clock64();
+            reinterpret_cast<unsigned long long*>(own_slot)[0] = t0;
+            reinterpret_cast<unsigned long long*>(own_slot)[1] = w0;
+        }
+    }
+    // call BEFORE the output slot is written
+    static __device__ __forceinline__ void stop(const uint32_t* own_slot, uint32_t* meta) {
+        if ((threadIdx.x & 63u) == 0) {
+            const unsigned long long t0 = reinterpret_cast<const unsigned long long*>(own_slot)[0], w0 = reinterpret_cast<const unsigned long long*>(own_slot)[1];
+            atomicAdd(reinterpret_cast<unsigned long long*>(meta + CLK_META), clock64() - t0);
+            atomicAdd(reinterpret_cast<unsigned long long*>(meta + CLK_META + 2), wall_clock64() - w0);
+        }
+    }
+};
 
 // Item geometry of the schedule, ONE definition for the kernels that build the items (sort_kernels.cuh) and the ones that walk them
 // (curve_kernels.cuh): a bucket of up to T = 2^logT entries is one item, a fuller one is cut into items of S = 2^logS entries.

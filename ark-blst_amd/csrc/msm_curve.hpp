@@ -4,6 +4,7 @@
 #pragma once
 #include <exception>
 #include "internal.hpp"
+#include "io_chunks.hpp"
 #include "curve_kernels.cuh"
 
 namespace mi {
@@ -36,20 +37,6 @@ inline size_t max_part(mi_ctx* ctx) {
     return MAX_PART_POINTS;
 }
 
-// Device of a caller-supplied device pointer.  A pointer this runtime does not know — plain host memory, or memory of a second HIP
-// runtime loaded into the process (load order) — is the caller's error (MI_E_INVALID), not an opaque fault later.
-inline int device_of_ptr(const void* p, const char* what) {
-    // the kernels read scalars and write window sums as 16-byte vectors: a misaligned device pointer would fault on the GPU
-    if (reinterpret_cast<uintptr_t>(p) & 15u)
-        throw HipFail{std::string(what) + " must be 16-byte aligned", false, true};
-    hipPointerAttribute_t a{};
-    hipError_t e = hipPointerGetAttributes(&a, p);
-    if (e != hipSuccess) (void)hipGetLastError();
-    if (e != hipSuccess || a.type == hipMemoryTypeUnregistered)
-        throw HipFail{std::string(what) + " is not device memory known to this HIP runtime (a host pointer, or memory allocated through a "
-                      "second HIP runtime in this process: see INTEGRATION.md, load order)", false, true};
-    return a.device;
-}
 // Does device slot k of the context read its shard of a scalar vector that lives on device `owner` IN PLACE?  Only when it is the
 // same device.  A remote shard is copied once with hipMemcpyPeerAsync (a DMA over xGMI where mi_msm_init could enable peer access,
 // staged through the host by the runtime where it could not) instead of being read twice by the sort's count and scatter passes
@@ -142,7 +129,7 @@ J horner(const J* win, const Plan& pl) {
 // the dominant kernel: one lane per work item for G1, a lane pair per work item for G2 (k_accumulate_g2_coop)
 template <class C>
 void launch_accumulate(hipStream_t s, const uint32_t* bases, const uint32_t* sorted, const uint32_t* offsets, const uint32_t* woff,
-                       const uint32_t* order, const uint32_t* item_bucket, size_t items_cap, const uint32_t* meta, uint32_t logT, uint32_t* partial) {
+                       const uint32_t* order, const uint32_t* item_bucket, size_t items_cap, uint32_t* meta, uint32_t logT, uint32_t* partial) {
     // grid = the host's upper bound of the item count; the kernels read the count itself from meta[0]
     if constexpr (std::is_same<C, msmk::G2C>::value) {
         hipLaunchKernelGGL(msmk::k_accumulate_g2_coop<C>, dim3((uint32_t)((2 * items_cap + 63) / 64)), dim3(64), 0, s, bases, sorted, offsets, woff, order,
@@ -181,6 +168,7 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     using RS = typename msmk::CoopOf<C>::RS;   // lane scheme of the reduce kernel
     using CS = typename msmk::CoopOf<C>::CS;   // lane scheme of the combine levels
     constexpr int BK = msmk::Geo<C>::BK_WORDS;
+    constexpr size_t CLK_BYTES = 16;   // the accumulate kernel's clock sums (kernels_common.cuh CLK_META), behind every group's window sums
     Plan pl = make_plan(n, shared ? table_c : ctx->forced_c, HostCurve<C>::cost(), shared, stride, fold);
     if (pl.c == 0) throw HipFail{"window_bits not usable for this n (sort geometry)"};
     const std::vector<Plan> groups = split_plan(pl, HostCurve<C>::cost(), n, shared, ctx->pipe_weights);
@@ -190,7 +178,9 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     d.prof.num_windows = pl.nwin;
     d.prof.n = n;
     d.prof.window_groups = (uint32_t)G;
-    d.ensure_host((size_t)pl.bwin * jac_bytes<C>());
+    d.ensure_host((size_t)pl.bwin * jac_bytes<C>() + G * CLK_BYTES);
+    // host image of the window sums: group g's windows (ascending) followed by its 16 clock bytes, groups in ascending window order
+    auto host_at = [&](size_t g) { return (shared ? 0 : (size_t)groups[g].win0 * jac_bytes<C>()) + (G - 1 - g) * CLK_BYTES; };
 
     hipStream_t sS = d.stream, sAcc[2] = {d.stream, d.stream};
     const bool phases = d.prof_level >= 2;   // see sort_and_schedule
@@ -198,7 +188,7 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     if (piped) {
         d.ensure_pipeline_streams();
         sS = d.aux_stream;
-        sAcc[1] = d.acc2_stream;
+        if (ctx->pipe_two_acc_streams) sAcc[1] = d.acc2_stream;
     }
     if (piped || trace) {
         // the aux stream starts behind what the caller queued on the lane's stream (base conversion, a staged scalar shard)
@@ -213,13 +203,13 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
         Scratch& sc = d.sc[g];
         const Plan& gp = groups[g];
         sc.pairs.ensure(gp.nchunks * 2 * BK * 4);
-        sc.pairs2.ensure(((gp.nchunks >> CS::LOG_LL) + gp.bwin) * 2 * BK * 4 + (size_t)gp.bwin * jac_bytes<C>());
+        sc.pairs2.ensure(((gp.nchunks >> CS::LOG_LL) + gp.bwin) * 2 * BK * 4 + (size_t)gp.bwin * jac_bytes<C>() + CLK_BYTES);
         sort_and_schedule(d, sc, sS, gp, d_scalars, d_flags, n, fmt, shared, stride, so[g], g == 0 ? host_scalars : nullptr, piped && g > 0);
         sc.partial.ensure(so[g].items_cap * BK * 4);
         hipStream_t sa = sAcc[g & 1];
         if (piped) HIP_TRY(hipStreamWaitEvent(sa, sc.ev[3], 0));
         launch_accumulate<C>(sa, d_bases, (const uint32_t*)sc.sorted.p, (const uint32_t*)sc.offsets.p, (const uint32_t*)sc.woff.p,
-                             (const uint32_t*)sc.order.p, (const uint32_t*)sc.item_bucket.p, so[g].items_cap, (const uint32_t*)sc.meta.p, gp.logT | (gp.logS << 16),
+                             (const uint32_t*)sc.order.p, (const uint32_t*)sc.item_bucket.p, so[g].items_cap, (uint32_t*)sc.meta.p, gp.logT | (gp.logS << 16),
                              (uint32_t*)sc.partial.p);
         if (piped) HIP_TRY(hipEventRecord(sc.ev[4], sa));
     }
@@ -241,7 +231,7 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
             uint32_t* lists[2] = {(uint32_t*)sc.merge_list.p, (uint32_t*)sc.merge_list2.p};
             uint64_t dd = 1, shrink = 1;
             for (uint32_t l = 0; dd < max_items; l++, dd *= msmk::MERGE_FAN, shrink *= msmk::MERGE_FAN) {
-                if (8 + l + 1 >= msmk::MERGE_META) throw HipFail{"merge tree deeper than its counters"};
+                if (8 + l + 1 >= msmk::CLK_META) throw HipFail{"merge tree deeper than its counters"};
                 const uint64_t bound = std::min<uint64_t>(so[g].nlist, so[g].nlist / shrink + so[g].nsplit);
                 hipLaunchKernelGGL(msmk::k_merge<CS>, dim3((uint32_t)((bound + (1u << CS::LOG_LL) - 1) >> CS::LOG_LL)), dim3(64), 0, sr, (uint32_t*)sc.partial.p,
                                    (const uint32_t*)sc.item_bucket.p, (const uint32_t*)sc.woff.p, (const uint32_t*)lists[l & 1],
@@ -266,7 +256,7 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
                                (const uint32_t*)sc.woff.p, (const uint32_t*)sc.offsets.p, (uint32_t*)sc.pairs.p, gp.coop_L, gp.nb, gp.chunks_per_win);
         }
         if (phases) HIP_TRY(hipEventRecord(sc.ev[5], sr));
-        uint32_t* jac_dev = (uint32_t*)((char*)sc.pairs2.p + sc.pairs2.cap - (size_t)gp.bwin * jac_bytes<C>());
+        uint32_t* jac_dev = (uint32_t*)((char*)sc.pairs2.p + sc.pairs2.cap - (size_t)gp.bwin * jac_bytes<C>() - CLK_BYTES);   // window sums, then the clock sums
         {
             uint32_t cpw = gp.chunks_per_win;
             uint32_t* in = (uint32_t*)sc.pairs.p;
@@ -275,7 +265,7 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
                 uint32_t cpw_out = (cpw + (1u << CS::LOG_LL) - 1) >> CS::LOG_LL;
                 const bool last = cpw_out == 1;
                 hipLaunchKernelGGL(msmk::k_combine<CS>, dim3(gp.bwin * cpw_out), dim3(64), 0, sr, (const uint32_t*)in, cpw, cpw_out, out,
-                                   last ? jac_dev : (uint32_t*)nullptr);
+                                   last ? jac_dev : (uint32_t*)nullptr, (const uint32_t*)sc.meta.p);
                 if (last) break;
                 std::swap(in, out);   // the levels shrink by 2^LOG_LL: ping-pong between the two pair buffers
                 cpw = cpw_out;
@@ -284,10 +274,12 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
         if (phases) HIP_TRY(hipEventRecord(sc.ev[6], sr));
         // window sums of the group, in their place among the call's windows (window 0 first; shared bucket sets: the one sum)
         const size_t at = shared ? 0 : (size_t)gp.win0 * jac_bytes<C>();
-        if (wo)   // ... they stay on the device (the caller exchanges them: mi_msm_g1_device_windows); no fold here
+        if (wo) {   // ... they stay on the device (the caller exchanges them: mi_msm_g1_device_windows); no fold here, only the clock sums come back
             HIP_TRY(hipMemcpyAsync((char*)wo->d_out + at, jac_dev, (size_t)gp.bwin * jac_bytes<C>(), hipMemcpyDeviceToDevice, sr));
-        else
-            HIP_TRY(hipMemcpyAsync((char*)d.h_pairs + at, jac_dev, (size_t)gp.bwin * jac_bytes<C>(), hipMemcpyDeviceToHost, sr));
+            HIP_TRY(hipMemcpyAsync((char*)d.h_pairs + host_at(g) + (size_t)gp.bwin * jac_bytes<C>(), (const char*)jac_dev + (size_t)gp.bwin * jac_bytes<C>(), CLK_BYTES,
+                                   hipMemcpyDeviceToHost, sr));
+        } else
+            HIP_TRY(hipMemcpyAsync((char*)d.h_pairs + host_at(g), jac_dev, (size_t)gp.bwin * jac_bytes<C>() + CLK_BYTES, hipMemcpyDeviceToHost, sr));
         if (phases || piped) HIP_TRY(hipEventRecord(sc.ev[7], sr));
     }
     if (wo) {
@@ -297,15 +289,28 @@ typename HostCurve<C>::J run_msm(mi_ctx* ctx, DevState& d, const uint32_t* d_bas
     // ---- phase 3: the host tail.  Horner fold over the window sums (top window first), group by group as they arrive
     J r = J::inf();
     double fold_ms = 0;
-    const J* win = static_cast<const J*>(d.h_pairs);   // pinned bytes the D2H copies write
+    unsigned long long clk_ticks = 0, ref_ticks = 0;   // the accumulate kernels' s_memtime / s_memrealtime sums
     for (size_t g = 0; g < G; g++) {
         const Plan& gp = groups[g];
         if (piped) HIP_TRY(hipEventSynchronize(d.sc[g].ev[7]));
         else HIP_TRY(hipStreamSynchronize(sS));
-        if (wo) continue;
+        const char* img = (const char*)d.h_pairs + host_at(g);   // pinned bytes the D2H copy wrote
         auto t0 = std::chrono::steady_clock::now();
-        for (int w = (int)(gp.win0 + gp.bwin) - 1; w >= (int)gp.win0; w--) r = r.dbl_n(pl.c).add(win[w]);
+        for (int w = (int)gp.bwin - 1; w >= 0 && !wo; w--) {
+            J wsum;
+            memcpy(&wsum, img + (size_t)w * jac_bytes<C>(), sizeof wsum);
+            r = r.dbl_n(pl.c).add(wsum);
+        }
         fold_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        unsigned long long ck[2];
+        memcpy(ck, img + (size_t)gp.bwin * jac_bytes<C>(), sizeof ck);
+        clk_ticks += ck[0];
+        ref_ticks += ck[1];
+    }
+    if (ref_ticks) {   // shader clock the accumulate kernels ran at: s_memtime counts shader cycles, s_memrealtime a constant 100 MHz
+        d.prof.accumulate_clock_ticks += clk_ticks;
+        d.prof.accumulate_ref_ticks += ref_ticks;
+        d.prof.accumulate_clock_ghz = 0.1 * (double)d.prof.accumulate_clock_ticks / (double)d.prof.accumulate_ref_ticks;
     }
     if (piped) HIP_TRY(hipStreamSynchronize(sS));   // nothing of this call is left on any stream (the aux stream ended with the last schedule)
     HIP_TRY(hipGetLastError());
@@ -460,7 +465,7 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
 // Resident base set.  precompute_c == 0: plain bases.  Otherwise W = num_windows(c, false) tables T_j[i] = 2^(c j) P_i (affine, device
 // form): every window of a later MSM then shares ONE bucket set (no per-window reduce, no Horner doublings) and c can be larger.
 template <class C>
-void build_resident(mi_ctx* ctx, DevState& d, Resident& res, const uint8_t* bases, size_t n, unsigned precompute_c) {
+void build_resident(mi_ctx* ctx, DevState& d, Resident& res, const uint8_t* bases, size_t n, unsigned precompute_c, bool bases_on_device = false) {
     using F = typename C::F;
     constexpr size_t PTB = (size_t)msmk::Geo<C>::PT_WORDS * 4, SLOTB = (size_t)msmk::Geo<C>::SLOT * 4, BKB = (size_t)msmk::Geo<C>::BK_WORDS * 4;
     (void)sizeof(F);
@@ -478,7 +483,7 @@ void build_resident(mi_ctx* ctx, DevState& d, Resident& res, const uint8_t* base
     res.tables = 1;
     res.table_c = 0;
     res.validated = false;
-    ingest<C>(d, bases, false, n, (uint32_t*)res.buf.p, (uint8_t*)res.flags.p);
+    ingest<C>(d, bases, bases_on_device, n, (uint32_t*)res.buf.p, (uint8_t*)res.flags.p);
     if (W > 1) {
         InvTree t(n);
         DevBuf proj, vals, pref, inv, top_raw;
@@ -505,14 +510,27 @@ void build_resident(mi_ctx* ctx, DevState& d, Resident& res, const uint8_t* base
     (void)ctx;
 }
 
+// where a new resident base set comes from
+enum class BaseSrc {
+    HostAffine,     // mi_msm_g1_set_bases: blst_p1_affine in host memory
+    DeviceAffine,   // mi_msm_g1_set_bases_device: the same form, already in device memory (single-device contexts)
+    HostJacobian    // mi_msm_g1_set_bases_from_jacobian: blst_p1 in host memory, normalised on the GPU on the way (normalize_batch feeding msm,
+                    // /root/reference/src/g1.rs:597-599 -> 604, without returning to the host in between)
+};
+template <class C> void normalize_run(mi_ctx* ctx, DevState& d, const void* h_in, const void* d_in_user, size_t n, void* h_out, void* d_out_user, bool publish_profile);
+
 template <class C>
-int set_bases_impl(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute_c) {
+int set_bases_impl(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute_c, BaseSrc src = BaseSrc::HostAffine) {
     if (!ctx || (n && !bases)) return fail(ctx, MI_E_INVALID, "invalid argument");
     if (precompute_c > 1 && (precompute_c < 7 || precompute_c > 22)) return fail(ctx, MI_E_INVALID, "window_bits must be 0 (choose) or 7..22");
     if ((n + ctx->devs.size() - 1) / ctx->devs.size() > (1ull << 31)) return fail(ctx, MI_E_INVALID, "more than 2^31 points per device");
+    if (src == BaseSrc::DeviceAffine && ctx->devs.size() != 1) return fail(ctx, MI_E_INVALID, "set_bases_device needs a single-device context");
     LaneLock lk(ctx, true);
     return guarded(ctx, [&]() -> int {
         size_t g = ctx->devs.size();
+        if (src == BaseSrc::DeviceAffine && n && device_of_ptr(bases, "d_bases", 4) != ctx->devs[0].dev)
+            return fail(ctx, MI_E_INVALID, "d_bases must live on the context's device");
+        const size_t in_bytes = src == BaseSrc::HostJacobian ? jac_bytes<C>() : aff_bytes<C>();
         std::vector<PartErr> errs(g);
         for_each_device(lk, g, [&](size_t k) {
             guarded_part(errs[k], [&] {
@@ -525,7 +543,14 @@ int set_bases_impl(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute
                 res.tables = 1;
                 res.table_c = 0;
                 res.validated = false;
-                if (hi > lo) build_resident<C>(ctx, d, res, (const uint8_t*)bases + lo * aff_bytes<C>(), hi - lo, precompute_c);
+                if (hi == lo) return;
+                const uint8_t* shard = (const uint8_t*)bases + lo * in_bytes;
+                if (src == BaseSrc::HostJacobian) {
+                    normalize_run<C>(ctx, d, shard, nullptr, hi - lo, nullptr, nullptr, false);   // affine points (reference form) in d.io_out
+                    build_resident<C>(ctx, d, res, (const uint8_t*)d.io_out.p, hi - lo, precompute_c, true);
+                } else {
+                    build_resident<C>(ctx, d, res, shard, hi - lo, precompute_c, src == BaseSrc::DeviceAffine);
+                }
             });
         });
         for (size_t k = 0; k < g; k++)
@@ -535,6 +560,23 @@ int set_bases_impl(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute
             }
         return MI_OK;
     });
+}
+
+// device slot k's shard of a new resident set from points already decoded into DEVICE memory in the reference's affine form (the caller —
+// mi_msm_g1_set_bases_from_compressed, points.hip — holds the context exclusively and runs this on the slot's worker thread).  validated:
+// the decoder ran Valid::check on every point.
+template <class C>
+void install_resident(mi_ctx* ctx, size_t k, const void* d_affine, size_t lo, size_t n, bool validated) {
+    DevState& d = ctx->devs[k];
+    auto& res = d.res[HostCurve<C>::IDX];
+    res.lo = lo;
+    res.n = n;
+    res.tables = 1;
+    res.table_c = 0;
+    res.validated = false;
+    if (n == 0) return;
+    build_resident<C>(ctx, d, res, (const uint8_t*)d_affine, n, 0, true);
+    res.validated = validated;
 }
 
 template <class C>
@@ -711,49 +753,133 @@ int msm_batch_impl(mi_ctx* ctx, const uint8_t* const* scalars, bool scalars_on_d
     });
 }
 
-// normalize_batch on device 0 of the context (host pointers in the reference's forms)
+// normalize_batch on one device.  Host pointers cross PCIe in chunks (io_chunks.hpp):
+//   per chunk, as it lands     k_norm_load (Z values into the tree's level 0)
+//   once                       the product tree up, the <= 64 top values inverted on the host, the tree down — at FULL size: a tree kernel has one
+//                              lane per group of NORM_K values, and cut into chunks its launches (n / 8 / 32 lanes) left most of the machine idle
+//                              (measured: 10 ms instead of 1 ms of kernels for 2^18 G2 points)
+//   per chunk                  k_norm_final, the chunk's affine points leave on the d2h stream while the next chunk is converted  A NULL host pointer with a device pointer: the
+// data is / stays in device memory (mi_g1_normalize_batch_device, mi_msm_g1_set_bases_from_jacobian: d_out_user == nullptr leaves the
+// affine points in d.io_out).  Scratch lives in the lane's DevState: nothing is allocated in steady state (round 5: six hipMalloc + hipFree per call).
 template <class C>
-void normalize_batch_dev(mi_ctx* ctx, DevState& d, const void* in, size_t n, void* out) {
+void normalize_run(mi_ctx* ctx, DevState& d, const void* h_in, const void* d_in_user, size_t n, void* h_out, void* d_out_user, bool publish_profile) {
     using J = typename HostCurve<C>::J;
     using FE = decltype(J::inf().x);
-    constexpr size_t SLOTB = (size_t)msmk::Geo<C>::SLOT * 4;
+    constexpr size_t SLOTB = (size_t)msmk::Geo<C>::SLOT * 4, K2 = (size_t)msmk::NORM_K * msmk::NORM_K;
     HIP_TRY(hipSetDevice(d.dev));
     hipStream_t s = d.stream;
-    InvTree t(n);
-    DevBuf raw_in, raw_out, vals, pref, inv, top_raw;
-    ScopedBufs guard{{&raw_in, &raw_out, &vals, &pref, &inv, &top_raw}};
-    raw_in.ensure(n * jac_bytes<C>());
-    raw_out.ensure(n * aff_bytes<C>());
-    vals.ensure(t.total * SLOTB);
-    pref.ensure(t.total * SLOTB);
-    inv.ensure(t.total * SLOTB);
-    top_raw.ensure(64 * sizeof(FE));
+    const InvTree t(n);
+    const size_t top = t.sz.size() - 1;
+    const uint32_t* raw_in = (const uint32_t*)d_in_user;
+    if (!raw_in) { d.io_in.ensure(n * jac_bytes<C>()); raw_in = (const uint32_t*)d.io_in.p; }
+    uint32_t* raw_out = (uint32_t*)d_out_user;
+    if (!raw_out) { d.io_out.ensure(n * aff_bytes<C>()); raw_out = (uint32_t*)d.io_out.p; }
+    d.nv_vals.ensure(t.total * SLOTB);
+    d.nv_pref.ensure(t.total * SLOTB);
+    d.nv_inv.ensure(t.total * SLOTB);
+    d.nv_top.ensure(64 * sizeof(FE));
+    auto at = [&](DevBuf& b, size_t l, size_t idx) { return (uint32_t*)((char*)b.p + (t.off[l] + idx) * SLOTB); };
+    // range [lo, lo + cnt) of level 0 seen from level l
+    auto level_range = [&](size_t l, size_t lo, size_t cnt, size_t& llo, size_t& lcnt) {
+        size_t div = 1;
+        for (size_t q = 0; q < l; q++) div *= msmk::NORM_K;
+        llo = lo / div;
+        lcnt = (lo + cnt + div - 1) / div - llo;
+    };
+    auto up = [&](size_t l, size_t lo, size_t cnt) {       // level l -> prefix products of its groups, group totals = level l + 1
+        size_t llo, lcnt;
+        level_range(l, lo, cnt, llo, lcnt);
+        const uint32_t groups = (uint32_t)((lcnt + msmk::NORM_K - 1) / msmk::NORM_K);
+        hipLaunchKernelGGL(msmk::k_norm_up<C>, dim3((groups + 255) / 256), dim3(256), 0, s, (const uint32_t*)at(d.nv_vals, l, llo), (uint32_t)lcnt,
+                           at(d.nv_pref, l, llo), at(d.nv_vals, l + 1, llo / msmk::NORM_K));
+    };
+    auto down = [&](size_t l, size_t lo, size_t cnt) {     // inverses of level l from the inverses of level l + 1
+        size_t llo, lcnt;
+        level_range(l, lo, cnt, llo, lcnt);
+        const uint32_t groups = (uint32_t)((lcnt + msmk::NORM_K - 1) / msmk::NORM_K);
+        hipLaunchKernelGGL(msmk::k_norm_down<C>, dim3((groups + 255) / 256), dim3(256), 0, s, (const uint32_t*)at(d.nv_vals, l, llo),
+                           (const uint32_t*)at(d.nv_pref, l, llo), (const uint32_t*)at(d.nv_inv, l + 1, llo / msmk::NORM_K), (uint32_t)lcnt,
+                           at(d.nv_inv, l, llo));
+    };
+    const size_t local = 0;                                 // tree levels handled per chunk: none (see above)
+    const IoPlan p = io_plan(n, h_in != nullptr || h_out != nullptr, K2);
+    const IoOut outs[1] = {{h_out, raw_out, aff_bytes<C>()}};
+    IoDrain drain(d);
+    // ---- per chunk, as it lands: Z values and the chunk-local up-sweep
+    for (size_t j = 0; j < p.K; j++) {
+        size_t lo, cnt;
+        io_range(p, n, j, lo, cnt);
+        io_feed(d, p, n, j, h_in, const_cast<uint32_t*>(raw_in), jac_bytes<C>());
+        HIP_TRY(hipEventRecord(d.iev[0][j], s));
+        hipLaunchKernelGGL(msmk::k_norm_load<C>, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, s, raw_in + lo * msmk::Geo<C>::RAW_JAC, (uint32_t)cnt,
+                           at(d.nv_vals, 0, lo));
+        for (size_t l = 0; l < local; l++) up(l, lo, cnt);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(d.iev[1][j], s));
+    }
+    // ---- once: upper up-sweep, top inversion on the host (one Fermat inversion; a single GPU lane would need ~1 ms), upper down-sweep
     HIP_TRY(hipEventRecord(d.ev[0], s));
-    HIP_TRY(hipMemcpyAsync(raw_in.p, in, n * jac_bytes<C>(), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipEventRecord(d.ev[1], s));
-    hipLaunchKernelGGL(msmk::k_norm_load<C>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)raw_in.p, (uint32_t)n,
-                       (uint32_t*)vals.p);
-    invert_tree<C>(d, t, vals, pref, inv, top_raw);
-    hipLaunchKernelGGL(msmk::k_norm_final<C>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)raw_in.p,
-                       (const uint32_t*)inv.p, (uint32_t)n, (uint32_t*)raw_out.p);
-    HIP_TRY(hipEventRecord(d.ev[2], s));
-    HIP_TRY(hipMemcpyAsync(out, raw_out.p, n * aff_bytes<C>(), hipMemcpyDeviceToHost, s));
+    for (size_t l = local; l < top; l++) up(l, 0, n);
+    const size_t m = t.sz[top];
+    hipLaunchKernelGGL(msmk::k_elems_to_raw<C>, dim3(1), dim3(64), 0, s, (const uint32_t*)at(d.nv_vals, top, 0), (uint32_t)m, (uint32_t*)d.nv_top.p);
+    d.ensure_host(2 * 64 * sizeof(FE));
+    FE* hv = static_cast<FE*>(d.h_pairs);                   // pinned: [0, 64) the top values, [64, 128) their inverses
+    HIP_TRY(hipMemcpyAsync(hv, d.nv_top.p, m * sizeof(FE), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipGetLastError());
-    mi_profile pr{};
-    pr.n = n;
-    pr.h2d_ms = ev_ms(d.ev[0], d.ev[1]);
-    pr.accumulate_ms = ev_ms(d.ev[1], d.ev[2]);   // all normalize kernels incl. the host inversion round trip
-    set_prof(ctx, pr);
+    {
+        FE pre[64], run = FE::one();
+        for (size_t k = 0; k < m; k++) { pre[k] = run; run = run * hv[k]; }
+        FE I = run.inv();
+        for (size_t k = m; k-- > 0;) { hv[64 + k] = I * pre[k]; I = I * hv[k]; }
+    }
+    HIP_TRY(hipMemcpyAsync(d.nv_top.p, hv + 64, m * sizeof(FE), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(msmk::k_elems_from_raw<C>, dim3(1), dim3(64), 0, s, (const uint32_t*)d.nv_top.p, (uint32_t)m, at(d.nv_inv, top, 0));
+    for (size_t l = top; l-- > local;) down(l, 0, n);
+    HIP_TRY(hipEventRecord(d.ev[1], s));
+    // ---- per chunk: chunk-local down-sweep, affine coordinates, results out
+    for (size_t j = 0; j < p.K; j++) {
+        size_t lo, cnt;
+        io_range(p, n, j, lo, cnt);
+        HIP_TRY(hipEventRecord(d.iev[2][j], s));
+        for (size_t l = local; l-- > 0;) down(l, lo, cnt);
+        hipLaunchKernelGGL(msmk::k_norm_final<C>, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, s, raw_in + lo * msmk::Geo<C>::RAW_JAC,
+                           (const uint32_t*)at(d.nv_inv, 0, lo), (uint32_t)cnt, raw_out + lo * msmk::Geo<C>::RAW_AFF);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(d.iev[3][j], s));
+        io_drain_chunk(d, p, n, j, d.iev[3][j], outs, 1);
+    }
+    io_finish(d);
+    if (publish_profile) {
+        mi_profile pr{};
+        pr.n = n;
+        pr.h2d_ms = h_in ? ev_ms(d.cev[0], d.cev[p.K]) : 0.0;
+        pr.accumulate_ms = ev_ms(d.ev[0], d.ev[1]);          // all normalize kernels incl. the host inversion round trip ...
+        for (size_t j = 0; j < p.K; j++) pr.accumulate_ms += ev_ms(d.iev[0][j], d.iev[1][j]) + ev_ms(d.iev[2][j], d.iev[3][j]);   // ... per chunk, without the waits for its input
+        set_prof(ctx, pr);
+    }
 }
 
 template <class C, class In, class Out>
-int normalize_impl(mi_ctx* ctx, const In* in, size_t n, Out* out) {
+int normalize_impl(mi_ctx* ctx, const In* in, bool on_device, size_t n, Out* out) {
     if (!ctx || (n && (!in || !out))) return fail(ctx, MI_E_INVALID, "invalid argument");
     if (n == 0) return MI_OK;
     if (n > 0x7fffffffull) return fail(ctx, MI_E_INVALID, "n too large");
+    if (on_device && ctx->devs.size() != 1) return fail(ctx, MI_E_INVALID, "the *_device entry points need a single-device context");
     LaneLock lk(ctx, true);
-    return guarded(ctx, [&]() -> int { normalize_batch_dev<C>(ctx, ctx->devs[0], in, n, out); return MI_OK; });
+    return guarded(ctx, [&]() -> int {
+        DevState& d = ctx->devs[0];
+        auto t0 = std::chrono::steady_clock::now();
+        if (on_device) {
+            if (device_of_ptr(in, "d_in", 4) != d.dev || device_of_ptr(out, "d_out", 4) != d.dev)
+                return fail(ctx, MI_E_INVALID, "device buffers must live on the context's device");
+            normalize_run<C>(ctx, d, nullptr, in, n, nullptr, out, true);
+        } else {
+            normalize_run<C>(ctx, d, in, nullptr, n, out, nullptr, true);
+        }
+        std::lock_guard<std::mutex> g(ctx->info_mu);
+        ctx->prof.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();   // the call as a C caller sees it
+        return MI_OK;
+    });
 }
 
 }  // namespace mi

@@ -4,6 +4,9 @@
 namespace mi {
 
 int g2_set_bases(mi_ctx* ctx, const void* bases, size_t n, unsigned precompute_c) { return set_bases_impl<msmk::G2C>(ctx, bases, n, precompute_c); }
+int g2_set_bases_device(mi_ctx* ctx, const void* d_bases, size_t n) { return set_bases_impl<msmk::G2C>(ctx, d_bases, n, 0, BaseSrc::DeviceAffine); }
+int g2_set_bases_from_jacobian(mi_ctx* ctx, const void* jac, size_t n) { return set_bases_impl<msmk::G2C>(ctx, jac, n, 0, BaseSrc::HostJacobian); }
+void g2_install_resident(mi_ctx* ctx, size_t k, const void* d_affine, size_t lo, size_t n, bool validated) { install_resident<msmk::G2C>(ctx, k, d_affine, lo, n, validated); }
 int g2_msm(mi_ctx* ctx, const void* bases, const uint8_t* scalars, bool scalars_on_device, size_t n, unsigned fmt, void* out) {
     return msm_impl<msmk::G2C>(ctx, bases, scalars, scalars_on_device, n, fmt, out);
 }
@@ -13,7 +16,7 @@ int g2_msm_windows(mi_ctx* ctx, const uint8_t* d_scalars, size_t n, unsigned fmt
 int g2_msm_batch(mi_ctx* ctx, const uint8_t* const* scalars, bool scalars_on_device, size_t k, size_t n, unsigned fmt, mi_g2* out) {
     return msm_batch_impl<msmk::G2C>(ctx, scalars, scalars_on_device, k, n, fmt, out);
 }
-int g2_normalize(mi_ctx* ctx, const mi_g2* in, size_t n, mi_g2_affine* out) { return normalize_impl<msmk::G2C>(ctx, in, n, out); }
+int g2_normalize(mi_ctx* ctx, const mi_g2* in, bool on_device, size_t n, mi_g2_affine* out) { return normalize_impl<msmk::G2C>(ctx, in, on_device, n, out); }
 
 CurveCost g2_cost() { return HostCurve<msmk::G2C>::cost(); }
 

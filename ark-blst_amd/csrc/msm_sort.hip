@@ -172,12 +172,11 @@ std::vector<Plan> split_plan(const Plan& pl, const CurveCost& cc, size_t n, bool
     (void)cc;
     std::vector<unsigned> w = weights;
     if (w.empty()) {
-        // built-in: two groups from 2^20 points on, the first with a quarter (c <= 16) or a third (three-level sort, c >= 17) of the windows —
-        // its sort is the exposed one, and its accumulate kernel is long enough to cover the sort of the rest.  Same-box A/B
-        // (profiles/r06_pipe_scan_*.jsonl): 2^20 -2 %, 2^22 -3 %, 2^24 -3..4 %; below 2^20 the call is a sum of latency chains that more
-        // launches only lengthen (2^18: +4 %)
-        if (n >= ((size_t)1 << 20) && pl.nwin >= 8) w = pl.c >= 17 ? std::vector<unsigned>{1, 2} : std::vector<unsigned>{1, 3};
-        else w = {1};
+        // built-in: ONE group.  The pipelined form (mi_msm_set_pipeline / ARKBLST_AMD_PIPELINE) hides the second group's sort, but it needs
+        // its streams on separate hardware queues and the HIP runtime assigns those by its own bookkeeping (DevState::ensure_pipeline_streams):
+        // same-box A/B in two processes, 2^20 / 2^22 / 2^24 points — tools/pipe_scan.py -2 % / -3 % / -4 %, bench.py +0 .. +30 % (profiles/
+        // r06_pipeline_ab.txt).  A gain that depends on which queue a stream lands on is not a default.
+        w = {1};
     }
     if (w.size() > (size_t)MAX_GROUPS) w.resize(MAX_GROUPS);
     if (w.size() > pl.nwin) w.resize(pl.nwin);

@@ -269,14 +269,24 @@ def _compact(d: dict, keys) -> dict:
     return {k: d[k] for k in keys if k in d}
 
 
-def _rooflines(g: str, n: int, log_n, acc_ms: float, nwin: int, precomputed: bool) -> dict:
+def _clock_of(profs):
+    """Shader clock of the accumulate kernels of the timed steps, measured INSIDE the kernel (mi_profile.accumulate_clock_ghz: the
+    ratio of the waves' s_memtime and s_memrealtime sums): (GHz, source) or (None, None) when no step carried it."""
+    t = sum(p.get("accumulate_clock_ticks", 0) for p in profs)
+    r = sum(p.get("accumulate_ref_ticks", 0) for p in profs)
+    if r:
+        return 0.1 * t / r, "measured in this run: s_memtime / s_memrealtime sums of the timed accumulate launches (mi_profile.accumulate_clock_ghz)"
+    return None, None
+
+
+def _rooflines(g: str, n: int, log_n, acc_ms: float, nwin: int, precomputed: bool, clock_now=None) -> dict:
     alg_bytes = ALG_BYTES_PER_POINT[g] * n
     gbs = alg_bytes / (acc_ms * 1e-3) / 1e9
     traffic, src, stale = _traffic(g, log_n, precomputed) if log_n is not None else (None, None, None)
     mads = nwin * FP_MULS_PER_ADD[g] * MADS_PER_FP_MUL       # window-aware: one mixed addition per point and window
     kernel = "k_accumulate<G1C>" if g == "g1" else "k_accumulate_g2_coop<G2C>"
     key = "k_accumulate<msmk::G1C>" if g == "g1" else "k_accumulate_g2_coop"
-    clock, clock_src = _measured_clock(key, g, log_n)
+    clock, clock_src = clock_now if clock_now and clock_now[0] else _measured_clock(key, g, log_n)   # this run's own clock; a committed profile's only as a fallback
     if clock is None:
         clock, clock_src = _measured_clock(key)
     # real cycles one SIMD spends per wave-wide mixed addition (64 additions), incl. the per-bucket set-up and the kernel's tail
@@ -379,7 +389,10 @@ def _phases(profs, breakdown=None) -> dict:
     return {k: sum(p[k] for p in (profs if k in timed else src)) / len(profs if k in timed else src) for k in keys}
 
 
-def _secondary_msm(pkg, co, torch, g, log_n, seed_off, ncpu, device, steps, precomputed=False, window_bits=0) -> dict:
+ALG_AFF = {"g1": 96, "g2": 192}
+
+
+def _secondary_msm(pkg, co, torch, g, log_n, seed_off, ncpu, device, steps, precomputed=False, window_bits=0, cpu_sample_log_n=0) -> dict:
     n = 1 << log_n
     leg = MsmLeg(pkg, co, torch, g, n, SEED_B + seed_off, SEED_S + seed_off, ncpu, device, precomputed=precomputed, window_bits=window_bits)
     try:
@@ -392,7 +405,18 @@ def _secondary_msm(pkg, co, torch, g, log_n, seed_off, ncpu, device, steps, prec
                + (" as precomputed 2^(c j) P tables" if precomputed else "") + ", scalars in HBM",
                "window_bits": p0["window_bits"], "num_windows": p0["num_windows"], "phases_ms": ph, "input_gen_s": leg.gen_s,
                "set_bases_s": leg.set_bases_s}
-        out.update(_rooflines(g, n, log_n, ph["accumulate_ms"], p0["num_windows"], precomputed))
+        out.update(_rooflines(g, n, log_n, ph["accumulate_ms"], p0["num_windows"], precomputed, _clock_of(r["profs"])))
+        out["kernel_ms"] = ph["accumulate_ms"]
+        out["step_frac"] = out["roofline"]["model_mads_per_point"] * n / (out["ms_per_step"] * 1e-3) / 1e12 / MAD_PEAK_T
+        out["window_groups"] = p0.get("window_groups", 1)
+        if cpu_sample_log_n:   # the CPU port beside the north-star size, on a bounded prefix (the full 2^24 workload takes the port a minute)
+            m = 1 << cpu_sample_log_n
+            t1 = time.perf_counter()
+            cpu = co.msm(g, leg.bases[:ALG_AFF[g] * m], leg.scalars[:32 * m], m, 0, ncpu)
+            cpu_s = time.perf_counter() - t1
+            assert co.to_affine(g, cpu) == co.dlog_expected(g, leg.scalars[:32 * m], leg.seed_b, m)
+            out["cpu_baseline"] = {"value": m / cpu_s, "unit": "points/s", "cores": ncpu, "kind": "port", "cpu_model": _cpu_model(), "seconds": cpu_s,
+                                   "sample": f"the first 2^{cpu_sample_log_n} of the 2^{log_n} points, one run (blst-style Pippenger restatement in C, oracle/msm_oracle.c)"}
         return out
     finally:
         leg.close()
@@ -475,25 +499,38 @@ def _normalize_leg(pkg, co, ncpu, device, g="g1", log_n=20) -> dict:
     jac = b"".join(co.sum_jac(g, bases[aff * i:aff * (i + 1)] + one + bases[aff * (i + 1):aff * (i + 2)] + one, 2) for i in range(m))
     blob = jac * (n // m)
     with pkg.Context([device]) as ctx:
-        ctx.normalize_batch(g, blob[:jb * 1024])
-        best, kms, out = 1e30, None, b""
+        ctx.normalize_batch(g, blob)          # sizes the context's staging buffers (steady state: nothing is allocated per call)
+        best, kms, out, py_ms = 1e30, None, b"", None
         for _ in range(3):
             t1 = time.perf_counter()
             out = ctx.normalize_batch(g, blob)
-            dt = time.perf_counter() - t1
-            if dt < best:
-                best, kms = dt, ctx.profile()["accumulate_ms"]
+            dt = (time.perf_counter() - t1) * 1e3
+            pr = ctx.profile()
+            if pr["total_ms"] < best:           # total_ms: wall time of the C call (host pointers in, host pointers out)
+                best, kms, py_ms = pr["total_ms"], pr["accumulate_ms"], dt
+        # the same entirely in device memory (mi_g1_normalize_batch_device): what a caller that keeps its points on the GPU pays
+        import torch
+        d_in = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+        d_out = torch.empty(n * aff, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        dev_ms = 1e30
+        for _ in range(3):
+            ctx.normalize_batch_device(g, d_in.data_ptr(), n, d_out.data_ptr())
+            dev_ms = min(dev_ms, ctx.profile()["total_ms"])
+        dev_ok = d_out.cpu().numpy().tobytes() == out
+        del d_in, d_out
     t1 = time.perf_counter()
     cpu = co.normalize_batch(g, blob, ncpu)
     cpu_s = time.perf_counter() - t1
-    ok = out == cpu
+    ok = out == cpu and dev_ok
     muls = NORM_FP_MULS_PER_POINT * (1 if g == "g1" else 3)
     mads = muls * MADS_PER_FP_MUL
     clock, clock_src = _measured_clock("k_accumulate<msmk::G1C>")
     gbs = (jb + aff) * n / (kms * 1e-3) / 1e9
-    return {"metric": f"{G} points/s, normalize_batch (Jacobian -> affine, one inversion)", "value": n / (kms * 1e-3), "unit": "points/s", "n": n,
-            "kernels_ms": kms, "call_ms_host_buffers": best * 1e3, "bit_exact": ok,
-            "workload": f"2^{log_n} {G} Jacobian points with non-trivial Z, host buffers in and out (PCIe-inclusive figure: call_ms_host_buffers)",
+    return {"metric": f"{G} points/s, normalize_batch (Jacobian -> affine, one inversion), host slices in and out", "value": n / (best * 1e-3), "unit": "points/s", "n": n,
+            "call_ms_host_buffers": best, "kernels_ms": kms, "call_ms_device_buffers": dev_ms, "python_binding_wall_ms": py_ms, "bit_exact": ok,
+            "workload": f"2^{log_n} {G} Jacobian points with non-trivial Z; value = the C call with host buffers in and out (PCIe-inclusive, what the trait's "
+                        "caller pays); kernels_ms and the device-buffer call beside it",
             "roofline": {"bound": "hbm", "kernel": "k_norm_load + k_norm_up/down x levels + k_norm_final", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": (jb + aff) * n, "kernel_ms": kms,
                          "note": f"algorithmic bytes = {jb} B Jacobian in + {aff} B affine out per point; the product tree adds ~3 slots of "
@@ -513,22 +550,23 @@ def _deserialize_g2_leg(pkg, co, ncpu, device, log_n=18) -> dict:
     bases = co.gen_bases("g2", SEED_B + 203, n, ncpu)
     with pkg.Context([device]) as ctx:
         enc = ctx.serialize_batch("g2", bases, True)
-        ctx.deserialize_batch("g2", enc[:96 * 1024], True, True)
-        t1 = time.perf_counter()
+        ctx.deserialize_batch("g2", enc, True, True)
         dec, st = ctx.deserialize_batch("g2", enc, True, True)
-        wall = time.perf_counter() - t1
-        kms = ctx.profile()["accumulate_ms"]
+        kms, wall = ctx.profile()["accumulate_ms"], ctx.profile()["total_ms"] * 1e-3
         ctx.deserialize_batch("g2", enc, True, False)
         kms_novalidate = ctx.profile()["accumulate_ms"]
+        t1 = time.perf_counter()
+        rejected = ctx.set_bases_from_compressed("g2", enc, n, True, True)
+        load_ms = (time.perf_counter() - t1) * 1e3
     m = 1 << 13   # CPU sample: ~1 s on 16 threads
     t1 = time.perf_counter()
     cdec, cst = co.g2_deserialize_batch(enc[:96 * m], True, True, 1, ncpu)
     cpu_s = time.perf_counter() - t1
-    ok = dec == bases and st == bytes(n) and cdec == bases[:192 * m] and cst == bytes(m)
+    ok = dec == bases and st == bytes(n) and cdec == bases[:192 * m] and cst == bytes(m) and rejected == 0
     fp_muls = DESER_G2_FP_MULS_PER_POINT
     clock, clock_src = _measured_clock("k_accumulate<msmk::G1C>")
-    return {"metric": "G2 points/s, deserialize_batch (compressed, validate on)", "value": n / (kms * 1e-3), "unit": "points/s", "n": n,
-            "kernel_ms": kms, "kernel_ms_validate_off": kms_novalidate, "call_ms_host_buffers": wall * 1e3, "bit_exact": ok,
+    return {"metric": "G2 points/s, deserialize_batch (compressed, validate on), host slices in and out", "value": n / wall, "unit": "points/s", "n": n,
+            "call_ms_host_buffers": wall * 1e3, "kernel_ms": kms, "kernel_ms_validate_off": kms_novalidate, "set_bases_from_compressed_ms": load_ms, "bit_exact": ok,
             "workload": f"2^{log_n} compressed G2 encodings (96 B), decompression (Fp2 square root) + on-curve + subgroup check, host buffers in and out",
             "roofline": _valu_roofline("k_deserialize_g2 + k_validate<G2C>", f"~{fp_muls} Fp-mul x {MADS_PER_FP_MUL} MAD per point",
                                        fp_muls * MADS_PER_FP_MUL * n, kms, clock, clock_src, {"traffic": None, "algorithmic_bytes_per_launch": (96 + 192) * n}),
@@ -544,24 +582,33 @@ def _deserialize_leg(pkg, co, ncpu, device, log_n=20) -> dict:
     bases = co.gen_bases("g1", SEED_B + 202, n, ncpu)
     with pkg.Context([device]) as ctx:
         enc = ctx.g1_serialize_batch(bases, True)
-        ctx.g1_deserialize_batch(enc[:48 * 1024], True, True)
-        t1 = time.perf_counter()
+        ctx.g1_deserialize_batch(enc, True, True)
         dec, st = ctx.g1_deserialize_batch(enc, True, True)
-        wall = time.perf_counter() - t1
-        kms = ctx.profile()["accumulate_ms"]
-        t1 = time.perf_counter()
+        kms, wall = ctx.profile()["accumulate_ms"], ctx.profile()["total_ms"] * 1e-3   # total_ms: wall time of the C call
         ctx.g1_deserialize_batch(enc, True, False)
         kms_novalidate = ctx.profile()["accumulate_ms"]
+        # SRS loading as ONE call (decode + Valid::check + conversion on the GPU, only the 48-byte encodings cross PCIe) against the three
+        # calls it replaces (deserialize to host, set_bases, validate_bases)
+        ctx.set_bases_from_compressed("g1", enc, n, True, True)
+        t1 = time.perf_counter()
+        rejected = ctx.set_bases_from_compressed("g1", enc, n, True, True)
+        load_ms = (time.perf_counter() - t1) * 1e3
+        t1 = time.perf_counter()
+        ctx.set_bases("g1", dec, n)
+        bad = ctx.validate_bases("g1")
+        three_ms = wall * 1e3 + (time.perf_counter() - t1) * 1e3
     m = 1 << 16   # CPU sample: ~1 s on 16 threads
     t1 = time.perf_counter()
     cdec, cst = co.g1_deserialize_batch(enc[:48 * m], True, True, 1, ncpu)
     cpu_s = time.perf_counter() - t1
-    ok = dec == bases and st == bytes(n) and cdec == bases[:96 * m] and cst == bytes(m)
+    ok = dec == bases and st == bytes(n) and cdec == bases[:96 * m] and cst == bytes(m) and rejected == 0 and bad == 0
     mads = DESER_FP_MULS_PER_POINT * MADS_PER_FP_MUL
     clock, clock_src = _measured_clock("k_accumulate<msmk::G1C>")
     gbs = (48 + 96) * n / (kms * 1e-3) / 1e9
-    return {"metric": "G1 points/s, deserialize_batch (compressed, validate on)", "value": n / (kms * 1e-3), "unit": "points/s", "n": n,
-            "kernel_ms": kms, "kernel_ms_validate_off": kms_novalidate, "call_ms_host_buffers": wall * 1e3, "bit_exact": ok,
+    return {"metric": "G1 points/s, deserialize_batch (compressed, validate on), host slices in and out", "value": n / wall, "unit": "points/s", "n": n,
+            "call_ms_host_buffers": wall * 1e3, "kernel_ms": kms, "kernel_ms_validate_off": kms_novalidate,
+            "srs_load": {"set_bases_from_compressed_ms": load_ms, "deserialize_then_set_bases_then_validate_ms": three_ms},
+            "bit_exact": ok,
             "workload": f"2^{log_n} compressed G1 encodings (48 B), decompression + on-curve + subgroup check, host buffers in and out",
             "roofline": _valu_roofline("k_deserialize_g1", f"{DESER_FP_MULS_PER_POINT} Fp-mul (square root 570 + subgroup test 1650) x {MADS_PER_FP_MUL} MAD per point",
                                        mads * n, kms, clock, clock_src, {"traffic": None, "algorithmic_bytes_per_launch": (48 + 96) * n}),
@@ -946,7 +993,7 @@ def main() -> None:
                 secondary[name] = {"error": repr(e)}
         if g == "g1" and log_n == 20 and not args.precomputed and args.dist == "uniform":
             guarded("g1_2p16", lambda: _secondary_msm(pkg, co, torch, "g1", 16, 16, ncpu, local_rank, 50))   # config #1's size (the reference's CPU-runnable case)
-            guarded("g1_2p24", lambda: _secondary_msm(pkg, co, torch, "g1", 24, 24, ncpu, local_rank, 3))
+            guarded("g1_2p24", lambda: _secondary_msm(pkg, co, torch, "g1", 24, 24, ncpu, local_rank, 3, cpu_sample_log_n=22))
             guarded("g2_2p20", lambda: _secondary_msm(pkg, co, torch, "g2", 20, 4, ncpu, local_rank, 5))
             guarded("g1_2p20_precomputed_tables", lambda: _secondary_msm(pkg, co, torch, "g1", 20, 0, ncpu, local_rank, 10, precomputed=True))
         guarded("pairing_2p16", lambda: _pairing_leg(pkg, co, ncpu, local_rank))
@@ -960,7 +1007,7 @@ def main() -> None:
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = total / (elapsed / args.steps)
-        full = _rooflines(g, headline_n, log_n, acc_ms, p0["num_windows"], args.precomputed)
+        full = _rooflines(g, headline_n, log_n, acc_ms, p0["num_windows"], args.precomputed, _clock_of(prof_acc))
         roof = full["roofline"]
         # whole-step fraction of the same roof: the model's multiply-adds of ALL ranks' points over the step time (sort, bucket reduction,
         # combine, host fold and exchange included) against the peak of the GPUs used; `roofline.frac` is the dominant kernel alone
@@ -1005,11 +1052,17 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline
         # compact recap: the north-star figures of every leg (the full records of the legs go to the sidecar file)
         def _brief(d):
-            b = {"value": d.get("value"), "ms": d.get("ms_per_step", d.get("ms", d.get("kernel_ms", d.get("kernels_ms")))), "bit_exact": d.get("bit_exact")}
+            b = {"value": d.get("value"), "ms": d.get("ms_per_step", d.get("ms", d.get("call_ms_host_buffers", d.get("kernel_ms", d.get("kernels_ms"))))),
+                 "bit_exact": d.get("bit_exact")}
+            if "call_ms_host_buffers" in d:   # rows (f): value and ms are the CALL (host slices in and out); the kernels' time beside it
+                b["kernel_ms"] = d.get("kernel_ms", d.get("kernels_ms"))
             if "roofline" in d and d["roofline"].get("bound") == "valu_int_mad":
                 b["valu_frac"] = round(d["roofline"]["frac"], 3)
             if "step_frac" in d:
                 b["step_frac"] = round(d["step_frac"], 3)
+            if "kernel_ms" in d and "roofline" in d and d is not out:
+                b["kernel_ms"] = d["kernel_ms"]
+                b["clock_ghz"] = d["roofline"].get("shader_clock_ghz")
             if d.get("cpu_baseline") and d is not out:
                 b["cpu"] = d["cpu_baseline"]["value"]
             return {k: (float("%.4g" % v) if isinstance(v, float) else v) for k, v in b.items()}

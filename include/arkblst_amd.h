@@ -88,6 +88,10 @@ typedef struct {
                                  sums over the groups of intervals that overlap in time; accumulate_ms is the span from the first accumulate kernel's
                                  start to the last one's end */
     uint32_t reserved;
+    /* Shader clock of the accumulate kernel(s) of THIS call, measured inside the kernel: every wave sums its s_memtime (shader cycles) and
+       s_memrealtime (constant 100 MHz) ticks; GHz = 0.1 x the ratio of the two sums.  bench.py prices the roofline at this clock (round 5 replayed one from a committed profile of another box). */
+    double accumulate_clock_ghz;
+    uint64_t accumulate_clock_ticks, accumulate_ref_ticks;
 } mi_profile;
 
 /* Replaces Device::all()[0] + ec_gpu_gen::program! + SingleMultiexpKernel::create (src/gpu.rs:233-237,101-119),
@@ -104,6 +108,26 @@ int mi_msm_device_id(const mi_ctx *ctx, int slot);
  * every call (src/gpu.rs:149).  Copies; no pointer is retained. */
 int mi_msm_g1_set_bases(mi_ctx *ctx, const mi_g1_affine *bases, size_t n);
 int mi_msm_g2_set_bases(mi_ctx *ctx, const mi_g2_affine *bases, size_t n);
+
+/* The same from points that are ALREADY in device memory in the same form (hipMalloc'd, a torch CUDA tensor's data_ptr, the output of
+ * mi_g1_deserialize_batch_device / mi_g1_normalize_batch_device): converted in place on the GPU, nothing crosses PCIe.  Synchronise the stream
+ * that produced them first.  Single-device contexts (the pointer lives on ONE device). */
+int mi_msm_g1_set_bases_device(mi_ctx *ctx, const void *d_bases, size_t n);
+int mi_msm_g2_set_bases_device(mi_ctx *ctx, const void *d_bases, size_t n);
+/* ... from Jacobian points in host memory (blst_p1 / blst_p2): normalize_batch on the GPU on the way into the resident set — the reference's
+ * `batch_convert_to_mul_base` feeding `msm` (src/g1.rs:597-599 -> 604) without the affine points returning to the host in between.  Every
+ * device of the context normalises its own shard. */
+int mi_msm_g1_set_bases_from_jacobian(mi_ctx *ctx, const mi_g1 *points, size_t n);
+int mi_msm_g2_set_bases_from_jacobian(mi_ctx *ctx, const mi_g2 *points, size_t n);
+/* ... from serialized points (the encodings of mi_g1_deserialize_batch below; `compressed`: 48 / 96-byte or 96 / 192-byte units): SRS loading
+ * as ONE call — decode, with `validate` Valid::check, and conversion run on the GPU, every device over its shard, and only the encodings cross
+ * PCIe (48 B per G1 point instead of 48 in + 96 out + 96 in again).  All or nothing: if any encoding is rejected (malformed, off the curve or,
+ * with `validate`, outside the prime-order subgroup) the call returns MI_E_INVALID, *n_rejected says how many, and the previous resident set is
+ * unchanged (mi_g1_deserialize_batch gives the per-point status).  With `validate` a set that was installed is recorded as validated: MSMs over
+ * it may fold signs as after mi_msm_g1_validate_bases, without that second pass.  The reference decodes point by point on the CPU
+ * (src/g1.rs:398-431). */
+int mi_msm_g1_set_bases_from_compressed(mi_ctx *ctx, const uint8_t *bytes, size_t n, int compressed, int validate, size_t *n_rejected);
+int mi_msm_g2_set_bases_from_compressed(mi_ctx *ctx, const uint8_t *bytes, size_t n, int compressed, int validate, size_t *n_rejected);
 
 /* Opt-in variant for a long-lived SRS: besides the bases, keep W = ceil(255 / c) tables T_j[i] = 2^(c j) * bases[i] resident
  * (W x the memory, built once on the GPU: c doublings per point and table plus one batch inversion).  Every window of a later
@@ -180,6 +204,14 @@ int mi_msm_g2_batch_device(mi_ctx *ctx, const void *const *d_scalars, size_t k, 
  * (Z == 0) give the all-zero affine point.  Host pointers; runs on the context's first device. */
 int mi_g1_normalize_batch(mi_ctx *ctx, const mi_g1 *in, size_t n, mi_g1_affine *out);
 int mi_g2_normalize_batch(mi_ctx *ctx, const mi_g2 *in, size_t n, mi_g2_affine *out);
+/* Rows (f) as the caller sees them (round 6).  The host-pointer forms above and below cross PCIe in up to eight chunks: the kernels of a
+ * chunk start when it has landed and its results leave while the next chunk is computed; the staging buffers belong to the context, nothing
+ * is allocated per call in steady state (round 5: 52.8 ms around 1.05 ms of kernels for normalize_batch of 2^20 G1 points; now the time of
+ * the two copies).  The *_device forms take and leave everything in DEVICE memory (4-byte aligned pointers on the context's device,
+ * single-device contexts; synchronise the producing stream first): decode -> check -> normalize -> mi_msm_g1_set_bases_device chains never
+ * touch the host.  d_in and d_out may not overlap. */
+int mi_g1_normalize_batch_device(mi_ctx *ctx, const void *d_in, size_t n, void *d_out);
+int mi_g2_normalize_batch_device(mi_ctx *ctx, const void *d_in, size_t n, void *d_out);
 
 /* Bulk point (de)serialisation for G1 in the ZCash / IETF format the reference uses (src/g1.rs:358-431:
  * to_compressed / to_uncompressed, from_*_unchecked, Valid::check = is_on_curve && is_torsion_free): the SRS-loading
@@ -193,6 +225,9 @@ int mi_g1_serialize_batch(mi_ctx *ctx, const mi_g1_affine *points, size_t n, int
 int mi_g2_deserialize_batch(mi_ctx *ctx, const uint8_t *bytes, size_t n, int compressed, int validate,
                             mi_g2_affine *out, uint8_t *status);
 int mi_g2_serialize_batch(mi_ctx *ctx, const mi_g2_affine *points, size_t n, int compressed, uint8_t *bytes);
+/* device-memory forms (see mi_g1_normalize_batch_device): d_out n affine points, d_status n bytes */
+int mi_g1_deserialize_batch_device(mi_ctx *ctx, const void *d_bytes, size_t n, int compressed, int validate, void *d_out, void *d_status);
+int mi_g2_deserialize_batch_device(mi_ctx *ctx, const void *d_bytes, size_t n, int compressed, int validate, void *d_out, void *d_status);
 
 /* Valid::check = is_on_curve && is_torsion_free (src/g1.rs:386-396, src/g2.rs:366-376) for n affine points in host memory: what
  * ark_serialize::Valid::batch_check runs per element on the CPU (the projective form, src/g1.rs:570-579, is normalize_batch followed by this).
@@ -200,6 +235,8 @@ int mi_g2_serialize_batch(mi_ctx *ctx, const mi_g2_affine *points, size_t n, int
  * the decoders above, without the decoding. */
 int mi_g1_check_batch(mi_ctx *ctx, const mi_g1_affine *points, size_t n, uint8_t *status);
 int mi_g2_check_batch(mi_ctx *ctx, const mi_g2_affine *points, size_t n, uint8_t *status);
+int mi_g1_check_batch_device(mi_ctx *ctx, const void *d_points, size_t n, void *d_status);
+int mi_g2_check_batch_device(mi_ctx *ctx, const void *d_points, size_t n, void *d_status);
 
 /* Pairing (BASELINE config #5).  Replaces <Bls12 as Pairing>::multi_miller_loop (src/pairing.rs:49-74:
  * a serial loop of blstrs::miller_loop_lines + blst_fp12_mul on one CPU thread) and final_exponentiation

@@ -112,7 +112,7 @@ def test_layout_sizes_match_reference_types(pkg):
     from ark_blst_amd import binding as b
 
     assert (b.G1_AFF, b.G1_JAC, b.G2_AFF, b.G2_JAC) == (96, 144, 192, 288)
-    assert C.sizeof(b.Profile) == 11 * 8 + 2 * 4 + 2 * 8 + 4 * 4   # mi_profile (round 6: + window_groups, reserved)
+    assert C.sizeof(b.Profile) == 11 * 8 + 2 * 4 + 2 * 8 + 4 * 4 + 3 * 8   # mi_profile (round 6: + window_groups, reserved, the in-kernel clock)
 
 
 def test_strerror_and_invalid_args(pkg):

