@@ -87,6 +87,7 @@ def load_library(test_hooks: bool = False):
         L.mi_multi_pairing.argtypes = [vp, vp, vp, sz, vp]
         L.mi_final_exponentiation.argtypes = [vp, vp]
         L.mi_msm_set_window_bits.argtypes = [vp, u]
+        L.mi_msm_get_window_bits.argtypes = [vp, C.POINTER(u)]
         L.mi_msm_set_pipeline.argtypes = [vp, C.POINTER(u), u]
         L.mi_msm_set_base_cache.argtypes = [vp, u]
         L.mi_msm_invalidate_base_cache.argtypes = [vp]
@@ -165,6 +166,11 @@ class Context:
 
     def set_window_bits(self, c: int):
         self._check(self._L.mi_msm_set_window_bits(self._h, c), "mi_msm_set_window_bits")
+
+    def get_window_bits(self) -> int:
+        v = C.c_uint(0)
+        self._check(self._L.mi_msm_get_window_bits(self._h, C.byref(v)), "mi_msm_get_window_bits")
+        return v.value
 
     def set_pipeline(self, weights=None):
         """Window groups of a pipelined call (mi_msm_set_pipeline): None = built-in choice, [1] = off, else relative sizes, top windows first."""
@@ -453,6 +459,7 @@ def load_rccl_library():
         L.mi_rccl_get_unique_id.argtypes = [vp]
         L.mi_rccl_comm_create.argtypes = [C.POINTER(vp), vp, vp, i, i]
         L.mi_rccl_comm_attach.argtypes = [C.POINTER(vp), vp, vp]
+        L.mi_rccl_comm_set_timeout_ms.argtypes = [vp, C.c_double]
         L.mi_rccl_comm_destroy.argtypes = [vp]
         L.mi_rccl_comm_destroy.restype = None
         L.mi_rccl_comm_size.argtypes = [vp]
@@ -496,6 +503,12 @@ class RcclComm:
 
     def __exit__(self, *a):
         self.close()
+
+    def set_timeout_ms(self, ms: float):
+        """How long a rank waits inside the exchange for its peers (default 60 s; 0 = for ever); on expiry the communicator is aborted (MI_E_COMM)."""
+        rc = self._L.mi_rccl_comm_set_timeout_ms(self._h, float(ms))
+        if rc != 0:
+            raise MsmError(rc, "mi_rccl_comm_set_timeout_ms", (self._L.mi_rccl_last_error() or b"").decode())
 
     def size(self) -> int:
         return self._L.mi_rccl_comm_size(self._h)

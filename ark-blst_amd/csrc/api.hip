@@ -354,6 +354,13 @@ int mi_msm_set_window_bits(mi_ctx* ctx, unsigned window_bits) {
     return MI_OK;
 }
 
+int mi_msm_get_window_bits(const mi_ctx* ctx, unsigned* window_bits) {
+    if (!ctx || !window_bits) return MI_E_INVALID;
+    LaneLock lk(const_cast<mi_ctx*>(ctx), true);
+    *window_bits = ctx->forced_c;
+    return MI_OK;
+}
+
 int mi_msm_set_pipeline(mi_ctx* ctx, const unsigned* weights, unsigned n_groups) {
     if (!ctx || n_groups > (unsigned)MAX_GROUPS || (n_groups > 1 && !weights)) return fail(ctx, MI_E_INVALID, "at most 4 window groups; weights must be given for more than one");
     LaneLock lk(ctx, true);

@@ -733,8 +733,6 @@ __global__ void __launch_bounds__(64, CS::MAX_OCC) k_combine(const uint32_t* __r
                                                              uint32_t* __restrict__ pairs_out, uint32_t* __restrict__ jac_out,
                                                              const uint32_t* __restrict__ meta) {
     aux_priority();
-    // last level: the accumulate kernel's clock sums travel to the host behind the window sums (4 words after the nwin Jacobian points)
-    if (jac_out && blockIdx.x == 0 && threadIdx.x < 4) jac_out[(size_t)gridDim.x * Geo<typename CS::C>::RAW_JAC + threadIdx.x] = meta[CLK_META + threadIdx.x];
     using Pt = typename CS::Pt;
     constexpr int NLL = 1 << CS::LOG_LL, BK = Geo<typename CS::C>::BK_WORDS, RJ = Geo<typename CS::C>::RAW_JAC;
     const uint32_t w = blockIdx.x / cpw_out, g = blockIdx.x % cpw_out, ll = CS::ll();
@@ -775,6 +773,8 @@ __global__ void __launch_bounds__(64, CS::MAX_OCC) k_combine(const uint32_t* __r
     }
     if (jac_out) {
         if (ll == 0) CS::store_jac_raw(jac_out + (size_t)w * RJ, acc);
+        // last level: the accumulate kernel's clock sums travel to the host behind the window sums (4 words after the gridDim.x Jacobian points)
+        if (blockIdx.x == 0 && threadIdx.x < 4) jac_out[(size_t)gridDim.x * RJ + threadIdx.x] = meta[CLK_META + threadIdx.x];
     } else {
         uint32_t* o = pairs_out + ((size_t)w * cpw_out + g) * 2 * BK;
         if (rider) CS::store(o, acc);

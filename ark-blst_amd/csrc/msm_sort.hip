@@ -250,15 +250,16 @@ void launch_coarseA(uint32_t c, dim3 grid, dim3 block, hipStream_t s, const uint
 }
 // the LDS-staged scatter exists for the window sizes whose coarse bins allow it (H <= 128: c <= 16)
 template <int CB = 7>
-void launch_coarse_staged(uint32_t c, dim3 grid, hipStream_t s, const uint32_t* scalars, const uint8_t* flags, const msmk::SortGeom& g,
+void launch_coarse_staged(uint32_t c, bool co, dim3 grid, hipStream_t s, const uint32_t* scalars, const uint8_t* flags, const msmk::SortGeom& g,
                           const uint32_t* tilecnt, const uint32_t* tileoff, const uint32_t* bin_base, uint32_t* coarse) {
     if constexpr (CB > 16) {
         throw HipFail{"staged coarse scatter: window_bits out of range"};
     } else {
         if (c == CB)
-            hipLaunchKernelGGL((msmk::k_coarse_staged<CB>), grid, dim3(256), msmk::COARSE_STAGED_LDS, s, scalars, flags, g, tilecnt, tileoff, bin_base, coarse);
+            if (co) hipLaunchKernelGGL((msmk::k_coarse_staged_co<CB>), grid, dim3(256), msmk::COARSE_STAGED_CO_LDS, s, scalars, flags, g, tilecnt, tileoff, bin_base, coarse);
+            else hipLaunchKernelGGL((msmk::k_coarse_staged<CB>), grid, dim3(512), 0, s, scalars, flags, g, tilecnt, tileoff, bin_base, coarse);
         else
-            launch_coarse_staged<CB + 1>(c, grid, s, scalars, flags, g, tilecnt, tileoff, bin_base, coarse);
+            launch_coarse_staged<CB + 1>(c, co, grid, s, scalars, flags, g, tilecnt, tileoff, bin_base, coarse);
     }
 }
 
@@ -374,8 +375,10 @@ void sort_and_schedule(DevState& d, Scratch& sc, hipStream_t s, const Plan& pl, 
     uint32_t coarse_block;
     if (staged) {
         g.wgroup = std::min<uint32_t>(std::min<uint32_t>(pl.nwin, 16), msmk::COARSE_STAGE_BINS / g.H);
-        g.tile_pts = (msmk::COARSE_STAGE / g.wgroup) / 256 * 256;   // >= 768 points; tile_pts * wgroup entries fit the staging buffer
-        coarse_block = 256;   // as k_coarse_staged
+        // tile_pts * wgroup entries fit the staging buffer of the kernel that will run: k_coarse_staged (512 lanes, 16384 entries) or, beside an
+        // accumulate kernel, k_coarse_staged_co (256 lanes, 14336 entries)
+        g.tile_pts = under_accumulate ? (msmk::COARSE_STAGE_CO / g.wgroup) / 256 * 256 : (msmk::COARSE_STAGE / g.wgroup) / 512 * 512;
+        coarse_block = under_accumulate ? 256 : 512;
     } else {
         size_t want = std::max<size_t>(std::max<size_t>(4096, n / 512), (size_t)64 * g.H / (shared_buckets ? pl.nwin : 1));
         g.tile_pts = (uint32_t)((std::min(want, n) + 1023) / 1024 * 1024);
@@ -395,7 +398,7 @@ void sort_and_schedule(DevState& d, Scratch& sc, hipStream_t s, const Plan& pl, 
                        (uint32_t*)sc.tileoff.p, (uint32_t*)sc.bin_tot.p);
     hipLaunchKernelGGL(msmk::k_binscan, dim3(1), dim3(1024), 0, s, (const uint32_t*)sc.bin_tot.p, g.nbins, (uint32_t*)sc.bin_base.p);
     if (staged)
-        launch_coarse_staged(pl.c, dim3(g.tiles, g.ngroups), s, d_scalars, d_flags, g, (const uint32_t*)sc.tilecnt.p, (const uint32_t*)sc.tileoff.p,
+        launch_coarse_staged(pl.c, under_accumulate, dim3(g.tiles, g.ngroups), s, d_scalars, d_flags, g, (const uint32_t*)sc.tilecnt.p, (const uint32_t*)sc.tileoff.p,
                              (const uint32_t*)sc.bin_base.p, (uint32_t*)sc.coarse.p);
     else
         launch_coarse<true>(pl.c, dim3(g.tiles, g.ngroups), dim3(coarse_block), s, d_scalars, d_flags, g, (uint32_t*)sc.tilecnt.p,
@@ -413,8 +416,9 @@ void sort_and_schedule(DevState& d, Scratch& sc, hipStream_t s, const Plan& pl, 
     hipLaunchKernelGGL(msmk::k_fine_scatter, dim3(segs_cap), dim3(256), msmk::FINE_SCATTER_LDS, s, (const uint32_t*)sc.coarse.p, (const uint32_t*)sc.bin_base.p,
                        (const uint32_t*)sc.seg_base.p, g, (const uint32_t*)sc.segcnt.p, (const uint32_t*)sc.segoff.p, (uint32_t*)sc.sorted.p);
     if (phases) HIP_TRY(hipEventRecord(sc.ev[2], s));
-    // ---- schedule: <= SCHED_MAX_BLK blocks of SCHED_NT lanes, each lane owning per_blk / SCHED_NT consecutive buckets
-    uint32_t per_blk = 4 * msmk::SCHED_NT;   // four buckets per lane (one per lane measured slower below 2^23 points: 0.073 against 0.043 ms)
+    // ---- schedule: <= SCHED_MAX_BLK blocks of 1024 (beside an accumulate kernel: 512) lanes, each lane owning per_blk / lanes consecutive buckets
+    const uint32_t sched_nt = under_accumulate ? 512 : 1024;
+    uint32_t per_blk = 4 * sched_nt;   // four buckets per lane (one per lane measured slower below 2^23 points: 0.073 against 0.043 ms)
     while ((pl.nbuckets + per_blk - 1) / per_blk > msmk::SCHED_MAX_BLK) per_blk <<= 1;
     uint32_t nblk = (uint32_t)((pl.nbuckets + per_blk - 1) / per_blk);
     // every bucket has at least one item (an empty bucket's item leaves infinity for the reduce), plus one per S entries of the split ones
@@ -431,14 +435,18 @@ void sort_and_schedule(DevState& d, Scratch& sc, hipStream_t s, const Plan& pl, 
     uint32_t* blk_i = blk_e + nblk;
     uint32_t* blk_max = blk_i + nblk;
     uint32_t* blk_cls = blk_max + nblk;
-    hipLaunchKernelGGL(msmk::k_sched1, dim3(nblk), dim3(msmk::SCHED_NT), 0, s, (const uint32_t*)sc.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT | (pl.cls_shift << 8) | (pl.logS << 16),
-                       nblk, blk_e, blk_i, blk_cls, blk_max);
-    hipLaunchKernelGGL(msmk::k_sched2, dim3(1), dim3(msmk::SCHED_NT), 0, s, nblk, blk_e, blk_i, blk_cls, (const uint32_t*)blk_max,
-                       (uint32_t*)sc.meta.p);
-    hipLaunchKernelGGL(msmk::k_sched3, dim3(nblk), dim3(msmk::SCHED_NT), 0, s, (const uint32_t*)sc.hist.p, (uint32_t)pl.nbuckets, per_blk, pl.logT | (pl.cls_shift << 8) | (pl.logS << 16),
-                       nblk, (const uint32_t*)blk_e, (const uint32_t*)blk_i, (const uint32_t*)blk_cls, (uint32_t*)sc.offsets.p,
-                       (uint32_t*)sc.woff.p, (uint32_t*)sc.order.p, (uint32_t*)sc.item_bucket.p, (uint32_t*)sc.merge_list.p,
-                       (uint32_t*)sc.meta.p);
+    const uint32_t packed = pl.logT | (pl.cls_shift << 8) | (pl.logS << 16);
+    auto schedule = [&](auto nt_tag) {
+        constexpr uint32_t NT = decltype(nt_tag)::value;
+        hipLaunchKernelGGL(msmk::k_sched1<NT>, dim3(nblk), dim3(NT), 0, s, (const uint32_t*)sc.hist.p, (uint32_t)pl.nbuckets, per_blk, packed, nblk, blk_e, blk_i, blk_cls,
+                           blk_max);
+        hipLaunchKernelGGL(msmk::k_sched2<NT>, dim3(1), dim3(NT), 0, s, nblk, blk_e, blk_i, blk_cls, (const uint32_t*)blk_max, (uint32_t*)sc.meta.p);
+        hipLaunchKernelGGL(msmk::k_sched3<NT>, dim3(nblk), dim3(NT), 0, s, (const uint32_t*)sc.hist.p, (uint32_t)pl.nbuckets, per_blk, packed, nblk, (const uint32_t*)blk_e,
+                           (const uint32_t*)blk_i, (const uint32_t*)blk_cls, (uint32_t*)sc.offsets.p, (uint32_t*)sc.woff.p, (uint32_t*)sc.order.p,
+                           (uint32_t*)sc.item_bucket.p, (uint32_t*)sc.merge_list.p, (uint32_t*)sc.meta.p);
+    };
+    if (under_accumulate) schedule(std::integral_constant<uint32_t, 512>{});
+    else schedule(std::integral_constant<uint32_t, 1024>{});
     // the merge launches are sized by the schedule's counts: one small read-back into pinned memory, waited for by read_schedule
     HIP_TRY(hipMemcpyAsync(sc.h_meta, sc.meta.p, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(sc.ev[3], s));

@@ -11,6 +11,7 @@
 #include <string>
 
 #include "../../include/arkblst_amd_rccl.h"
+#include "deadline.hpp"
 
 static_assert(MI_RCCL_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
 
@@ -81,6 +82,12 @@ struct mi_rccl_comm {
     Header* h_hdr = nullptr;     // pinned staging of this rank's header
     std::mutex mu;
     mi_rccl_timing timing{};
+    double timeout_ms = 60000.0;   // mi_rccl_comm_set_timeout_ms: how long a rank waits inside the exchange for its peers
+    bool aborted = false;          // the communicator was aborted after a timeout / an asynchronous error: every later call fails at once
+    // window size the ranks agreed on after a disagreement, and the n of THIS rank it was for: pinned for the duration of later calls with
+    // the same n, so that they agree at the first attempt (the caller's context is left as it was: ADVICE r05)
+    unsigned agreed_c = 0;
+    size_t agreed_for_n = 0;
 };
 
 namespace {
@@ -95,38 +102,106 @@ int finish_create(mi_rccl_comm* c) {
     return MI_OK;
 }
 
+// the caller's window-size setting is restored on every path out of the call
+struct WindowBitsGuard {
+    mi_ctx* ctx;
+    unsigned saved = 0;
+    bool armed = false;
+    explicit WindowBitsGuard(mi_ctx* c) : ctx(c) { armed = mi_msm_get_window_bits(ctx, &saved) == MI_OK; }
+    ~WindowBitsGuard() { if (armed) (void)mi_msm_set_window_bits(ctx, saved); }
+};
+
+// After a timeout or an asynchronous error the communicator is unusable: abort it (peers blocked in the same collective then see an
+// error instead of waiting for ever) and fail every later call.  A communicator the host program attached stays the program's to destroy.
+void abort_comm(mi_rccl_comm* c) {
+    if (c->aborted) return;
+    c->aborted = true;
+    if (c->comm) (void)ncclCommAbort(c->comm);
+    if (c->owns_comm) c->comm = nullptr;
+    (void)hipGetLastError();
+}
+
 template <class Jac, class Windows, class Fold>
 int allgather_fold(mi_rccl_comm* c, const void* d_scalars, size_t n, unsigned fmt, Jac* out, Windows device_windows, Fold fold_windows) {
     if (!c || !out || (n && !d_scalars)) return fail(MI_E_INVALID, "invalid argument");
     std::lock_guard<std::mutex> lk(c->mu);
+    if (c->aborted || !c->comm) return fail(MI_E_COMM, "the communicator was aborted by an earlier failure: create a new one");
     DeviceGuard dg(c->device);
+    WindowBitsGuard restore(c->ctx);
     constexpr size_t JAC = sizeof(Jac);
     const size_t block = SLOTS * JAC;
     mi_rccl_timing tm{};
     tm.bytes_per_rank = (uint32_t)block;
+    if (c->agreed_c && c->agreed_for_n == n && restore.saved == 0) (void)mi_msm_set_window_bits(c->ctx, c->agreed_c);   // what this shard size agreed on before
     for (uint32_t attempt = 0;; attempt++) {
-        // ---- local part: this rank's shard through the single-GPU pipeline; the window sums stay in device memory
+        // ---- local part: this rank's shard through the single-GPU pipeline; the window sums stay in device memory.  From here to the
+        // all-gather NOTHING returns: a failure is recorded and travels as a FAILED header, so that no peer is left waiting for this rank
         auto t0 = std::chrono::steady_clock::now();
         mi_window_info info{};
         int local_rc = MI_OK;
         std::string local_msg;
+        auto local_fail = [&](int code, const std::string& msg) {
+            if (local_rc == MI_OK) { local_rc = code; local_msg = msg; }
+            info = mi_window_info{FAILED, 0};
+        };
         if (n) {
-            local_rc = device_windows(c->ctx, d_scalars, n, fmt, c->d_send + JAC, &info);
-            if (local_rc != MI_OK) {   // e.g. n beyond this rank's resident shard: the other ranks are already on their way into the all-gather
-                local_msg = std::string("device_windows: ") + mi_msm_last_error(c->ctx);
-                info = mi_window_info{FAILED, 0};
-            }
+            int rc = device_windows(c->ctx, d_scalars, n, fmt, c->d_send + JAC, &info);
+            if (rc != MI_OK) local_fail(rc, std::string("device_windows: ") + mi_msm_last_error(c->ctx));   // e.g. n beyond this rank's resident shard
         } else {
-            HIP_RC(hipMemsetAsync(c->d_send, 0, block, c->stream));   // Z = 0 everywhere: the point at infinity per window
+            hipError_t e = hipMemsetAsync(c->d_send, 0, block, c->stream);   // Z = 0 everywhere: the point at infinity per window
+            if (e != hipSuccess) { (void)hipGetLastError(); local_fail(MI_E_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e)); }
         }
         tm.msm_ms += ms_since(t0);
         // ---- exchange: header + window sums of every rank in ONE all-gather, one D2H of the gathered block, fold on every rank
         auto t1 = std::chrono::steady_clock::now();
         *c->h_hdr = Header{MAGIC, info.window_bits, info.num_windows, 0, (uint64_t)n};
-        HIP_RC(hipMemcpyAsync(c->d_send, c->h_hdr, sizeof(Header), hipMemcpyHostToDevice, c->stream));
-        NCCL_RC(ncclAllGather(c->d_send, c->d_recv, block, ncclUint8, c->comm, c->stream));
-        HIP_RC(hipMemcpyAsync(c->h_recv, c->d_recv, (size_t)c->n_ranks * block, hipMemcpyDeviceToHost, c->stream));
-        HIP_RC(hipStreamSynchronize(c->stream));
+        hipError_t he = hipMemcpyAsync(c->d_send, c->h_hdr, sizeof(Header), hipMemcpyHostToDevice, c->stream);
+        if (he != hipSuccess) {
+            // not even the failure mark can be sent: abort the communicator, the peers' collective ends with an error instead of hanging
+            (void)hipGetLastError();
+            abort_comm(c);
+            return fail(local_rc != MI_OK ? local_rc : MI_E_HIP, local_rc != MI_OK ? local_msg : std::string("hipMemcpyAsync(header): ") + hipGetErrorString(he));
+        }
+        ncclResult_t nr = ncclAllGather(c->d_send, c->d_recv, block, ncclUint8, c->comm, c->stream);
+        if (nr != ncclSuccess) {
+            abort_comm(c);
+            return nccl_fail(nr, "ncclAllGather");
+        }
+        he = hipMemcpyAsync(c->h_recv, c->d_recv, (size_t)c->n_ranks * block, hipMemcpyDeviceToHost, c->stream);
+        if (he != hipSuccess) {   // the collective itself is complete-able by the peers: no abort needed, this rank just has no result
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(c->stream);
+            return hip_fail(he, "hipMemcpyAsync(gathered block)");
+        }
+        // wait with a deadline: a peer that never arrives must not hang this rank for ever
+        hipError_t stream_err = hipSuccess;
+        ncclResult_t async_err = ncclSuccess;
+        double waited = 0;
+        const mi::WaitResult wr = mi::wait_deadline(
+            [&] {
+                hipError_t q = hipStreamQuery(c->stream);
+                if (q == hipSuccess) return true;
+                if (q != hipErrorNotReady) stream_err = q;
+                return false;
+            },
+            [&] {
+                if (stream_err != hipSuccess) return true;
+                ncclResult_t a = ncclSuccess;
+                if (ncclCommGetAsyncError(c->comm, &a) != ncclSuccess) return false;
+                if (a != ncclSuccess && a != ncclInProgress) { async_err = a; return true; }
+                return false;
+            },
+            c->timeout_ms, &waited);
+        if (wr != mi::WaitResult::Done) {
+            (void)hipGetLastError();
+            abort_comm(c);
+            tm.exchange_ms += ms_since(t1);
+            c->timing = tm;
+            if (wr == mi::WaitResult::TimedOut)
+                return fail(MI_E_COMM, "the all-gather did not complete within " + std::to_string((long)c->timeout_ms) + " ms (a peer never arrived?): communicator aborted");
+            return fail(MI_E_COMM, stream_err != hipSuccess ? std::string("stream error during the all-gather: ") + hipGetErrorString(stream_err)
+                                                            : std::string("asynchronous RCCL error: ") + ncclGetErrorString(async_err));
+        }
         // every rank reads the same headers and therefore takes the same decision below
         mi_window_info agreed{};
         bool same = true;
@@ -146,8 +221,11 @@ int allgather_fold(mi_rccl_comm* c, const void* d_scalars, size_t n, unsigned fm
             tm.exchange_ms += ms_since(t1);
             if (attempt >= 1)
                 return fail(MI_E_INVALID, "ranks disagree on the window geometry with the window size pinned (validated and unvalidated base sets mixed?)");
-            int rc = mi_msm_set_window_bits(c->ctx, cmax);
-            if (rc != MI_OK) return fail(rc, "mi_msm_set_window_bits");
+            // pin the largest window size FOR THIS CALL (WindowBitsGuard puts the caller's setting back) and remember it for this shard size.
+            // A failure to pin it does not leave the loop: the repeated local part then disagrees again and every rank fails together above
+            c->agreed_c = cmax;
+            c->agreed_for_n = n;
+            (void)mi_msm_set_window_bits(c->ctx, cmax);
             tm.repeats++;
             continue;
         }
@@ -248,7 +326,7 @@ void mi_rccl_comm_destroy(mi_rccl_comm* c) {
     {
         DeviceGuard dg(c->device);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
-        if (c->owns_comm && c->comm) (void)ncclCommDestroy(c->comm);
+        if (c->owns_comm && c->comm) (void)(c->aborted ? ncclCommAbort(c->comm) : ncclCommDestroy(c->comm));
         if (c->d_send) (void)hipFree(c->d_send);
         if (c->d_recv) (void)hipFree(c->d_recv);
         if (c->h_recv) (void)hipHostFree(c->h_recv);
@@ -256,6 +334,13 @@ void mi_rccl_comm_destroy(mi_rccl_comm* c) {
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
+}
+
+int mi_rccl_comm_set_timeout_ms(mi_rccl_comm* c, double timeout_ms) {
+    if (!c || !(timeout_ms >= 0)) return fail(MI_E_INVALID, "invalid argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->timeout_ms = timeout_ms;
+    return MI_OK;
 }
 
 int mi_rccl_comm_size(const mi_rccl_comm* c) { return c ? c->n_ranks : 0; }

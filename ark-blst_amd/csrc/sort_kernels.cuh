@@ -73,24 +73,76 @@ __global__ void __launch_bounds__(1024) k_coarse(const uint32_t* __restrict__ sc
 // group of windows small enough that ALL its entries fit in LDS (<= 16384 entries, 64 KB), counting-sorts them by bin there
 // (positions from the tile's own counts) and writes them out in order: every (tile, bin) run — >= 32 entries — leaves as
 // consecutive words instead of one 4-byte store per entry through an LDS cursor.
-// LDS of the staged kernels below is DYNAMIC (extern __shared__, the size passed at launch; round 6).  With a large static array the
+constexpr uint32_t COARSE_STAGE = 16384;
+constexpr uint32_t COARSE_STAGE_BINS = 512;
+template <int CB>
+__global__ void __launch_bounds__(512) k_coarse_staged(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flags, SortGeom g,
+                                                       const uint32_t* __restrict__ tilecnt, const uint32_t* __restrict__ tileoff,
+                                                       const uint32_t* __restrict__ bin_base, uint32_t* __restrict__ coarse) {
+        aux_priority();
+    __shared__ uint32_t stage[COARSE_STAGE];
+    __shared__ uint32_t lstart[COARSE_STAGE_BINS + 1], cur[COARSE_STAGE_BINS], goff[COARSE_STAGE_BINS];
+    const uint32_t tile = blockIdx.x, grp = blockIdx.y, t = threadIdx.x, nt = 512;
+    const uint32_t wend = g.win0 + g.nwin;
+    const uint32_t w0 = g.win0 + grp * g.wgroup, w1 = w0 + g.wgroup < wend ? w0 + g.wgroup : wend;
+    const uint32_t bin0 = (w0 - g.win0) * g.H, ncnt = (w1 - w0) * g.H;   // ncnt <= COARSE_STAGE_BINS
+    const uint32_t mine = t < ncnt ? tilecnt[(size_t)tile * g.nbins + bin0 + t] : 0u;
+    goff[t] = t < ncnt ? bin_base[bin0 + t] + tileoff[(size_t)tile * g.nbins + bin0 + t] : 0u;
+    cur[t] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < COARSE_STAGE_BINS; d <<= 1) {   // inclusive scan of the counts
+        uint32_t v = t >= d ? cur[t - d] : 0;
+        __syncthreads();
+        cur[t] += v;
+        __syncthreads();
+    }
+    const uint32_t excl = cur[t] - mine;
+    __syncthreads();
+    lstart[t] = excl;
+    cur[t] = excl;
+    if (t == COARSE_STAGE_BINS - 1) lstart[COARSE_STAGE_BINS] = excl + mine;
+    __syncthreads();
+    const uint32_t total = lstart[COARSE_STAGE_BINS];
+    const uint32_t lo_mask = (1u << g.lo_bits) - 1u;
+    const uint32_t p0 = tile * g.tile_pts, p1 = p0 + g.tile_pts < g.n ? p0 + g.tile_pts : g.n;
+    for (uint32_t i = p0 + t; i < p1; i += nt) {
+        if (inf_flags[i] != 0) continue;
+        uint32_t s[8];
+        const bool flip = load_scalar(s, scalars, i, g.fmt);
+        for_each_digit_static<CB>(s, flip, w0, w1, [&](uint32_t w, uint32_t b, bool neg) {
+            uint32_t k = (w - w0) * g.H + (b >> g.lo_bits);
+            uint32_t pos = atomicAdd(&cur[k], 1u);
+            stage[pos] = (i << (g.lo_bits + 1)) | ((neg ? 1u : 0u) << g.lo_bits) | (b & lo_mask);
+        });
+    }
+    __syncthreads();
+    for (uint32_t j = t; j < total; j += nt) {
+        uint32_t k = 0;   // the bin whose run holds position j
+#pragma unroll
+        for (uint32_t step = COARSE_STAGE_BINS / 2; step >= 1; step >>= 1)
+            if (lstart[k + step] <= j) k += step;
+        coarse[goff[k] + (j - lstart[k])] = stage[j];
+    }
+}
+
+// ---- the same kernel for launches that run BESIDE an accumulate kernel (the later groups of a pipelined call, run_msm): 256 lanes, two
+// bins per lane, and DYNAMIC LDS (extern __shared__, the size passed at launch; k_fine_scatter / k_mid_scatter likewise).  With a large static array the
 // compiler derives the kernel's maximum occupancy from it and PADS the register allocation up to the most that occupancy allows (72 KB
 // and 256 lanes: two waves per SIMD, so 176 registers are allocated for a kernel that uses 52; 36 KB: 104 for one that uses 20 — read off the
 // kernel descriptors, tools/kernel_resources.py).  Alone that costs nothing; beside an accumulate kernel, which leaves 80 registers per
 // lane and SIMD, such a workgroup waits for accumulate waves to retire on all four SIMDs of a compute unit (tools/ubench_coresidency.hip).
-constexpr uint32_t COARSE_STAGE = 14336;   // entries staged per workgroup; with the three bin arrays below 62 KB, under the 64 KB a launch may ask for without a function attribute
-constexpr uint32_t COARSE_STAGE_BINS = 512;
-constexpr uint32_t COARSE_STAGED_LDS = (COARSE_STAGE + 3 * COARSE_STAGE_BINS + 1) * 4;
+constexpr uint32_t COARSE_STAGE_CO = 14336;   // entries staged per workgroup; with the three bin arrays below 62 KB, under the 64 KB a launch may ask for without a function attribute
+constexpr uint32_t COARSE_STAGED_CO_LDS = (COARSE_STAGE_CO + 3 * COARSE_STAGE_BINS + 1) * 4;
 template <int CB>
-__global__ void __launch_bounds__(256) k_coarse_staged(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flags, SortGeom g,
+__global__ void __launch_bounds__(256) k_coarse_staged_co(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flags, SortGeom g,
                                                        const uint32_t* __restrict__ tilecnt, const uint32_t* __restrict__ tileoff,
                                                        const uint32_t* __restrict__ bin_base, uint32_t* __restrict__ coarse) {
     aux_priority();
     // 256 lanes, two bins per lane (round 6; it was 512 lanes): one wave per SIMD with 56 registers finds room beside the two resident waves
     // of an accumulate kernel (2 x 216 of 512 registers per lane), two did not — in a pipelined call this kernel runs under one (see AUX_BLOCK)
     extern __shared__ uint32_t dyn_lds[];
-    uint32_t* const stage = dyn_lds;                                  // [COARSE_STAGE]
-    uint32_t* const lstart = stage + COARSE_STAGE;                    // [COARSE_STAGE_BINS + 1]
+    uint32_t* const stage = dyn_lds;                                  // [COARSE_STAGE_CO]
+    uint32_t* const lstart = stage + COARSE_STAGE_CO;                    // [COARSE_STAGE_BINS + 1]
     uint32_t* const cur = lstart + COARSE_STAGE_BINS + 1;             // [COARSE_STAGE_BINS]
     uint32_t* const goff = cur + COARSE_STAGE_BINS;                   // [COARSE_STAGE_BINS]
     constexpr uint32_t NT = 256;
@@ -528,12 +580,11 @@ __global__ void __launch_bounds__(256) k_mid_scatter(const uint2* __restrict__ c
 //   * order[] lists item ids by DESCENDING length class (65 classes): the 64 lanes of a wave then run the same
 //     number of additions (bucket loads are Poisson distributed: unsorted, a wave waits for its longest lane,
 //     ~70 % lane efficiency at a mean of 32) and the longest items start first.
-// Layout: nblk <= SCHED_MAX_BLK blocks of SCHED_NT lanes; block k owns `per_blk` consecutive buckets, lane t owns
-// per_blk / SCHED_NT consecutive ones.  item id of (bucket b, chunk k) = woff[b] + k.
-// SCHED_NT = 512 (round 6; 1024 before): two waves per SIMD of <= 32 registers find room beside the two resident waves of an accumulate
-// kernel (80 of 512 registers per lane are left), four did not — in a pipelined call the schedule of group g + 1 runs under accumulate(g).
+// Layout: nblk <= SCHED_MAX_BLK blocks of NT lanes; block k owns `per_blk` consecutive buckets, lane t owns per_blk / NT consecutive ones.  item id of (bucket b, chunk k) = woff[b] + k.
+// The kernels are templates over the workgroup size NT: 1024 lanes for a one-group call; 512 for the later groups of a pipelined call (round 6),
+// whose schedule runs under an accumulate kernel — two waves per SIMD of <= 32 registers find room beside its two resident waves (80 of
+// 512 registers per lane are left), four do not.
 constexpr int SCHED_CLASSES = 65;
-constexpr uint32_t SCHED_NT = 512, SCHED_LOG_NT = 9;
 
 // A bucket of up to T = 2^logT entries is ONE item; a fuller one is split into items of S = 2^logS entries, S = max(16, T / 4) (round 4: it
 // was T).  Skewed scalars (witness bits: half the scalars are 0 or 1) put 10^5..10^6 entries into one bucket; with items of T = 64 a lane
@@ -550,7 +601,8 @@ __device__ __forceinline__ uint32_t last_len(uint32_t cnt, uint32_t it, uint32_t
 // or the lanes of a wave walk items of visibly different lengths (measured +8 % on the accumulate kernel at 2^24).
 __device__ __forceinline__ uint32_t class_of(uint32_t len, uint32_t cls_shift) { uint32_t c = len >> cls_shift; return c < 64 ? c : 64; }
 
-__global__ void __launch_bounds__(SCHED_NT) k_sched1(const uint32_t* __restrict__ hist, uint32_t m, uint32_t per_blk, uint32_t logT,
+template <uint32_t NT>
+__global__ void __launch_bounds__(NT) k_sched1(const uint32_t* __restrict__ hist, uint32_t m, uint32_t per_blk, uint32_t logT,
                                                  uint32_t nblk, uint32_t* __restrict__ blk_e, uint32_t* __restrict__ blk_i,
                                                  uint32_t* __restrict__ blk_cls, uint32_t* __restrict__ blk_max) {
     aux_priority();
@@ -560,7 +612,7 @@ __global__ void __launch_bounds__(SCHED_NT) k_sched1(const uint32_t* __restrict_
     if (t < SCHED_CLASSES) cls[t] = 0;
     if (t == 0) { se = 0; si = 0; smax = 1; }
     __syncthreads();
-    uint32_t per_t = per_blk >> SCHED_LOG_NT;
+    uint32_t per_t = per_blk / NT;
     uint32_t lo = blk * per_blk + t * per_t, hi = lo + per_t < m ? lo + per_t : m;
     const uint32_t cls_shift = (logT >> 8) & 0xffu, logS = (logT >> 16) & 0xffu;   // the launch packs log2 T | class shift << 8 | log2 S << 16
     logT &= 0xffu;
@@ -585,33 +637,50 @@ __global__ void __launch_bounds__(SCHED_NT) k_sched1(const uint32_t* __restrict_
 // (1024 blocks since round 5: at 2^24 points the 6.8 M buckets were spread over 208 blocks, 32 consecutive buckets per lane — one lane per
 // 128-byte line, one block per CU — and k_sched1 / k_sched3 took 0.12 + 0.50 ms)
 constexpr uint32_t SCHED_MAX_BLK = 1024;
-__global__ void __launch_bounds__(SCHED_NT) k_sched2(uint32_t nblk, uint32_t* __restrict__ blk_e, uint32_t* __restrict__ blk_i,
+template <uint32_t NT>
+__global__ void __launch_bounds__(NT) k_sched2(uint32_t nblk, uint32_t* __restrict__ blk_e, uint32_t* __restrict__ blk_i,
                                                  uint32_t* __restrict__ blk_cls, const uint32_t* __restrict__ blk_max,
                                                  uint32_t* __restrict__ meta) {
     aux_priority();
     __shared__ uint32_t a[SCHED_MAX_BLK], b[SCHED_MAX_BLK], ctot[SCHED_CLASSES], cbase[SCHED_CLASSES];
     uint32_t t = threadIdx.x;
-    static_assert(SCHED_MAX_BLK == 2 * SCHED_NT, "two block sums per lane");
-    const uint32_t t2 = t + SCHED_NT;
-    const uint32_t ve = t < nblk ? blk_e[t] : 0, vi = t < nblk ? blk_i[t] : 0;
-    const uint32_t ve2 = t2 < nblk ? blk_e[t2] : 0, vi2 = t2 < nblk ? blk_i[t2] : 0;
-    a[t] = ve; a[t2] = ve2;
-    b[t] = vi; b[t2] = vi2;
+    constexpr uint32_t PER = SCHED_MAX_BLK / NT;   // block sums per lane (1 or 2)
+    static_assert(PER == 1 || PER == 2, "k_sched2: 512 or 1024 lanes");
+    uint32_t ve[PER], vi[PER];
+#pragma unroll
+    for (uint32_t r = 0; r < PER; r++) {
+        const uint32_t k = t + NT * r;
+        ve[r] = k < nblk ? blk_e[k] : 0;
+        vi[r] = k < nblk ? blk_i[k] : 0;
+        a[k] = ve[r];
+        b[k] = vi[r];
+    }
     __syncthreads();
     for (uint32_t d = 1; d < SCHED_MAX_BLK; d <<= 1) {
-        uint32_t xa = 0, xb = 0;
-        if (t >= d) { xa = a[t - d]; xb = b[t - d]; }
-        const uint32_t xa2 = a[t2 - d], xb2 = b[t2 - d];   // d <= SCHED_NT <= t2
+        uint32_t xa[PER], xb[PER];
+#pragma unroll
+        for (uint32_t r = 0; r < PER; r++) {
+            const uint32_t k = t + NT * r;
+            xa[r] = k >= d ? a[k - d] : 0;
+            xb[r] = k >= d ? b[k - d] : 0;
+        }
         __syncthreads();
-        a[t] += xa; a[t2] += xa2;
-        b[t] += xb; b[t2] += xb2;
+#pragma unroll
+        for (uint32_t r = 0; r < PER; r++) {
+            const uint32_t k = t + NT * r;
+            a[k] += xa[r];
+            b[k] += xb[r];
+        }
         __syncthreads();
     }
-    if (t < nblk) { blk_e[t] = a[t] - ve; blk_i[t] = b[t] - vi; }
-    if (t2 < nblk) { blk_e[t2] = a[t2] - ve2; blk_i[t2] = b[t2] - vi2; }
-    // class rows: wave w handles classes w, w+8, ...; exclusive scan of each row in chunks of 64 lanes
+#pragma unroll
+    for (uint32_t r = 0; r < PER; r++) {
+        const uint32_t k = t + NT * r;
+        if (k < nblk) { blk_e[k] = a[k] - ve[r]; blk_i[k] = b[k] - vi[r]; }
+    }
+    // class rows: wave w handles classes w, w + NT / 64, ...; exclusive scan of each row in chunks of 64 lanes
     uint32_t wave = t >> 6, lane = t & 63;
-    for (uint32_t c = wave; c < SCHED_CLASSES; c += SCHED_NT / 64) {
+    for (uint32_t c = wave; c < SCHED_CLASSES; c += NT / 64) {
         uint32_t run = 0;
         for (uint32_t base = 0; base < nblk; base += 64) {
             uint32_t idx = base + lane;
@@ -632,7 +701,7 @@ __global__ void __launch_bounds__(SCHED_NT) k_sched2(uint32_t nblk, uint32_t* __
         cbase[t] = above;
     }
     __syncthreads();
-    for (uint32_t idx = t; idx < SCHED_CLASSES * nblk; idx += SCHED_NT) blk_cls[idx] += cbase[idx / nblk];
+    for (uint32_t idx = t; idx < SCHED_CLASSES * nblk; idx += NT) blk_cls[idx] += cbase[idx / nblk];
     if (t == 0) {
         uint32_t mx = 1;
         for (uint32_t k = 0; k < nblk; k++) mx = blk_max[k] > mx ? blk_max[k] : mx;
@@ -646,14 +715,15 @@ __global__ void __launch_bounds__(SCHED_NT) k_sched2(uint32_t nblk, uint32_t* __
 }
 
 // per block: bucket-level exclusive scans -> offsets / cursor / woff; every item gets its slot in order[]
-__global__ void __launch_bounds__(SCHED_NT) k_sched3(const uint32_t* __restrict__ hist, uint32_t m, uint32_t per_blk, uint32_t logT,
+template <uint32_t NT>
+__global__ void __launch_bounds__(NT) k_sched3(const uint32_t* __restrict__ hist, uint32_t m, uint32_t per_blk, uint32_t logT,
                                                  uint32_t nblk, const uint32_t* __restrict__ blk_e, const uint32_t* __restrict__ blk_i,
                                                  const uint32_t* __restrict__ blk_cls, uint32_t* __restrict__ offsets,
                                                  uint32_t* __restrict__ woff,
                                                  uint32_t* __restrict__ order, uint32_t* __restrict__ item_bucket,
                                                  uint32_t* __restrict__ merge_list, uint32_t* __restrict__ meta) {
     aux_priority();
-    __shared__ uint32_t pe[SCHED_NT], pi[SCHED_NT], cur[SCHED_CLASSES];
+    __shared__ uint32_t pe[NT], pi[NT], cur[SCHED_CLASSES];
     // buckets split into many items (skewed scalars: one bucket can hold all N entries) are written out by the whole
     // workgroup after the per-lane pass; one lane doing it alone cost 0.65 ms for a bucket of 2^20 entries
     constexpr uint32_t HV_CAP = 512, HV_MIN = 64;   // (64 slots until round 4: the 128 buckets of a 7-bit top window overflowed them, and a lone lane wrote 4096 items each — 1.2 ms)
@@ -661,7 +731,7 @@ __global__ void __launch_bounds__(SCHED_NT) k_sched3(const uint32_t* __restrict_
     uint32_t t = threadIdx.x, blk = blockIdx.x;
     if (t == 0) hv_n = 0;
     if (t < SCHED_CLASSES) cur[t] = blk_cls[t * nblk + blk];
-    uint32_t per_t = per_blk >> SCHED_LOG_NT;
+    uint32_t per_t = per_blk / NT;
     uint32_t lo = blk * per_blk + t * per_t, hi = lo + per_t < m ? lo + per_t : m;
     const uint32_t cls_shift = (logT >> 8) & 0xffu, logS = (logT >> 16) & 0xffu;
     logT &= 0xffu;
@@ -674,7 +744,7 @@ __global__ void __launch_bounds__(SCHED_NT) k_sched3(const uint32_t* __restrict_
     pe[t] = sum_e;
     pi[t] = sum_i;
     __syncthreads();
-    for (uint32_t d = 1; d < SCHED_NT; d <<= 1) {
+    for (uint32_t d = 1; d < NT; d <<= 1) {
         uint32_t xe = t >= d ? pe[t - d] : 0, xi = t >= d ? pi[t - d] : 0;
         __syncthreads();
         pe[t] += xe;
@@ -706,12 +776,12 @@ __global__ void __launch_bounds__(SCHED_NT) k_sched3(const uint32_t* __restrict_
         run_e += h;
         run_i += it;
     }
-    if (blk == nblk - 1 && t == SCHED_NT - 1) { offsets[m] = run_e; woff[m] = run_i; }
+    if (blk == nblk - 1 && t == NT - 1) { offsets[m] = run_e; woff[m] = run_i; }
     __syncthreads();
     const uint32_t nh = hv_n < HV_CAP ? hv_n : HV_CAP;
     for (uint32_t s = 0; s < nh; s++) {
         const uint32_t k = hv_k[s], r0 = hv_run[s], it = hv_it[s], pos = hv_pos[s], mp = hv_mp[s];
-        for (uint32_t j = t; j < it; j += SCHED_NT) {
+        for (uint32_t j = t; j < it; j += NT) {
             if (j + 1 < it) { order[pos + j] = r0 + j; item_bucket[r0 + j] = k; }
             if (j % MERGE_FAN == 0) merge_list[mp + j / MERGE_FAN] = r0 + j;
         }

@@ -294,6 +294,7 @@ int mi_g2_fold_windows(const mi_g2 *windows, size_t n_ranks, size_t rank_stride,
 
 /* Tuning / introspection. window_bits = 0 restores the built-in heuristic (cf. calc_window_size, src/gpu.rs:218-223). */
 int mi_msm_set_window_bits(mi_ctx *ctx, unsigned window_bits);
+int mi_msm_get_window_bits(const mi_ctx *ctx, unsigned *window_bits);   /* the current setting (0 = built-in heuristic) */
 /* Window groups of a pipelined call.  From 2^17 points on, a call over plain (not precomputed) bases processes its digit windows in groups, top
  * windows first, each group with its own scratch: the sort of group g + 1 and the bucket reduction of group g - 1 run under the accumulate kernel
  * of group g on separate streams, and the host folds the window sums of a group while the GPU works on the next.  n_groups = 0

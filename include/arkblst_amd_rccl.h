@@ -38,6 +38,12 @@ int mi_rccl_comm_create(mi_rccl_comm **out, mi_ctx *ctx, const uint8_t id[MI_RCC
  * mi_rccl_comm_destroy.  Its device must be the context's. */
 int mi_rccl_comm_attach(mi_rccl_comm **out, mi_ctx *ctx, void *nccl_comm);
 
+/* How long a rank waits inside the exchange for its peers (milliseconds; default 60000; 0 = for ever).  When the deadline passes, or RCCL
+ * reports an asynchronous error, the call aborts the communicator (ncclCommAbort: peers blocked in the same collective get an error instead
+ * of waiting), returns MI_E_COMM, and every later call on this communicator fails at once with MI_E_COMM — the process is expected to exit
+ * or to build a new communicator.  Round 5 waited in hipStreamSynchronize for ever. */
+int mi_rccl_comm_set_timeout_ms(mi_rccl_comm *comm, double timeout_ms);
+
 void mi_rccl_comm_destroy(mi_rccl_comm *comm);
 int mi_rccl_comm_size(const mi_rccl_comm *comm);
 int mi_rccl_comm_rank(const mi_rccl_comm *comm);
@@ -45,8 +51,8 @@ int mi_rccl_comm_rank(const mi_rccl_comm *comm);
 /* Collective.  out = sum over ALL ranks of sum_i scalars_r[i] * bases_r[i], i < n_r: rank r passes ITS n_r scalars (device memory on the
  * context's device, synchronised by the caller as for mi_msm_g1_device) over the first n_r points of ITS resident shard; every rank
  * receives the same point.  Ranks may pass different n (0 included).  All ranks must arrive at the same window size: equal shard sizes
- * do; when they do not, the call pins the largest one on every rank's context (mi_msm_set_window_bits) and repeats the local part once —
- * later calls with the same sizes agree at once.  A rank whose local part fails (say n beyond its resident shard) still joins the all-gather with a
+ * do; when they do not, the call pins the largest one FOR ITS OWN DURATION (the context's mi_msm_set_window_bits setting is put back on every
+ * path out) and repeats the local part once; the communicator remembers the agreed size for this shard size, so later calls agree at once.  A rank whose local part fails (say n beyond its resident shard) still joins the all-gather with a
  * failure mark: it returns its own error, every other rank MI_E_COMM naming it — nobody is left waiting inside the collective.  Blocking. */
 int mi_msm_g1_allgather_fold(mi_rccl_comm *comm, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g1 *out);
 int mi_msm_g2_allgather_fold(mi_rccl_comm *comm, const void *d_scalars, size_t n, unsigned scalar_fmt, mi_g2 *out);

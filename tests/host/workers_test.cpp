@@ -5,6 +5,7 @@
 // -fsanitize=thread, -fsanitize=address,undefined.
 #define MI_TEST_HOOKS 1
 #include "../../ark-blst_amd/csrc/common.hpp"
+#include "../../ark-blst_amd/csrc/deadline.hpp"
 
 #include <cassert>
 #include <stdexcept>
@@ -206,6 +207,28 @@ int main() {
         ctx.cache_entries = 0;
         std::shared_ptr<BaseCacheEntry> none;
         CHECK(!cache_begin(&ctx, 0, sets[1].data(), 8192, none));
+    }
+    // 7. the exchange's wait with a deadline (multi_rccl.hip): a collective whose peer never arrives ends in TimedOut, an asynchronous error in
+    //    Failed, a completion signalled from another thread in Done — never in a hang
+    {
+        double waited = 0;
+        std::atomic<bool> never{false};
+        auto t0 = std::chrono::steady_clock::now();
+        CHECK(wait_deadline([&] { return never.load(); }, [] { return false; }, 30.0, &waited) == WaitResult::TimedOut);   // the never-signalled event
+        const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        CHECK(waited >= 30.0 && wall >= 30.0 && wall < 500.0);
+        std::atomic<int> polls{0};
+        CHECK(wait_deadline([&] { return false; }, [&] { return ++polls >= 5; }, 1000.0, &waited) == WaitResult::Failed && waited < 500.0);
+        std::atomic<bool> flag{false};
+        std::thread setter([&] { std::this_thread::sleep_for(std::chrono::milliseconds(5)); flag.store(true); });
+        CHECK(wait_deadline([&] { return flag.load(); }, [] { return false; }, 2000.0, &waited) == WaitResult::Done);
+        setter.join();
+        CHECK(waited >= 4.0 && waited < 1000.0);
+        CHECK(wait_deadline([] { return true; }, [] { return true; }, 1.0) == WaitResult::Done);        // completion wins over a late error
+        std::atomic<bool> late{false};
+        std::thread setter2([&] { std::this_thread::sleep_for(std::chrono::milliseconds(20)); late.store(true); });
+        CHECK(wait_deadline([&] { return late.load(); }, [] { return false; }, 0.0) == WaitResult::Done);   // 0 = no deadline
+        setter2.join();
     }
     printf("workers OK\n");
     return 0;

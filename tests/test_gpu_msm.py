@@ -1067,6 +1067,15 @@ def test_rccl_allgather_fold_world_size_one(pkg, co, group):
             assert ei.value.code == -1 and "resident" in str(ei.value)
             short = comm.allgather_fold(group, d_sc.data_ptr(), 100, pkg.SCALAR_CANONICAL)
             assert _canon(co, group, short) == _canon(co, group, co.msm(group, bases[:100 * (jac * 2 // 3)], sc[:3200], 100, 0, 1))
+            # round 6: the call leaves the context's window-size setting as it found it — pinned by the caller ...
+            comm.set_timeout_ms(5000)
+            c.set_window_bits(11)
+            pinned = comm.allgather_fold(group, d_sc.data_ptr(), n, pkg.SCALAR_CANONICAL)
+            assert _canon(co, group, pinned) == _canon(co, group, got) and comm.timing()["window_bits"] == 11 and c.get_window_bits() == 11
+            c.set_window_bits(0)
+            # ... or not at all
+            comm.allgather_fold(group, d_sc.data_ptr(), n, pkg.SCALAR_CANONICAL)
+            assert c.get_window_bits() == 0
         # a multi-device context is refused (one context per rank)
         with pkg.Context([0, 0]) as c2:
             with pytest.raises(pkg.MsmError):
