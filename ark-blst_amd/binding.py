@@ -3,12 +3,16 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SCALAR_CANONICAL, SCALAR_MONTGOMERY = 0, 1
 G1_AFF, G1_JAC, G2_AFF, G2_JAC = 96, 144, 192, 288
 FP12 = 576
 MAX_WINDOWS = 37   # MI_MAX_WINDOWS
+
+
+ABORT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)   # int (*check)(void *user): mi_msm_set_abort_check
 
 
 class WindowInfo(C.Structure):
@@ -88,6 +92,7 @@ def load_library(test_hooks: bool = False):
         L.mi_final_exponentiation.argtypes = [vp, vp]
         L.mi_msm_set_window_bits.argtypes = [vp, u]
         L.mi_msm_get_window_bits.argtypes = [vp, C.POINTER(u)]
+        L.mi_msm_set_abort_check.argtypes = [vp, ABORT_FN, vp]
         L.mi_msm_set_pipeline.argtypes = [vp, C.POINTER(u), u]
         L.mi_msm_set_base_cache.argtypes = [vp, u]
         L.mi_msm_invalidate_base_cache.argtypes = [vp]
@@ -126,12 +131,35 @@ def _buf(b):
     return C.cast(arr, C.c_void_p), arr
 
 
+def check_runtime_order():
+    """One HIP runtime per process.  The library links libamdhip64.so.7 by soname and a torch wheel bundles a runtime with
+    the same soname: whichever loads first serves both.  If this library was loaded BEFORE torch, torch's bundled HSA runtime ends up next to
+    the system one and torch.cuda reports "No HIP GPUs are available" — much later and far from the cause.  Refuse here, with the reason:
+    torch is imported, but the libamdhip64 mapped into the process is not the one from torch's own lib directory."""
+    torch = sys.modules.get("torch")
+    if torch is None or os.environ.get("ARKBLST_AMD_SKIP_RUNTIME_ORDER_CHECK"):
+        return
+    tlib = os.path.join(os.path.dirname(getattr(torch, "__file__", "") or ""), "lib")
+    if not os.path.exists(os.path.join(tlib, "libamdhip64.so")) and not any(f.startswith("libamdhip64.so") for f in (os.listdir(tlib) if os.path.isdir(tlib) else [])):
+        return   # this torch does not bundle a HIP runtime: nothing to order
+    try:
+        mapped = {line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64.so" in line}
+    except OSError:
+        return
+    foreign = sorted(m for m in mapped if not os.path.realpath(m).startswith(os.path.realpath(tlib)))
+    if foreign:   # loaded in the right order there is exactly one runtime in the process: torch's
+        raise ImportError("libarkblst_amd.so was loaded before torch: the process holds TWO HIP runtimes (" + ", ".join(sorted(mapped)) + "); torch's bundled "
+                          "one under " + tlib + " then finds no devices ('No HIP GPUs are available').  Import torch BEFORE the first ark_blst_amd "
+                          "context is created (INTEGRATION.md §6); ARKBLST_AMD_SKIP_RUNTIME_ORDER_CHECK=1 silences this check.")
+
+
 class Context:
     """Owns one mi_ctx (streams, resident bases, scratch).  device_ids=None -> device 0 only.
     test_hooks=True loads the test build of the library (extra mi_test_* entry points; tests only)."""
 
     def __init__(self, device_ids=None, test_hooks: bool = False):
         self._L = load_library(test_hooks)
+        check_runtime_order()
         self._h = C.c_void_p()
         if device_ids is None:
             device_ids = [0]
@@ -166,6 +194,12 @@ class Context:
 
     def set_window_bits(self, c: int):
         self._check(self._L.mi_msm_set_window_bits(self._h, c), "mi_msm_set_window_bits")
+
+    def set_abort_check(self, fn=None):
+        """The reference driver's maybe_abort (src/gpu.rs:58,133-137): fn() -> bool is asked at the start of every MSM call and between the
+        passes of a long one; True ends the call with MI_E_ABORTED (-8).  None removes the check."""
+        self._abort_cb = ABORT_FN(lambda _user: 1 if fn() else 0) if fn else C.cast(None, ABORT_FN)   # kept alive by the context
+        self._check(self._L.mi_msm_set_abort_check(self._h, self._abort_cb, None), "mi_msm_set_abort_check")
 
     def get_window_bits(self) -> int:
         v = C.c_uint(0)

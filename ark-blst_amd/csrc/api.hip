@@ -354,6 +354,14 @@ int mi_msm_set_window_bits(mi_ctx* ctx, unsigned window_bits) {
     return MI_OK;
 }
 
+int mi_msm_set_abort_check(mi_ctx* ctx, int (*check)(void*), void* user) {
+    if (!ctx) return MI_E_INVALID;
+    LaneLock lk(ctx, true);   // no call is in flight while the pair changes
+    ctx->abort_check = check;
+    ctx->abort_user = user;
+    return MI_OK;
+}
+
 int mi_msm_get_window_bits(const mi_ctx* ctx, unsigned* window_bits) {
     if (!ctx || !window_bits) return MI_E_INVALID;
     LaneLock lk(const_cast<mi_ctx*>(ctx), true);
@@ -407,6 +415,7 @@ const char* mi_msm_strerror(int code) {
         case MI_E_NO_BASES: return "no resident base set";
         case MI_E_UNSUPPORTED: return "not supported on this host (the library needs an x86-64 CPU with BMI2 and ADX)";
         case MI_E_COMM: return "RCCL communication error";
+        case MI_E_ABORTED: return "aborted by the caller's abort check";
         default: return "unknown error";
     }
 }

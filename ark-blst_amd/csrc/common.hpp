@@ -32,6 +32,7 @@ struct HipFail {
     std::string msg;
     bool oom = false;
     bool invalid = false;   // the caller's argument is at fault (MI_E_INVALID), not the runtime
+    bool aborted = false;   // the caller's abort check said stop (MI_E_ABORTED)
 };
 #define HIP_TRY(expr)                                                                                     \
     do {                                                                                                  \
@@ -291,6 +292,9 @@ struct mi_ctx {
     // window groups of a pipelined call (run_msm): 0 entries = the built-in choice; {1} = never pipeline; otherwise relative weights of the
     // groups, top windows first (mi_msm_set_pipeline / ARKBLST_AMD_PIPELINE)
     std::vector<unsigned> pipe_weights;
+    // the caller's abort check (mi_msm_set_abort_check): the reference driver's maybe_abort, src/gpu.rs:58,133-137
+    int (*abort_check)(void*) = nullptr;
+    void* abort_user = nullptr;
     bool pipe_two_acc_streams = false;   // ARKBLST_AMD_PIPELINE_ACC2=1: accumulate kernels of odd groups on a second normal-priority stream (see DevState::ensure_pipeline_streams)
     bool trace = false;   // ARKBLST_AMD_TRACE=1: MSM calls at profile level 2 print their phase boundaries to stderr (run_msm)
     // base-set cache of the stateless call shape (api.hip mi_msm_set_base_cache); [0] = G1, [1] = G2
@@ -525,6 +529,9 @@ struct LaneLock {
     DeviceWorkers* workers() { return c->workers[lane == 1 ? 1 : 0].get(); }
 };
 
+// true: the caller asked to stop (mi_msm_set_abort_check)
+inline bool abort_requested(const mi_ctx* ctx) { return ctx->abort_check && ctx->abort_check(ctx->abort_user) != 0; }
+
 inline void set_prof(mi_ctx* ctx, const mi_profile& p) {
     std::lock_guard<std::mutex> lk(ctx->info_mu);
     ctx->prof = p;
@@ -574,7 +581,7 @@ int guarded(mi_ctx* ctx, Fn fn) {
         return fn();
     } catch (const HipFail& e) {
         bool oom = e.oom || e.msg.find("out of memory") != std::string::npos;
-        return fail(ctx, e.invalid ? MI_E_INVALID : oom ? MI_E_NOMEM : MI_E_HIP, e.msg);
+        return fail(ctx, e.aborted ? MI_E_ABORTED : e.invalid ? MI_E_INVALID : oom ? MI_E_NOMEM : MI_E_HIP, e.msg);
     } catch (const std::bad_alloc&) {
         return fail(ctx, MI_E_NOMEM, "host allocation failed");
     } catch (const std::exception& e) {
@@ -594,7 +601,7 @@ void guarded_part(PartErr& e, Fn fn) noexcept {
     try {
         fn();
     } catch (const HipFail& f) {
-        e.code = f.invalid ? MI_E_INVALID : (f.oom || f.msg.find("out of memory") != std::string::npos) ? MI_E_NOMEM : MI_E_HIP;
+        e.code = f.aborted ? MI_E_ABORTED : f.invalid ? MI_E_INVALID : (f.oom || f.msg.find("out of memory") != std::string::npos) ? MI_E_NOMEM : MI_E_HIP;
         e.msg = f.msg;
     } catch (const std::bad_alloc&) {
         e.code = MI_E_NOMEM;

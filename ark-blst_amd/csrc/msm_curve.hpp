@@ -404,6 +404,8 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
         }
     } drain{d};
     for (size_t lo = 0; lo < n; lo += part_max) {   // one pass unless n exceeds the per-pass limit
+        // between two passes nothing of this call is on the GPU (run_msm returned): the place where the reference's driver asks maybe_abort
+        if (lo > 0 && abort_requested(ctx)) throw HipFail{"aborted by the caller's abort check between two passes", false, false, true};
         const size_t m = std::min(part_max, n - lo);
         if (d.prof_level >= 2) HIP_TRY(hipEventRecord(d.ev[0], s));
         // Host slices (the trait's call shape) cross PCIe in chunks on the lane's copy stream, each consumed as it lands: bases first
@@ -585,6 +587,7 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
     const uint8_t* bases = static_cast<const uint8_t*>(bases_v);
     if (!ctx || !out || (n && !scalars) || fmt > 1) return fail(ctx, MI_E_INVALID, "invalid argument");
     LaneLock lane(ctx, false);
+    if (abort_requested(ctx)) return fail(ctx, MI_E_ABORTED, "aborted by the caller's abort check");   // src/gpu.rs:133-137
     std::vector<DevState>& devs = lane.devs();
     return guarded(ctx, [&]() -> int {
         size_t g = devs.size();

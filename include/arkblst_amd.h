@@ -59,7 +59,8 @@ enum {
     MI_E_NOMEM = -4,        /* device or host allocation failed */
     MI_E_NO_BASES = -5,     /* bases == NULL but no resident base set was uploaded */
     MI_E_UNSUPPORTED = -6,  /* host CPU lacks BMI2 / ADX (the host tail is built for them) */
-    MI_E_COMM = -7          /* an RCCL call of the multi-process exchange failed (libarkblst_amd_rccl.so, arkblst_amd_rccl.h) */
+    MI_E_COMM = -7,         /* an RCCL call of the multi-process exchange failed (libarkblst_amd_rccl.so, arkblst_amd_rccl.h) */
+    MI_E_ABORTED = -8       /* the caller's abort check (mi_msm_set_abort_check) asked to stop: EcError::Aborted of the reference's driver */
 };
 
 /* Per-call timing of the last MSM on this context, milliseconds, measured with HIP events on the
@@ -295,6 +296,13 @@ int mi_g2_fold_windows(const mi_g2 *windows, size_t n_ranks, size_t rank_stride,
 /* Tuning / introspection. window_bits = 0 restores the built-in heuristic (cf. calc_window_size, src/gpu.rs:218-223). */
 int mi_msm_set_window_bits(mi_ctx *ctx, unsigned window_bits);
 int mi_msm_get_window_bits(const mi_ctx *ctx, unsigned *window_bits);   /* the current setting (0 = built-in heuristic) */
+/* Cooperative abort, the reference driver's `maybe_abort` (src/gpu.rs:55-58,133-137: "an optional function which will be called at places where
+ * it is possible to abort the multiexp calculations").  check(user) is called on the calling thread at the start of every MSM call and between the
+ * passes of a call that is longer than one pass of the pipeline (more than 2^26 points per device); a non-zero return ends the call with
+ * MI_E_ABORTED (EcError::Aborted) before the next pass is queued — work already on the GPU is waited for, nothing is left running.  check = NULL
+ * removes it.  The function must be callable from any thread that calls into the context and must not call back into the library. */
+int mi_msm_set_abort_check(mi_ctx *ctx, int (*check)(void *user), void *user);
+
 /* Window groups of a pipelined call.  From 2^17 points on, a call over plain (not precomputed) bases processes its digit windows in groups, top
  * windows first, each group with its own scratch: the sort of group g + 1 and the bucket reduction of group g - 1 run under the accumulate kernel
  * of group g on separate streams, and the host folds the window sums of a group while the GPU works on the next.  n_groups = 0

@@ -291,3 +291,28 @@ def test_plan_picks_against_the_committed_scans(pkg):
         for (group, log_n), t in sorted(tab.items()):
             c = pkg.test_plan(1 << log_n, 0, group, fold=fold)["c"]
             assert c in t and t[c] <= 1.15 * min(t.values()), (kind, group, log_n, c, t)
+
+
+def test_binding_refuses_the_wrong_load_order():
+    """the library loaded BEFORE torch leaves the process with two HIP runtimes and torch without devices; the binding says so
+    when the first context is created instead of letting 'No HIP GPUs are available' surface somewhere else.  The right order passes."""
+    import subprocess
+    import sys
+
+    prog = """
+import sys
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+g.load_package()
+from ark_blst_amd import binding as b
+ORDER
+try:
+    b.check_runtime_order()
+    print("accepted")
+except ImportError as e:
+    print("refused", "TWO HIP runtimes" in str(e))
+""" % ROOT
+    bad = subprocess.run([sys.executable, "-c", prog.replace("ORDER", "b.load_library()\nimport torch")], capture_output=True, text=True, timeout=600)
+    good = subprocess.run([sys.executable, "-c", prog.replace("ORDER", "import torch\nb.load_library()")], capture_output=True, text=True, timeout=600)
+    assert bad.stdout.strip().endswith("refused True"), bad.stdout + bad.stderr[-2000:]
+    assert good.stdout.strip().endswith("accepted"), good.stdout + good.stderr[-2000:]
