@@ -381,12 +381,23 @@ typename HostCurve<C>::J device_msm(mi_ctx* ctx, DevState& d, const uint8_t* bas
     Resident& res = (cached && !bases) ? *cached : d.res[HostCurve<C>::IDX];
     const bool shared = !bases && res.tables > 1;
     const size_t part_max = max_part(ctx);
+    if (cached && bases) {   // the whole shard in one buffer, whatever the number of passes
+        try {
+            cached->buf.ensure(n * msmk::Geo<C>::PT_WORDS * 4);
+            cached->flags.ensure(n);
+        } catch (const HipFail& f) {
+            // no room for another cached copy of the shard: the call itself needs only one pass's worth in the lane's scratch, which it
+            // has had all along — give the entry up (msm_impl sees n = 0 and does not publish it) and run uncached
+            if (!f.oom && f.msg.find("out of memory") == std::string::npos) throw;
+            (void)hipGetLastError();
+            cached->buf.release();
+            cached->flags.release();
+            cached->n = 0;
+            cached = nullptr;
+        }
+    }
     DevBuf& conv_bases = cached && bases ? cached->buf : d.call_bases;   // where the call's converted points go
     DevBuf& conv_flags = cached && bases ? cached->flags : d.call_flags;
-    if (cached && bases) {   // the whole shard in one buffer, whatever the number of passes
-        cached->buf.ensure(n * msmk::Geo<C>::PT_WORDS * 4);
-        cached->flags.ensure(n);
-    }
     if (wo && n > part_max) throw HipFail{"device_windows: n exceeds one pass of the pipeline (2^26 points per device)", false, true};
     // A failure between enqueueing the chunked H2D copies (copy stream) and the call's final synchronisation must not return while
     // copies still read the caller's host buffers and write this lane's scratch: drain both streams before the error leaves
@@ -669,6 +680,12 @@ int msm_impl(mi_ctx* ctx, const void* bases_v, const uint8_t* scalars, bool scal
                 rc = run();
                 if (rc != MI_OK) return rc;
             }
+            if (fill)   // a shard that found no memory for its cached copy ran uncached (device_msm): the entry is incomplete, not published
+                for (size_t k = 0; k < g; k++) {
+                    size_t lo, hi;
+                    shard_range(n, g, k, lo, hi);
+                    if (fill && fill->shard[k].n != hi - lo) fill.reset();
+                }
             cache_finish(ctx, HostCurve<C>::IDX, hit, fill, fp);
         }
         J r = J::inf();

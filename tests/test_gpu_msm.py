@@ -1269,6 +1269,21 @@ def test_allocation_failure_is_an_error_code_not_an_abort(pkg, co):
                 c.multi_pairing(bases[:96 * 40], co.gen_bases("g2", 3, 40, 2))
             assert e.value.code == -4
             c.test_fail_allocs(0)
+    # no memory for the base-set cache's copy of the vector is NOT a failed call — it runs uncached, as it would with the cache off
+    n2 = 6000
+    b2 = co.gen_bases("g1", SEED_B + 241, n2, 8)
+    s2 = co.gen_scalars(SEED_S + 241, n2)
+    w2 = co.dlog_expected("g1", s2, SEED_B + 241, n2)
+    with pkg.Context([0], test_hooks=True) as c:
+        c.set_base_cache(2)
+        c.msm("g1", b2[:96 * 5000], s2[:32 * 5000], 5000, pkg.SCALAR_CANONICAL)   # sizes the lane's scratch (uncached size class: its own entry)
+        c.test_fail_allocs(1)                                                      # the next growing allocation: the new entry's point buffer
+        assert _canon(co, "g1", c.msm("g1", b2, s2, n2, pkg.SCALAR_CANONICAL)) == w2
+        st = c.base_cache_stats()
+        assert st["entries"] == 1 and st["misses"] == 2                            # the 6000-point vector was not cached ...
+        c.test_fail_allocs(0)
+        assert _canon(co, "g1", c.msm("g1", b2, s2, n2, pkg.SCALAR_CANONICAL)) == w2
+        assert c.base_cache_stats()["entries"] == 2                                # ... and is on the next call
 
 
 def test_multi_device_context_device_resident_scalars(pkg, co):
