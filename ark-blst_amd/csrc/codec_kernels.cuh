@@ -39,23 +39,30 @@ __device__ __forceinline__ bool fp_equal(const Fp& a, const Fp& b) {  // a == b 
     return fp28::fp_is_zero_any(fp28::fp_sub<16>(a, b));
 }
 
-// r = [|z|] p: 63 exception-free doublings (ec::proj_dbl, multiplier inlined: 3 S + 4 M + one fused pair instead of the 12 M of
-// adding a point to itself — round 4) + 5 complete additions through the shared body
-__device__ __noinline__ void g1_mul_z(ec::Proj<ec::FpOps>& r, const ec::Proj<ec::FpOps>& p) {
-    r = p;
+// [|z|] p: 63 exception-free doublings (ec::proj_dbl, multiplier inlined: 3 S + 4 M + one fused pair instead of the 12 M of adding a point to
+// itself — round 4) + 5 complete additions through the shared body.  BY VALUE and inlined (round 6): as an out-of-line function over references
+// the running point lived in scratch memory and every doubling loaded and stored it — rocprofv3's FETCH_SIZE / WRITE_SIZE of the callers showed
+// 26 KB of HBM traffic per point (k_validate<G1C>: 6.85 GB per 2^18-point launch, 185 x the 144 algorithmic bytes; profiles/r06_rows_f_g1_2p20_*).
+// Only the five additions go through a call, on a COPY: the loop variable's address is never taken.
+__device__ __forceinline__ ec::Proj<ec::FpOps> g1_mul_z(const ec::Proj<ec::FpOps>& p) {
+    ec::Proj<ec::FpOps> r = p;
 #pragma unroll 1
     for (int bit = 62; bit >= 0; bit--) {
         ec::proj_dbl<ec::FpOpsInlinePS>(r);
-        if ((fp28c::Z_ABS >> bit) & 1) add_inplace(r, p);
+        if ((fp28c::Z_ABS >> bit) & 1) {
+            ec::Proj<ec::FpOps> t = r;
+            add_inplace(t, p);
+            r = t;
+        }
     }
+    return r;
 }
 
 // is_torsion_free of an affine point in the internal form: (beta x, y) == -[z^2] P, i.e. X == beta x Z, Y == -y Z, Z != 0
 __device__ __forceinline__ bool g1_in_subgroup(const Fp& x, const Fp& y) {
     using F = ec::FpOps;
-    ec::Proj<F> p1 = ec::proj_from_affine<F>(x, y), q, q2;
-    g1_mul_z(q, p1);
-    g1_mul_z(q2, q);                                                     // [z^2] P
+    const ec::Proj<F> p1 = ec::proj_from_affine<F>(x, y);
+    const ec::Proj<F> q2 = g1_mul_z(g1_mul_z(p1));                       // [z^2] P
     Fp bx = fp28::fp_mul_call(x, fp28::fp_const(fp28c::BETA));
     bool ok = !fp28::fp_is_zero_any(q2.z);
     ok = ok && fp_equal(q2.x, fp28::fp_mul_call(bx, q2.z));
@@ -178,10 +185,11 @@ __global__ void __launch_bounds__(256, 2) k_serialize_g1(const uint32_t* __restr
 
 // ---------------------------------------------------------------------------------------------- G2 point decoding
 // Same for G2 (/root/reference/src/g2.rs:338-411): 96-byte compressed / 192-byte uncompressed, coordinates in Fp2
-// serialised c1 first; y^2 = x^3 + 4(1 + u).  Square root in Fp2 for p = 3 mod 4 (Adj, Rodriguez-Henriquez Alg. 9):
-// a1 = a^((p-3)/4), alpha = a1^2 a, x0 = a1 a; root = u x0 if alpha = -1 else (1 + alpha)^((p-1)/2) x0.
+// serialised c1 first; y^2 = x^3 + 4(1 + u).  Square root in Fp2 by the complex method (fp2_sqrt_complex below; rounds 2-5: Adj,
+// Rodriguez-Henriquez Alg. 9 with two exponentiations in Fp2).
 // Subgroup test: psi(P) == [z] P (z < 0), psi(x, y) = (conj(x) PSI_X, conj(y) PSI_Y)  (M. Scott, eprint 2021/1130).
 using G2F = ec::Fp2Ops;
+constexpr int G2_RAW_AFF_WORDS = Geo<G2C>::RAW_AFF;   // 48
 __device__ __forceinline__ bool fp2_equal(const ec::Fp2& a, const ec::Fp2& b) { return fp_equal(a.c0, b.c0) && fp_equal(a.c1, b.c1); }
 __device__ __forceinline__ bool fp2_is_zero(const ec::Fp2& a) { return fp28::fp_is_zero_any(a.c0) && fp28::fp_is_zero_any(a.c1); }
 __device__ __forceinline__ ec::Fp2 fp2_conj(const ec::Fp2& a) { return ec::Fp2{a.c0, fp28::fp_neg<16>(a.c1)}; }
@@ -421,6 +429,82 @@ __global__ void __launch_bounds__(256, 2) k_serialize_g2(const uint32_t* __restr
         fp28::fp_pack384(w, fp_to_canonical(y.c0)); words_to_be48(b + 144, w);
     } else {
         b[0] |= (uint8_t)(0x80 | (fp2_lex_largest(y) ? 0x20 : 0));
+    }
+}
+
+// Valid::check for G2 on LANE PAIRS (round 6): the even lane holds c0 and the odd lane c1 of every Fp2 value (CoopF2, coop_fp2.cuh — the
+// scheme of the G2 accumulate kernel), two lanes per point.  k_validate<G2C> above keeps a whole Fp2 per lane and runs its 64-bit ladder
+// through the shared out-of-line multiplier: the point lives in scratch, 180 scratch loads / stores per doubling — rocprofv3 counted
+// 61 GB of HBM traffic per 2^18-point launch (4 TB/s: the kernel was bound by its own spills, profiles/r06_rows_f_g2_2p18_pmc_summary.json).
+// Here a projective point is 42 registers per lane, the multiplier is inlined, nothing is called and nothing spills; a lane-pair product is
+// one fused two-product reduction per lane (600 instructions against 3 x 616 for the Karatsuba product of one lane).  Same MODEs, same
+// outputs as k_validate<G2C, MODE>; grid = ceil(2 n / 256) workgroups of 256 lanes.
+__device__ __forceinline__ bool pair_all(bool v) {
+    const int m = v ? 1 : 0;
+    return (m & __builtin_amdgcn_mov_dpp(m, 0xB1, 0xF, 0xF, true)) != 0;
+}
+__device__ __forceinline__ uint32_t pair_or(uint32_t v) { return v | (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) k_validate_g2_coop(uint32_t* __restrict__ pts, uint32_t n, uint8_t* __restrict__ status, uint32_t* __restrict__ n_bad) {
+    using F = CoopF2;
+    const uint32_t i = (blockIdx.x * 256 + threadIdx.x) >> 1, h = threadIdx.x & 1u;
+    if (i >= n) return;                                   // both lanes of a pair share i
+    Fp x, y;                                               // this lane's component of x and y
+    if constexpr (MODE != 0) {
+        if (MODE == 1 && status[i] != 0) return;
+        uint32_t* q = pts + (size_t)i * G2_RAW_AFF_WORDS;   // x.c0 | x.c1 | y.c0 | y.c1, 12 words each
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) any |= q[12 * h + k] | q[24 + 12 * h + k];
+        if (pair_or(any) == 0) {                           // infinity: a member of every subgroup
+            if (MODE == 2 && h == 0) status[i] = 0;
+            return;
+        }
+        fp_from_raw(x, q + 12 * h);
+        fp_from_raw(y, q + 24 + 12 * h);
+    } else {
+        const uint32_t* q = pts + (size_t)i * G2_PT_WORDS;   // device form: x.c0 | x.c1 | y.c0 | y.c1 in 16-word slots, word 63 = infinity flag
+        if (q[G2_PT_WORDS - 1] != 0) return;
+        load_fp16(x, q + 16 * h);
+        load_fp16(y, q + 32 + 16 * h);
+    }
+    uint8_t st = 0;
+    if constexpr (MODE != 1) {                             // y^2 == x^3 + 4 (1 + u)
+        const Fp four = fp28::fp_const(fp28c::FOUR);
+        const Fp rhs = F::add(F::mul(F::sqr(x), x), four);
+        if (!pair_all(fp_equal(F::sqr(y), rhs))) st = 2;
+    }
+    if (st == 0) {                                         // psi(P) == [z] P = -[|z|] P:  X_q == px Z_q, Y_q == -py Z_q, Z_q != 0
+        const ec::Proj<F> p1 = ec::proj_from_affine<F>(x, y);
+        ec::Proj<F> q = p1;
+#pragma unroll 1
+        for (int bit = 62; bit >= 0; bit--) {
+            ec::proj_dbl<F>(q);
+            if ((fp28c::Z_ABS >> bit) & 1) ec::proj_add<F>(q, p1);   // five of the 63 steps; wave-uniform
+        }
+        const Fp cx = F::select(h != 0, x, fp28::fp_neg<16>(x)), cy = F::select(h != 0, y, fp28::fp_neg<16>(y));   // conj: the odd lane's component negated
+        const Fp px = F::mul(cx, F::select(h != 0, fp28::fp_zero(), fp28::fp_const(fp28c::PSI_X1)));
+        const Fp py = F::mul(cy, F::select(h != 0, fp28::fp_const(fp28c::PSI_Y0), fp28::fp_const(fp28c::PSI_Y1)));
+        bool ok = !pair_all(fp28::fp_is_zero_any(q.z));
+        ok = ok && pair_all(fp_equal(q.x, F::mul(px, q.z)));
+        ok = ok && pair_all(fp28::fp_is_zero_any(F::add(q.y, F::mul(py, q.z))));
+        if (!ok) st = 3;
+    }
+    if constexpr (MODE == 1) {
+        if (st) {
+            if (h == 0) status[i] = st;
+            uint32_t* q = pts + (size_t)i * G2_RAW_AFF_WORDS;
+#pragma unroll
+            for (int k = 0; k < 12; k++) { q[12 * h + k] = 0u; q[24 + 12 * h + k] = 0u; }
+        }
+    } else if constexpr (MODE == 2) {
+        if (h == 0) status[i] = st;
+    } else {
+        if (h == 0) {
+            if (status) status[i] = st;
+            if (st) atomicAdd(n_bad, 1u);
+        }
     }
 }
 

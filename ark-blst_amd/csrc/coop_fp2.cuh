@@ -66,6 +66,7 @@ struct CoopF2 {
         Fp lin = fp28::fp_select(hi(), fp28::fp_sub<4>(a, pa), fp28::fp_add(a, pa));
         return fp28::fp_mul(lin, fp28::fp_const(fp28::TWELVE));
     }
+    static __device__ __forceinline__ E mul_b3_red(const E& a) { return mul_b3(a); }   // already a field product: < 2p (ec::proj_dbl asks for it)
     static __device__ __forceinline__ E mul_fp(const E& a, const Fp& s) { return fp28::fp_mul(a, s); }
     static __device__ __forceinline__ E norm2(const E& a) { return fp28::fp_mul(a, fp28::fp_one()); }
     static __device__ __forceinline__ E dbl(const E& a) { return fp28::fp_add(a, a); }

@@ -24,8 +24,8 @@ struct G2Codec {
     static constexpr size_t UNIT = 96;
     static void decode(hipStream_t s, const uint8_t* in, size_t cnt, int compressed, int validate, uint32_t* out, uint8_t* st) {
         hipLaunchKernelGGL(msmk::k_deserialize_g2, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, s, in, (uint32_t)cnt, compressed ? 1 : 0, validate ? 1 : 0, out, st);
-        if (validate)
-            hipLaunchKernelGGL((msmk::k_validate<msmk::G2C, 1>), dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, s, out, (uint32_t)cnt, st, (uint32_t*)nullptr);
+        if (validate)   // the subgroup test on lane pairs (codec_kernels.cuh k_validate_g2_coop): two lanes per point
+            hipLaunchKernelGGL((msmk::k_validate_g2_coop<1>), dim3((uint32_t)((2 * cnt + 255) / 256)), dim3(256), 0, s, out, (uint32_t)cnt, st, (uint32_t*)nullptr);
     }
     static void encode(hipStream_t s, const uint32_t* in, size_t cnt, int compressed, uint8_t* out) {
         hipLaunchKernelGGL(msmk::k_serialize_g2, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, s, in, (uint32_t)cnt, compressed ? 1 : 0, out);
@@ -130,8 +130,12 @@ int validate_bases_impl(mi_ctx* ctx, int idx, size_t* n_invalid) {
             HIP_TRY(hipSetDevice(d.dev));
             d.io_status.ensure(16);
             HIP_TRY(hipMemsetAsync(d.io_status.p, 0, 4, d.stream));
-            hipLaunchKernelGGL((msmk::k_validate<C, 0>), dim3((uint32_t)((res.n + 255) / 256)), dim3(256), 0, d.stream, (uint32_t*)res.buf.p,
-                               (uint32_t)res.n, (uint8_t*)nullptr, (uint32_t*)d.io_status.p);
+            if constexpr (std::is_same<C, msmk::G2C>::value)
+                hipLaunchKernelGGL((msmk::k_validate_g2_coop<0>), dim3((uint32_t)((2 * res.n + 255) / 256)), dim3(256), 0, d.stream, (uint32_t*)res.buf.p,
+                                   (uint32_t)res.n, (uint8_t*)nullptr, (uint32_t*)d.io_status.p);
+            else
+                hipLaunchKernelGGL((msmk::k_validate<C, 0>), dim3((uint32_t)((res.n + 255) / 256)), dim3(256), 0, d.stream, (uint32_t*)res.buf.p,
+                                   (uint32_t)res.n, (uint8_t*)nullptr, (uint32_t*)d.io_status.p);
             HIP_TRY(hipGetLastError());
         }
         for (size_t k = 0; k < ctx->devs.size(); k++) {
@@ -184,8 +188,12 @@ int check_batch_impl(mi_ctx* ctx, const void* points, bool on_device, size_t n, 
         const IoOut outs[1] = {{on_device ? nullptr : (void*)status, d_st, 1}};
         double h2d = 0;
         const double k_ms = io_stream_pass(d, n, on_device ? nullptr : points, d_pts, aff, outs, 1, [&](size_t lo, size_t cnt) {
-            hipLaunchKernelGGL((msmk::k_validate<C, 2>), dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, d.stream, d_pts + lo * (aff / 4), (uint32_t)cnt,
-                               d_st + lo, (uint32_t*)nullptr);
+            if constexpr (std::is_same<C, msmk::G2C>::value)
+                hipLaunchKernelGGL((msmk::k_validate_g2_coop<2>), dim3((uint32_t)((2 * cnt + 255) / 256)), dim3(256), 0, d.stream, d_pts + lo * (aff / 4), (uint32_t)cnt,
+                                   d_st + lo, (uint32_t*)nullptr);
+            else
+                hipLaunchKernelGGL((msmk::k_validate<C, 2>), dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, d.stream, d_pts + lo * (aff / 4), (uint32_t)cnt,
+                                   d_st + lo, (uint32_t*)nullptr);
         }, &h2d, (size_t)1 << 18);
         mi_profile pr{};
         pr.n = n; pr.h2d_ms = h2d; pr.accumulate_ms = k_ms;

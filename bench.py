@@ -157,6 +157,31 @@ def _traffic(g: str, log_n, precomputed: bool):
     return None, None, None
 
 
+def _rows_f_traffic(g: str, log_n: int, kernel_keys):
+    """HBM bytes of the named kernels of a rows-(f) call (their LARGEST launch = the full-size call; warm-up launches are smaller) from the newest
+    committed PMC summary of tools/profile_rows_f.sh for this group and size: (bytes, source, stale) or (None, None, None)."""
+    try:
+        files = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if "rows_f" in f and f.endswith("_pmc_summary.json")), reverse=True)
+        for f in files:
+            pj = json.load(open(os.path.join(ROOT, "profiles", f)))
+            wl = pj.get("workload") or {}
+            if (wl.get("group"), wl.get("log_n")) != (g, log_n):
+                continue
+            ks = pj.get("kernels", {})
+            tot, found = 0.0, 0
+            for key in kernel_keys:
+                # a kernel that runs in several launches per call (chunks; the tree's levels): launches per call x mean bytes per launch
+                for k, v in ks.items():
+                    if key in k and "hbm_bytes_per_launch_corrected" in v:
+                        tot += v["hbm_bytes_per_launch_corrected"] * v.get("launches", 1) / max(1, pj.get("calls_profiled", 1))
+                        found += 1
+            if found:
+                return tot, "profiles/" + f, pj.get("source_sha256") != source_hash()
+    except Exception:
+        pass
+    return None, None, None
+
+
 def _pairing_traffic():
     """HBM bytes of the two Miller kernels (largest launch of each = the 2^16-pair call) from the newest committed PMC summary."""
     try:
@@ -531,12 +556,14 @@ def _normalize_leg(pkg, co, ncpu, device, g="g1", log_n=20) -> dict:
     mads = muls * MADS_PER_FP_MUL
     clock, clock_src = _measured_clock("k_accumulate<msmk::G1C>")
     gbs = (jb + aff) * n / (kms * 1e-3) / 1e9
+    traffic, tsrc, tstale = _rows_f_traffic(g, log_n, ("k_norm_",))
     return {"metric": f"{G} points/s, normalize_batch (Jacobian -> affine, one inversion), host slices in and out", "value": n / (best * 1e-3), "unit": "points/s", "n": n,
             "call_ms_host_buffers": best, "kernels_ms": kms, "call_ms_device_buffers": dev_ms, "python_binding_wall_ms": py_ms, "bit_exact": ok,
             "workload": f"2^{log_n} {G} Jacobian points with non-trivial Z; value = the C call with host buffers in and out (PCIe-inclusive, what the trait's "
                         "caller pays); kernels_ms and the device-buffer call beside it",
             "roofline": {"bound": "hbm", "kernel": "k_norm_load + k_norm_up/down x levels + k_norm_final", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": (jb + aff) * n, "kernel_ms": kms,
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc, "traffic_stale": tstale,
+                         "algorithmic_bytes_per_launch": (jb + aff) * n, "kernel_ms": kms,
                          "note": f"algorithmic bytes = {jb} B Jacobian in + {aff} B affine out per point; the product tree adds ~3 slots of "
                                  "intermediate values per point and level-0 element; arithmetic is 12 field multiplications per point, "
                                  "so neither roof is close: the row is bound by its five dependent passes over the data"},
@@ -579,7 +606,9 @@ def _deserialize_g2_leg(pkg, co, ncpu, device, log_n=18) -> dict:
             "call_ms_host_buffers": wall * 1e3, "kernel_ms": kms, "kernel_ms_validate_off": kms_novalidate, "set_bases_from_compressed_ms": load_ms, "bit_exact": ok,
             "workload": f"2^{log_n} compressed G2 encodings (96 B), decompression (Fp2 square root, complex method: two Fp exponentiations) + on-curve + subgroup check, host buffers in and out",
             "roofline": _valu_roofline("k_deserialize_g2 + k_validate<G2C>", f"~{fp_muls} Fp-mul x {MADS_PER_FP_MUL} MAD per point",
-                                       fp_muls * MADS_PER_FP_MUL * n, kms, clock, clock_src, {"traffic": None, "algorithmic_bytes_per_launch": (96 + 192) * n}),
+                                       fp_muls * MADS_PER_FP_MUL * n, kms, clock, clock_src,
+                                       dict(zip(("traffic", "traffic_source", "traffic_stale"), _rows_f_traffic("g2", log_n, ("k_deserialize_g2", "k_validate<msmk::G2C, 1>"))),
+                                            algorithmic_bytes_per_launch=(96 + 192) * n)),
             "cpu_baseline": {"value": m / cpu_s, "unit": "points/s", "cores": ncpu, "kind": "port", "cpu_model": _cpu_model(), "seconds": cpu_s,
                              "sample": f"{m} of the encodings: Fp2 square root by two Fp2 exponentiations + psi-endomorphism subgroup test in C "
                                        "(oracle/msm_oracle.c orc_g2_deserialize_batch, mode 1)"}}
@@ -627,7 +656,9 @@ def _deserialize_leg(pkg, co, ncpu, device, log_n=20) -> dict:
             "bit_exact": ok,
             "workload": f"2^{log_n} compressed G1 encodings (48 B), decompression + on-curve + subgroup check, host buffers in and out",
             "roofline": _valu_roofline("k_deserialize_g1", f"{DESER_FP_MULS_PER_POINT} Fp-mul (square root 570 + subgroup test 1650) x {MADS_PER_FP_MUL} MAD per point",
-                                       mads * n, kms, clock, clock_src, {"traffic": None, "algorithmic_bytes_per_launch": (48 + 96) * n}),
+                                       mads * n, kms, clock, clock_src,
+                                       dict(zip(("traffic", "traffic_source", "traffic_stale"), _rows_f_traffic("g1", log_n, ("k_deserialize_g1",))),
+                                            algorithmic_bytes_per_launch=(48 + 96) * n)),
             "hbm_roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_launch": (48 + 96) * n},
             "cpu_baseline": {"value": m / cpu_s, "unit": "points/s", "cores": ncpu, "kind": "port", "cpu_model": _cpu_model(), "seconds": cpu_s,

@@ -9,8 +9,11 @@ import torch
 import __graft_entry__ as ge
 from oracle import coracle as co
 pkg = ge.load_package()
-g = sys.argv[1] if len(sys.argv) > 1 else "g1"
-ln = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+_args = [a for a in sys.argv[1:] if not a.startswith("--")]
+g = _args[0] if _args else "g1"
+ln = int(_args[1]) if len(_args) > 1 else 20
+ONLY = [a.split("=")[1].split(",") for a in sys.argv if a.startswith("--only=")]
+ONLY = ONLY[0] if ONLY else None
 n = 1 << ln
 aff, jb, unit = (96, 144, 48) if g == "g1" else (192, 288, 96)
 bases = co.gen_bases(g, 4242, n, 16)
@@ -21,6 +24,10 @@ jac = b"".join(co.sum_jac(g, bases[aff * i:aff * (i + 1)] + one + bases[aff * (i
 rows = {}
 with pkg.Context([0]) as c:
     def timed(name, fn, reps=3):
+        if ONLY and not any(name.startswith(o) for o in ONLY):
+            return
+        if "--once" in sys.argv:   # profiler runs: one warm call sizes the buffers, ONE profiled-size call follows
+            reps = 1
         fn()
         best = None
         for _ in range(reps):
@@ -41,4 +48,4 @@ with pkg.Context([0]) as c:
     timed("set_bases_from_jacobian", lambda: c.set_bases_from_jacobian(g, jac, n))
     timed("set_bases_from_compressed_validate", lambda: c.set_bases_from_compressed(g, enc, n, True, True), reps=2)
     timed("set_bases_from_compressed_no_validate", lambda: c.set_bases_from_compressed(g, enc, n, True, False), reps=2)
-print(json.dumps({"group": g, "log_n": ln, "rows": rows}, indent=1))
+print(json.dumps({"group": g, "log_n": ln, "rows": rows}, indent=None if "--oneline" in sys.argv else 1))
