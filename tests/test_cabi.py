@@ -316,3 +316,28 @@ except ImportError as e:
     good = subprocess.run([sys.executable, "-c", prog.replace("ORDER", "import torch\nb.load_library()")], capture_output=True, text=True, timeout=600)
     assert bad.stdout.strip().endswith("refused True"), bad.stdout + bad.stderr[-2000:]
     assert good.stdout.strip().endswith("accepted"), good.stdout + good.stderr[-2000:]
+
+
+def test_kernels_that_run_beside_the_accumulate_kernel_fit_there(pkg):
+    """Round 6: k_accumulate<G1C> holds two waves of 216 registers on every SIMD, so a workgroup is dispatched beside it only
+    when its waves need at most 80 registers per lane and SIMD — counted in what the hardware ALLOCATES (the kernel descriptor), which the compiler
+    pads for kernels with large static LDS.  The sort and schedule kernels of a pipelined call's later groups are launched with 256 lanes (512 for
+    the schedule, 1024 for k_binscan); read the allocations off the shipped code object and hold them to the rule."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+
+    alloc = kr.allocated_vgprs(pkg.lib_path())
+    acc = [v for k, v in alloc.items() if "k_accumulate<msmk::G1C>" in k]
+    assert acc and acc[0] <= 216, acc                          # the budget the rule below is derived from: 512 - 2 * 216 = 80
+    lanes = {"k_coarse<false": 256, "k_coarse<true": 256, "k_coarse_staged_co<": 256, "k_coarseA<": 256, "k_colscan": 256, "k_binscan": 1024, "k_seg_count": 256,
+             "k_fine_count": 256, "k_fine_scan": 256, "k_fine_scatter": 256, "k_mid_count": 256, "k_mid_scan": 512, "k_mid_scatter": 256,
+             "k_sched1<512": 512, "k_sched2<512": 512, "k_sched3<512": 512}
+    seen = set()
+    for name, regs in alloc.items():
+        for key, nt in lanes.items():
+            if key in name:
+                seen.add(key)
+                assert (nt // 256) * regs <= 80, (name, nt, regs)
+    assert seen == set(lanes), set(lanes) - seen

@@ -97,6 +97,39 @@ def resources(lib: str | None = None) -> dict[str, dict[str, int]]:
 HOT = ("msmk::k_accumulate", "msmk::k_reduce_", "msmk::k_combine", "msmk::k_miller_", "msmk::k_fp12_prod")
 
 
+def allocated_vgprs(lib: str | None = None) -> dict[str, int]:
+    """demangled kernel name -> registers per lane the hardware ALLOCATES for a wave (granulated_workitem_vgpr_count of the kernel descriptor,
+    granule 8 on gfx950).  Not the same as the notes' vgpr_count: with a large static LDS array the compiler pads the allocation up to the most its
+    LDS-limited occupancy allows (round 6: 176 allocated for 52 used), which decides whether a workgroup fits BESIDE another kernel."""
+    import struct
+    lib = lib or os.path.join(ROOT, "ark-blst_amd", "lib", "libarkblst_amd.so")
+    out: dict[str, int] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for elf in code_objects(lib, tmp):
+            syms = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-s", "--wide", elf], capture_output=True, text=True, check=True).stdout
+            secs = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-S", "--wide", elf], capture_output=True, text=True, check=True).stdout
+            ro = None
+            for line in secs.splitlines():
+                f = line.split()
+                if ".rodata" in f:
+                    i = f.index(".rodata")
+                    ro = (int(f[i + 2], 16), int(f[i + 3], 16))
+            if ro is None:
+                continue
+            data = open(elf, "rb").read()
+            kds = []
+            for line in syms.splitlines():
+                f = line.split()
+                if len(f) >= 8 and f[7].endswith(".kd"):
+                    kds.append((f[7][:-3], int(f[1], 16)))
+            names = demangle([k for k, _ in kds])
+            for raw, addr in kds:
+                off = addr - ro[0] + ro[1]
+                rsrc1 = struct.unpack_from("<I", data, off + 48)[0]
+                out[names[raw]] = ((rsrc1 & 0x3F) + 1) * 8
+    return out
+
+
 def is_hot(name: str) -> bool:
     return any(h in name for h in HOT)
 

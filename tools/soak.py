@@ -158,6 +158,40 @@ def loop(ctx, rnd, tid):
             if got != want:
                 print("PAIRING MISMATCH", seed, n); failed.append(1); return
             stats["pairing"] += 1; stats["pairs"] += n
+        elif r < 0.30 and nthreads == 1:   # round 6: SRS loading as one call (decode + check on the GPU) and normalize feeding the resident set, then MSMs over it
+            g = rnd.choice(["g1", "g1", "g2"])
+            aff, lim = AFF[g], POOL[g] // 4
+            n = rnd.choice([1, 2, 255, 256, 257, rnd.randrange(1, lim), rnd.randrange(1, lim)])
+            start = rnd.randrange(0, POOL[g] - n + 1)
+            bases = bytearray(pools[g][aff * start:aff * (start + n)])
+            for k in range(min(n, 6)):
+                if rnd.random() < 0.5: bases[aff * rnd.randrange(n):][:aff] = bytes(aff)
+            bases = bytes(bases)
+            compressed = rnd.random() < 0.7
+            enc = ctx.serialize_batch(g, bases, compressed)
+            dec, st = ctx.deserialize_batch(g, enc, compressed, True)
+            if dec != bases or st != bytes(n):
+                print("CODEC MISMATCH", seed, g, n, compressed); failed.append(1); return
+            if rnd.random() < 0.5:
+                if ctx.set_bases_from_compressed(g, enc, n, compressed, rnd.random() < 0.7) != 0:
+                    print("SRS LOAD REJECTED VALID POINTS", seed, g, n); failed.append(1); return
+            else:   # Jacobian with Z = 1 or a scaled Z for a few points (the C oracle normalises them back)
+                one = bytes.fromhex("fdff02000000097602000cc40b00f4ebba58c7535798485f455752705358ce776dec56a2971a075c93e480fac35ef615") + (bytes(48) if g == "g2" else b"")
+                jac = b"".join((bases[aff * i:aff * (i + 1)] + one) if any(bases[aff * i:aff * (i + 1)]) else bytes(aff + len(one)) for i in range(n))
+                if co.normalize_batch(g, jac, ncpu) != bases or ctx.normalize_batch(g, jac) != bases:
+                    print("NORMALIZE MISMATCH", seed, g, n); failed.append(1); return
+                ctx.set_bases_from_jacobian(g, jac, n)
+            for rep in range(2):
+                m = rnd.choice([n, rnd.randrange(1, n + 1)])
+                sc = [rnd.randrange(o.R_ORDER) for _ in range(m)]
+                canon = b"".join(o.fr_to_canon_bytes(x) for x in sc)
+                ctx.set_pipeline(rnd.choice([None, [1, 3], [1, 1, 1]]))
+                got = ctx.msm(g, None, canon, m, pkg.SCALAR_CANONICAL)
+                ctx.set_pipeline(None)
+                if co.to_affine(g, got) != co.to_affine(g, co.msm(g, bases[:aff * m], canon, m, 0, ncpu)):
+                    print("MSM OVER LOADED SRS MISMATCH", seed, g, n, m); failed.append(1); return
+                stats["msm_" + g] += 1; stats["points"] += m
+            stats["srs_loads"] = stats.get("srs_loads", 0) + 1
         else:
             g = "g2" if r < 0.4 else "g1"
             aff, lim = AFF[g], POOL[g]
@@ -185,15 +219,18 @@ def loop(ctx, rnd, tid):
             data = canon if fmt == pkg.SCALAR_CANONICAL else co.fr_to_mont(canon)
             c = rnd.choice([0, 0, 0, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, rnd.randrange(17, 23)]) if nthreads == 1 else 0   # the setting is per context
             part = rnd.choice([0] * 9 + [rnd.randrange(200, 5000)]) if nthreads == 1 else 0   # passes per call (test hook)
+            pipe = rnd.choice([None, None, [1], [1, 3], [1, 1], [2, 1, 1], [1, 1, 1, 1], [1, 7], [5, 1]]) if nthreads == 1 else None   # round 6: window groups
             if nthreads == 1:
                 ctx.set_window_bits(c)
                 ctx.test_set_max_part(part)
+                ctx.set_pipeline(pipe)
             try:
                 got = ctx.msm(g, bytes(bases), data, n, fmt)
             finally:
                 if nthreads == 1:
                     ctx.set_window_bits(0)
                     ctx.test_set_max_part(0)
+                    ctx.set_pipeline(None)
             want = co.msm(g, bytes(bases), canon, n, 0, ncpu)
             if co.to_affine(g, got) != co.to_affine(g, want):
                 print("MSM MISMATCH", seed, g, n, kind, c, fmt); failed.append(1); return
