@@ -39,36 +39,12 @@ __device__ __forceinline__ bool fp_equal(const Fp& a, const Fp& b) {  // a == b 
     return fp28::fp_is_zero_any(fp28::fp_sub<16>(a, b));
 }
 
-// [|z|] p: 63 exception-free doublings (ec::proj_dbl, multiplier inlined: 3 S + 4 M + one fused pair instead of the 12 M of adding a point to
-// itself — round 4) + 5 complete additions through the shared body.  BY VALUE and inlined (round 6): as an out-of-line function over references
-// the running point lived in scratch memory and every doubling loaded and stored it — rocprofv3's FETCH_SIZE / WRITE_SIZE of the callers showed
-// 26 KB of HBM traffic per point (k_validate<G1C>: 6.85 GB per 2^18-point launch, 185 x the 144 algorithmic bytes; profiles/r06_rows_f_g1_2p20_*).
-// Only the five additions go through a call, on a COPY: the loop variable's address is never taken.
-__device__ __forceinline__ ec::Proj<ec::FpOps> g1_mul_z(const ec::Proj<ec::FpOps>& p) {
-    ec::Proj<ec::FpOps> r = p;
-#pragma unroll 1
-    for (int bit = 62; bit >= 0; bit--) {
-        ec::proj_dbl<ec::FpOpsInlinePS>(r);
-        if ((fp28c::Z_ABS >> bit) & 1) {
-            ec::Proj<ec::FpOps> t = r;
-            add_inplace(t, p);
-            r = t;
-        }
-    }
-    return r;
-}
-
-// is_torsion_free of an affine point in the internal form: (beta x, y) == -[z^2] P, i.e. X == beta x Z, Y == -y Z, Z != 0
-__device__ __forceinline__ bool g1_in_subgroup(const Fp& x, const Fp& y) {
-    using F = ec::FpOps;
-    const ec::Proj<F> p1 = ec::proj_from_affine<F>(x, y);
-    const ec::Proj<F> q2 = g1_mul_z(g1_mul_z(p1));                       // [z^2] P
-    Fp bx = fp28::fp_mul_call(x, fp28::fp_const(fp28c::BETA));
-    bool ok = !fp28::fp_is_zero_any(q2.z);
-    ok = ok && fp_equal(q2.x, fp28::fp_mul_call(bx, q2.z));
-    ok = ok && fp28::fp_is_zero_any(fp28::fp_add(q2.y, fp28::fp_mul_call(y, q2.z)));
-    return ok;
-}
+// is_torsion_free of an affine point in the internal form: ec::g1_torsion_free — two 63-step Jacobian ladders (round 6: 4 S + 3 M + one
+// small reduction per doubling where the homogeneous doubling of rounds 4-5 took 3 S + 5.5 M), doublings with the multiplier inlined,
+// the ten additions through the shared body on a COPY.  BY VALUE and inlined since round 6: as an out-of-line function over references
+// the running point lived in scratch memory and every doubling loaded and stored it — rocprofv3's FETCH_SIZE / WRITE_SIZE of the callers
+// showed 26 KB of HBM traffic per point (k_validate<G1C>: 6.85 GB per 2^18-point launch, 185 x the 144 algorithmic bytes).
+__device__ __forceinline__ bool g1_in_subgroup(const Fp& x, const Fp& y) { return ec::g1_torsion_free<ec::FpOpsInlinePS, ec::FpOps>(x, y); }
 __device__ __forceinline__ bool g1_on_curve(const Fp& x, const Fp& y) {   // y^2 == x^3 + 4
     Fp rhs = fp28::fp_add(fp28::fp_mul_call(fp28::fp_sqr_call(x), x), fp28::fp_const(fp28c::FOUR));
     return fp_equal(fp28::fp_sqr_call(y), rhs);

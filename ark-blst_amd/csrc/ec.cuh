@@ -266,6 +266,96 @@ FP_HD void proj_dbl_n(Proj<F>& a, int k) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Jacobian arithmetic over Fp for the G1 subgroup ladder (is_torsion_free, /root/reference/src/g1.rs:386-431 -> blst_p1_affine_in_g1):
+// x = X / Z^2, y = Y / Z^3, infinity is Z == 0 (mod p).  The ladder is 126 doublings and 10 additions, so the doubling is the cost: the
+// a = 0 Jacobian doubling is 4 S + 3 M + one small reduction (2478 multiply-adds + ~120 plain instructions) where proj_dbl takes 3178.
+//   The formulas are NOT complete, and need not be: an addition whose operands agree up to sign, or with an operand at infinity, leaves
+//   Z3 == 0, and Z == 0 survives every later doubling and addition — the caller reads that as "not in the subgroup".  That answer is right:
+//   with P of prime order r the ladder's partial multiples [k]P, 1 < k < 2^64, are never 0 or +-P, so only points outside G1 can reach
+//   those cases (small-order points do, tests/test_host_model.py and the GPU suite hold them).
+// Bounds: coordinates in X < 10p, Y < 34p, Z < 4p; jac_dbl leaves X < 2.01p, Y < 34p, Z < 4p; jac_add leaves X, Y < 10p, Z < 2p.
+// ------------------------------------------------------------------------------------------------
+struct JacFp {
+    fp28::Fp x, y, z;
+};
+
+// a <- 2a (dbl-2009-l with X B as a product): A = X^2, B = Y^2, C = B^2, S = X B, E = 3A, X3 = E^2 - 8S, Y3 = E (4S - X3) - 8C, Z3 = 2YZ
+template <class F>
+FP_HD void jac_dbl(JacFp& a) {
+    using namespace fp28;
+    const Fp A = F::sqr(a.x), B = F::sqr(a.y), C = F::sqr(B);
+    const Fp S = F::mul(a.x, B);
+    const Fp E = fp_mul_small<3>(A);                                               // < 6p
+    const Fp yz = F::mul(a.y, a.z);                                                // 34p * 4p
+    a.x = fp_reduce_small(fp_sub<32>(F::sqr(E), fp_mul_small<8>(S)));              // 8S < 16p; < 34p before the reduction, < 2.01p after
+    a.y = fp_sub<32>(F::mul(E, fp_sub<4>(fp_mul_small<4>(S), a.x)), fp_mul_small<8>(C));   // 6p * 12p; < 34p
+    a.z = fp_add(yz, yz);                                                          // < 4p
+}
+
+// a <- a + b (add-2007-bl; Z2_ONE: b is affine, b.z is not read — madd-2007-bl)
+template <class F, bool Z2_ONE>
+FP_HD void jac_add(JacFp& a, const JacFp& b) {
+    using namespace fp28;
+    const Fp z1z1 = F::sqr(a.z);
+    const Fp U2 = F::mul(b.x, z1z1), S2 = F::mul(F::mul(b.y, a.z), z1z1);
+    Fp U1, S1, zsum;
+    if (Z2_ONE) {
+        U1 = fp_reduce_small(a.x);                                                 // < 2.01p
+        S1 = fp_reduce_small(a.y);
+    } else {
+        const Fp z2z2 = F::sqr(b.z);
+        U1 = F::mul(a.x, z2z2);
+        S1 = F::mul(F::mul(a.y, b.z), z2z2);
+        zsum = fp_sub<8>(F::sqr(fp_add(a.z, b.z)), fp_add(z1z1, z2z2));            // 2 Z1 Z2  < 10p
+    }
+    const Fp H = fp_sub<4>(U2, U1);                                                // < 6p
+    const Fp H2 = fp_add(H, H);
+    const Fp I = F::sqr(H2), J = F::mul(H, I), V = F::mul(U1, I);
+    const Fp d = fp_sub<4>(S2, S1);
+    const Fp r = fp_add(d, d);                                                     // < 12p
+    const Fp S1J = F::mul(S1, J);
+    a.x = fp_sub<8>(F::sqr(r), fp_add(J, fp_add(V, V)));                           // J + 2V < 6p; < 10p
+    a.y = fp_sub<8>(F::mul(r, fp_sub<16>(V, a.x)), fp_add(S1J, S1J));              // 12p * 18p; < 10p
+    a.z = Z2_ONE ? F::mul(fp_add(a.z, a.z), H) : F::mul(zsum, H);                  // < 2p
+}
+
+// [|z|] p for the BLS parameter |z| = 0xd201000000010000: 63 doublings with the multiplier of FD (inlined in the kernels), 5 additions
+// with FA's (the shared call), on a copy so that the loop variable's address is never taken (codec_kernels.cuh, round 6)
+template <class FD, class FA, bool AFFINE>
+FP_HD JacFp jac_mul_z(const JacFp& p) {
+    JacFp r = p;
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+    for (int bit = 62; bit >= 0; bit--) {
+        jac_dbl<FD>(r);
+        if ((fp28c::Z_ABS >> bit) & 1) {
+            JacFp t = r;
+            jac_add<FA, AFFINE>(t, p);
+            r = t;
+        }
+    }
+    return r;
+}
+
+// is_torsion_free of an affine point of the curve (not infinity): (beta x, y) == -[z^2] P (Scott 2021; what blst_p1_affine_in_g1 tests), in
+// Jacobian coordinates X == beta x Z^2, Y == -y Z^3, Z != 0.  x, y < 4p.
+template <class FD, class FA>
+FP_HD bool g1_torsion_free(const fp28::Fp& x, const fp28::Fp& y) {
+    using namespace fp28;
+    JacFp p;
+    p.x = x; p.y = y; p.z = fp_one();
+    const JacFp q1 = jac_mul_z<FD, FA, true>(p);
+    const JacFp q2 = jac_mul_z<FD, FA, false>(q1);                                 // [z^2] P
+    const Fp zz = FA::sqr(q2.z);
+    const Fp bx = FA::mul(x, fp_const(fp28c::BETA));
+    bool ok = !fp_is_zero_any(q2.z);
+    ok = ok && fp_is_zero_any(fp_sub<16>(q2.x, FA::mul(bx, zz)));                  // q2.x < 10p
+    ok = ok && fp_is_zero_any(fp_add(q2.y, FA::mul(y, FA::mul(zz, q2.z))));        // q2.y < 34p
+    return ok;
+}
+
 template <class F>
 FP_HD bool proj_is_inf_exact(const Proj<F>& p) { return F::limbs_all_zero(p.z); }
 

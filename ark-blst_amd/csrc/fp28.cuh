@@ -135,6 +135,29 @@ FP_HD Fp fp_mul_small(const Fp& a) {
     return r;
 }
 
+// v + 2p - (q + 1) p with q = floor(l[13] * 40323 / 2^32), for an N-form value v < 127p: result N-form, p <= result < 2.01p.  About 100
+// plain instructions where a multiplication by the internal one (the other way below 2p) is 406 multiply-adds: what lets the Jacobian
+// doubling of the G1 subgroup ladder (ec.cuh jac_dbl) subtract 8 X B and stay inside the multiplier's contract.
+//   l[13] <= v / 2^364 < l[13] + 1.01 (N-form low limbs), 106513 < p / 2^364 < 106514, 40323 / 2^32 = 1 / 106514.82: q <= v / p and
+//   v / p - q < 1 + 1.36e7 * 1.6e-10 + 1e-5 < 1.003.  (q + 1) p is produced with EXACT limbs (one 64-bit multiply-add per limb, the carry
+//   is the addend of the next), so the subtraction is fp_sub<2>'s: the spread 2p keeps every low limb non-negative, and its top limb
+//   (2 * 106513 - 1) covers the top limb of (q + 1) p, which exceeds v's by at most 1 + 106514.
+FP_HD Fp fp_reduce_small(const Fp& v) {
+    const uint32_t q1 = (uint32_t)(((uint64_t)v.l[NL - 1] * 40323u) >> 32) + 1u;   // <= 128
+    Fp qp;
+    uint64_t t = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        t = (uint64_t)q1 * P[k] + (t >> W);
+        qp.l[k] = k < NL - 1 ? ((uint32_t)t & MASK) : (uint32_t)t;
+    }
+    Fp r;
+#pragma unroll
+    for (int k = 0; k < NL; k++) r.l[k] = v.l[k] + S2[k] - qp.l[k];
+    fp_norm1(r);
+    return r;
+}
+
 // lane-wise select without branches
 FP_HD Fp fp_select(bool take_b, const Fp& a, const Fp& b) {
     Fp r;

@@ -111,4 +111,22 @@ void h28_g1_dbl_n(const uint8_t* base, int k, uint8_t* out) {
     ec::proj_dbl_n<F>(a, k);
     store_proj_as_jac(out, a);
 }
+// fp_reduce_small on m * a (m <= 127 copies of a value < 2p added up): raw limbs in and out, the caller does the integer arithmetic
+void h28_fp_reduce_small(const uint8_t* a, int m, uint32_t* in_limbs, uint32_t* out_limbs) {
+    Fp x = load_blst(a), v = fp_zero();
+    for (int k = 0; k < m; k++) v = fp_add(v, x);
+    Fp r = fp_reduce_small(v);
+    memcpy(in_limbs, v.l, sizeof v.l);
+    memcpy(out_limbs, r.l, sizeof r.l);
+}
+// the G1 subgroup test of the decoders and of Valid::check (codec_kernels.cuh g1_in_subgroup), and its ladder's result [z^2] P as
+// Jacobian bytes (zeros when Z == 0)
+int h28_g1_torsion_free(const uint8_t* base) { return ec::g1_torsion_free<ec::FpOpsInlinePS, F>(load_blst(base), load_blst(base + 48)) ? 1 : 0; }
+void h28_g1_mul_z2(const uint8_t* base, uint8_t* out) {
+    ec::JacFp p;
+    p.x = load_blst(base); p.y = load_blst(base + 48); p.z = fp_one();
+    ec::JacFp q = ec::jac_mul_z<ec::FpOpsInlinePS, F, false>(ec::jac_mul_z<ec::FpOpsInlinePS, F, true>(p));
+    if (fp_is_zero_any(q.z)) { memset(out, 0, 144); return; }
+    store_blst(out, q.x); store_blst(out + 48, q.y); store_blst(out + 96, q.z);
+}
 }

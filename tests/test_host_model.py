@@ -136,3 +136,55 @@ def test_karatsuba_column_and_bias_bounds():
         assert col2 == 2 * col
         assert max(col2, 2 * col) + 14 * prod + (1 << 36) < 1 << 63, name
     assert 2 * 6 * 14 * prod > 1 << 63                            # six terms: why the tree does not use this form
+
+
+def test_small_reduction_and_jacobian_subgroup_ladder(h28, co, o):
+    """Round 6: the G1 subgroup test runs on a Jacobian ladder (ec.cuh jac_dbl / jac_add / g1_torsion_free) whose doubling subtracts 8 X B and
+    comes back under the multiplier's contract with fp_reduce_small.  Pinned here on the host build of the same headers: the reduction on
+    multiples up to 126 (value in [p, 2.01 p), same residue), [z^2] P against the oracle's scalar multiplication on subgroup and off-subgroup
+    points, and the verdict on points of SMALL order, where the incomplete addition meets its exceptional cases (P + P, P - P, infinity + P)
+    and must still answer "not in the subgroup"."""
+    import tests.cofactor_util as cu
+
+    rnd = random.Random(61)
+    lim = (C.c_uint32 * 14)()
+    lout = (C.c_uint32 * 14)()
+    val = lambda l: sum(int(v) << (28 * k) for k, v in enumerate(l))
+    for m in list(range(0, 12)) + [31, 32, 33, 63, 64, 65, 100, 125, 126]:
+        for a in (0, 1, o.P - 1, rnd.randrange(o.P), rnd.randrange(o.P)):
+            h28.h28_fp_reduce_small(o.fp_to_mont_bytes(a), m, lim, lout)
+            vi, vo = val(lim), val(lout)
+            assert (vi - vo) % o.P == 0 and o.P <= vo < 2 * o.P + o.P // 100, (m, a)
+            assert all(int(v) <= (1 << 28) + 15 for v in lout[:13])
+
+    z2 = 0xd201000000010000 ** 2
+    bases = co.gen_bases("g1", 61, 6)
+    good = [o.affine_from_bytes(o.F1, bases[96 * i:96 * i + 96]) for i in range(6)]
+    off = cu.off_subgroup_points(o, "g1", 4)
+    oj = C.create_string_buffer(144)
+    for pt, want in [(p, 1) for p in good] + [(p, 0) for p in off]:
+        b = o.affine_to_bytes(o.F1, pt)
+        h28.h28_g1_mul_z2(b, oj)
+        assert co.to_affine("g1", oj.raw) == o.affine_to_bytes(o.F1, o.scalar_mul(o.F1, pt, z2))
+        assert h28.h28_g1_torsion_free(b) == want
+    # points of small order: n = h1 * r is the group order, h1 = 3 * 11^2 * 10177^2 * 859267^2 * 52437899^2
+    n = cu.H1 * o.R_ORDER
+    seen = 0
+    for q in (3, 11, 10177):
+        assert cu.H1 % q == 0
+        cof = n
+        while cof % q == 0:
+            cof //= q
+        for base in off:
+            t = o.scalar_mul(o.F1, base, cof)               # in the q-primary part
+            if t is o.INF:
+                continue
+            while o.scalar_mul(o.F1, t, q) is not o.INF:
+                t = o.scalar_mul(o.F1, t, q)                # order exactly q
+            assert h28.h28_g1_torsion_free(o.affine_to_bytes(o.F1, t)) == 0
+            h28.h28_g1_mul_z2(o.affine_to_bytes(o.F1, t), oj)
+            want = o.scalar_mul(o.F1, t, z2 % q)
+            if oj.raw != bytes(144):                        # no exceptional case met on the way: then the value is the right one
+                assert co.to_affine("g1", oj.raw) == o.affine_to_bytes(o.F1, want)
+            seen += 1
+    assert seen >= 6
