@@ -451,20 +451,19 @@ __global__ void __launch_bounds__(256, 2) k_validate_g2_coop(uint32_t* __restric
         const Fp rhs = F::add(F::mul(F::sqr(x), x), four);
         if (!pair_all(fp_equal(F::sqr(y), rhs))) st = 2;
     }
-    if (st == 0) {                                         // psi(P) == [z] P = -[|z|] P:  X_q == px Z_q, Y_q == -py Z_q, Z_q != 0
-        const ec::Proj<F> p1 = ec::proj_from_affine<F>(x, y);
-        ec::Proj<F> q = p1;
-#pragma unroll 1
-        for (int bit = 62; bit >= 0; bit--) {
-            ec::proj_dbl<F>(q);
-            if ((fp28c::Z_ABS >> bit) & 1) ec::proj_add<F>(q, p1);   // five of the 63 steps; wave-uniform
-        }
+    if (st == 0) {                                         // psi(P) == [z] P = -[|z|] P:  X_q == px Z_q^2, Y_q == -py Z_q^3, Z_q != 0
+        // Jacobian ladder (ec.cuh jac_dbl / jac_add over the lane-pair field, round 6): 4 S + 3 M per doubling where the homogeneous doubling
+        // took 4 S + 4 M; its exceptional cases leave Z == 0, i.e. "not in the subgroup", and only points outside G2 reach them
+        ec::JacFp p1;
+        p1.x = x; p1.y = y; p1.z = F::one();
+        const ec::JacFp q = ec::jac_mul_z<F, F, true, true>(p1);   // five of the 63 steps add; wave-uniform
         const Fp cx = F::select(h != 0, x, fp28::fp_neg<16>(x)), cy = F::select(h != 0, y, fp28::fp_neg<16>(y));   // conj: the odd lane's component negated
         const Fp px = F::mul(cx, F::select(h != 0, fp28::fp_zero(), fp28::fp_const(fp28c::PSI_X1)));
         const Fp py = F::mul(cy, F::select(h != 0, fp28::fp_const(fp28c::PSI_Y0), fp28::fp_const(fp28c::PSI_Y1)));
+        const Fp zz = F::sqr(q.z);
         bool ok = !pair_all(fp28::fp_is_zero_any(q.z));
-        ok = ok && pair_all(fp_equal(q.x, F::mul(px, q.z)));
-        ok = ok && pair_all(fp28::fp_is_zero_any(F::add(q.y, F::mul(py, q.z))));
+        ok = ok && pair_all(fp_equal(q.x, F::mul(px, zz)));
+        ok = ok && pair_all(fp28::fp_is_zero_any(F::add(q.y, F::mul(py, F::mul(zz, q.z)))));
         if (!ok) st = 3;
     }
     if constexpr (MODE == 1) {

@@ -281,7 +281,9 @@ struct JacFp {
 };
 
 // a <- 2a (dbl-2009-l with X B as a product): A = X^2, B = Y^2, C = B^2, S = X B, E = 3A, X3 = E^2 - 8S, Y3 = E (4S - X3) - 8C, Z3 = 2YZ
-template <class F>
+// REDUCE_Y: Y3 is brought below 2.01p as well — for the lane-pair Fp2 field (coop_fp2.cuh), whose squaring forms (a + a')(a + 32p - a') and
+// takes components below 20p only.  The same code serves Fp2 there: every operation below is component-wise except F::mul / F::sqr.
+template <class F, bool REDUCE_Y = false>
 FP_HD void jac_dbl(JacFp& a) {
     using namespace fp28;
     const Fp A = F::sqr(a.x), B = F::sqr(a.y), C = F::sqr(B);
@@ -290,6 +292,7 @@ FP_HD void jac_dbl(JacFp& a) {
     const Fp yz = F::mul(a.y, a.z);                                                // 34p * 4p
     a.x = fp_reduce_small(fp_sub<32>(F::sqr(E), fp_mul_small<8>(S)));              // 8S < 16p; < 34p before the reduction, < 2.01p after
     a.y = fp_sub<32>(F::mul(E, fp_sub<4>(fp_mul_small<4>(S), a.x)), fp_mul_small<8>(C));   // 6p * 12p; < 34p
+    if (REDUCE_Y) a.y = fp_reduce_small(a.y);
     a.z = fp_add(yz, yz);                                                          // < 4p
 }
 
@@ -322,14 +325,14 @@ FP_HD void jac_add(JacFp& a, const JacFp& b) {
 
 // [|z|] p for the BLS parameter |z| = 0xd201000000010000: 63 doublings with the multiplier of FD (inlined in the kernels), 5 additions
 // with FA's (the shared call), on a copy so that the loop variable's address is never taken (codec_kernels.cuh, round 6)
-template <class FD, class FA, bool AFFINE>
+template <class FD, class FA, bool AFFINE, bool REDUCE_Y = false>
 FP_HD JacFp jac_mul_z(const JacFp& p) {
     JacFp r = p;
 #if defined(__HIPCC__)
 #pragma unroll 1
 #endif
     for (int bit = 62; bit >= 0; bit--) {
-        jac_dbl<FD>(r);
+        jac_dbl<FD, REDUCE_Y>(r);
         if ((fp28c::Z_ABS >> bit) & 1) {
             JacFp t = r;
             jac_add<FA, AFFINE>(t, p);

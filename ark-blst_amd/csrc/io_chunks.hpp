@@ -18,6 +18,18 @@ struct IoOut {
 };
 
 constexpr size_t IO_MAX_CHUNKS = 8;   // DevState::cev / iev hold eight chunk events
+// min_chunk of the decoders and the subgroup check (see io_plan): 2^18 points for G1 — one lane per point, two rounds of the machine per chunk;
+// with 2^17 every chunk is exactly one round and its ragged end is paid eight times (measured, 2^20 points: kernels 26.3 -> 27.3 ms, call
+// 31.0 -> 32.1) — and 2^17 for G2, whose subgroup test runs two lanes per point (2^18 points: call 18.1 -> 13.6 ms, the copies of one half
+// under the kernels of the other).  ARKBLST_AMD_IO_MIN_CHUNK overrides both (measurement only).
+inline size_t io_heavy_chunk(bool g2) {
+    static const size_t forced = [] {
+        const char* e = getenv("ARKBLST_AMD_IO_MIN_CHUNK");
+        return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)0;
+    }();
+    if (forced >= 256) return forced;
+    return g2 ? (size_t)1 << 17 : (size_t)1 << 18;
+}
 struct IoPlan {
     size_t K, chunk;   // chunks, elements per chunk (a multiple of `align`; the last chunk is the remainder)
 };
@@ -103,8 +115,11 @@ double io_stream_pass(DevState& d, size_t n, const void* h_in, void* d_in, size_
         launch(lo, cnt);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(d.iev[1][j], d.stream));
-        io_drain_chunk(d, p, n, j, d.iev[1][j], outs, nouts);
     }
+    // the result copies in a loop of their own: a copy to PAGEABLE host memory (what the trait's slices are) holds the calling thread until it
+    // is done, so issued inside the loop above it kept chunk j + 1's input copy and kernels from being enqueued while chunk j's results left:
+    // nothing overlapped (G2, 2^20 points: 52.0 ms in eight chunks against 48.3 ms in one)
+    for (size_t j = 0; j < p.K; j++) io_drain_chunk(d, p, n, j, d.iev[1][j], outs, nouts);
     io_finish(d);
     double k_ms = 0;
     for (size_t j = 0; j < p.K; j++) k_ms += ev_ms(d.iev[0][j], d.iev[1][j]);

@@ -866,8 +866,8 @@ void normalize_run(mi_ctx* ctx, DevState& d, const void* h_in, const void* d_in_
                            (const uint32_t*)at(d.nv_inv, 0, lo), (uint32_t)cnt, raw_out + lo * msmk::Geo<C>::RAW_AFF);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(d.iev[3][j], s));
-        io_drain_chunk(d, p, n, j, d.iev[3][j], outs, 1);
     }
+    for (size_t j = 0; j < p.K; j++) io_drain_chunk(d, p, n, j, d.iev[3][j], outs, 1);   // after every kernel is enqueued (io_chunks.hpp io_stream_pass)
     io_finish(d);
     if (publish_profile) {
         mi_profile pr{};

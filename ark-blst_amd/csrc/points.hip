@@ -49,7 +49,7 @@ void decode_run(mi_ctx* ctx, DevState& d, const uint8_t* h_bytes, const uint8_t*
     double h2d = 0;
     const double k_ms = io_stream_pass(d, n, h_bytes, d_in, sz, outs, 2, [&](size_t lo, size_t cnt) {
         K::decode(d.stream, d_in + lo * sz, cnt, compressed, validate, d_out + lo * (aff / 4), d_st + lo);
-    }, &h2d, (size_t)1 << 18);
+    }, &h2d, io_heavy_chunk(std::is_same<typename K::C, msmk::G2C>::value));
     if (publish_profile) {
         mi_profile pr{};
         pr.n = n;
@@ -194,7 +194,7 @@ int check_batch_impl(mi_ctx* ctx, const void* points, bool on_device, size_t n, 
             else
                 hipLaunchKernelGGL((msmk::k_validate<C, 2>), dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, d.stream, d_pts + lo * (aff / 4), (uint32_t)cnt,
                                    d_st + lo, (uint32_t*)nullptr);
-        }, &h2d, (size_t)1 << 18);
+        }, &h2d, io_heavy_chunk(std::is_same<C, msmk::G2C>::value));
         mi_profile pr{};
         pr.n = n; pr.h2d_ms = h2d; pr.accumulate_ms = k_ms;
         pr.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -819,6 +819,50 @@ def test_check_batch_is_valid_check(ctx, co, o, group):
     assert ctx.check_batch(group, b"") == b""
 
 
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_subgroup_ladder_on_small_order_points(ctx, co, o, group):
+    """Round 6: the subgroup tests run on Jacobian ladders whose additions are not complete (ec.cuh jac_add).  Points of SMALL order are the
+    inputs that reach the exceptional cases ([k]P == +-P, [k]P == infinity in mid-ladder): orders 3, 11, 10177 on E(Fp) and 13, 23, 2713 on
+    E'(Fp2) (the prime factors of the cofactors the reference holds, src/g1.rs:42, src/g2.rs:45-54).  All of them are curve points outside
+    the subgroup: Valid::check must say 3 and the validating decoder must reject them, next to subgroup points that pass."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cofactor_util import H1, H2, off_subgroup_points
+
+    F = o.F1 if group == "g1" else o.F2
+    aff = 96 if group == "g1" else 192
+    h, primes = (H1, (3, 11, 10177)) if group == "g1" else (H2, (13, 23, 2713))
+    n_curve = h * o.R_ORDER
+    small = []
+    for q in primes:
+        assert h % q == 0
+        cof = n_curve
+        while cof % q == 0:
+            cof //= q
+        for base in off_subgroup_points(o, group, 3):
+            t = o.scalar_mul(F, base, cof)
+            if t is o.INF:
+                continue
+            while o.scalar_mul(F, t, q) is not o.INF:
+                t = o.scalar_mul(F, t, q)
+            assert o.on_curve(F, t)
+            small.append(o.affine_to_bytes(F, t))
+            small.append(o.affine_to_bytes(F, o.aff_neg(F, t)))
+    assert len(small) >= 6
+    good = co.gen_bases(group, 6262, 64, 4)
+    blob = []
+    for i, b in enumerate(small):
+        blob += [good[aff * (2 * i % 64):aff * (2 * i % 64 + 1)], b]
+    st = ctx.check_batch(group, b"".join(blob))
+    assert st == bytes([0, 3] * len(small))
+    ser = ctx.serialize_batch(group, b"".join(blob), compressed=True)
+    pts, st2 = ctx.deserialize_batch(group, ser, compressed=True, validate=True)
+    assert bytes(st2) == bytes([0, 3] * len(small))
+    for i, b in enumerate(blob):
+        assert bytes(pts[aff * i:aff * (i + 1)]) == (b if i % 2 == 0 else bytes(aff))
+
+
 def test_plain_cpp_harness_of_the_exchange(tmp_path, co):
     """examples/multi_gpu_msm.cpp: the one-process-per-GPU deployment in plain C++ against the two C ABIs — no Python host, no torch, the
     system's RCCL — built with g++ and run as ONE rank on this box's GPU (rank 0 writes the ncclUniqueId file, creates the communicator,
