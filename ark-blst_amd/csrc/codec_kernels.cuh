@@ -39,6 +39,34 @@ __device__ __forceinline__ bool fp_equal(const Fp& a, const Fp& b) {  // a == b 
     return fp28::fp_is_zero_any(fp28::fp_sub<16>(a, b));
 }
 
+// a^e for one of the two constant square-root exponents, by a sliding window of four bits (round 6): the schedule (tools/gen_fp28_consts.py sw4)
+// is a list of (squarings << 4 | table index) over the odd powers a, a^3 .. a^15 — 378 squarings + 79 multiplications + 8 for the table where
+// square-and-multiply over the 229 set bits took 378 + 228: 27 % fewer multiply-adds per exponentiation.  The table is 112 registers; its entry is
+// picked by the (wave-uniform) index with selects, so there is ONE inlined multiplication site and one squaring site, as before.
+template <int N>
+__device__ __forceinline__ Fp fp_pow_sw4(const Fp& a, const uint16_t (&sched)[N]) {
+    Fp t[8];
+    const Fp a2 = fp28::fp_sqr_call(a);
+    t[0] = a;
+#pragma unroll
+    for (int k = 1; k < 8; k++) t[k] = fp28::fp_mul_call(t[k - 1], a2);
+    auto pick = [&](uint32_t idx) {
+        Fp m = t[0];
+#pragma unroll
+        for (uint32_t k = 1; k < 8; k++) m = fp28::fp_select(idx == k, m, t[k]);
+        return m;
+    };
+    Fp acc = pick(sched[0] & 15u);
+#pragma unroll 1
+    for (int i = 1; i < N; i++) {
+        const uint32_t v = sched[i];
+#pragma unroll 1
+        for (uint32_t sq = v >> 4; sq; sq--) acc = fp28::fp_sqr(acc);
+        if ((v & 15u) != 15u) acc = fp28::fp_mul(acc, pick(v & 15u));
+    }
+    return acc;
+}
+
 // is_torsion_free of an affine point in the internal form: ec::g1_torsion_free — two 63-step Jacobian ladders (round 6: 4 S + 3 M + one
 // small reduction per doubling where the homogeneous doubling of rounds 4-5 took 3 S + 5.5 M), doublings with the multiplier inlined,
 // the ten additions through the shared body on a COPY.  BY VALUE and inlined since round 6: as an out-of-line function over references
@@ -84,14 +112,7 @@ __global__ void __launch_bounds__(256, 2) k_deserialize_g1(const uint8_t* __rest
         Fp rhs = fp28::fp_add(fp28::fp_mul_call(fp28::fp_sqr_call(x), x), fp28::fp_const(fp28c::FOUR));   // x^3 + 4  < 4p
         bool on_curve;
         if (compressed) {
-            // y = rhs^((p+1)/4): left-to-right square and multiply over the 379-bit exponent
-            Fp acc = rhs;
-#pragma unroll 1
-            for (int bit = 377; bit >= 0; bit--) {  // top set bit of (p+1)/4 is bit 378; multiplier inlined (two bodies): no call, no scratch copy of rhs per step
-                acc = fp28::fp_sqr(acc);
-                if ((fp28c::SQRT_EXP32[bit >> 5] >> (bit & 31)) & 1) acc = fp28::fp_mul(acc, rhs);
-            }
-            y = acc;
+            y = fp_pow_sw4(rhs, fp28c::SQRT_SW4);   // rhs^((p+1)/4)
             on_curve = fp_equal(fp28::fp_sqr_call(y), rhs);
             if (!on_curve) st = 1;  // no square root: malformed compressed encoding
             // pick the root the sort flag asks for
@@ -181,15 +202,7 @@ __device__ __noinline__ ec::Fp2 fp2_pow(const ec::Fp2& a, const uint32_t (&e)[12
 }
 // a^((p-3)/4) in Fp: for a square a, a * a^((p-3)/4) is a square root of a and a^((p-3)/4) itself is that root's INVERSE
 // (their product is a^((p-1)/2) = 1); for a non-square the product of the two is -1 and (a * a^((p-3)/4))^2 = -a.
-__device__ __noinline__ Fp fp_pow_p3_4(const Fp& a) {
-    Fp acc = a;
-#pragma unroll 1
-    for (int bit = 377; bit >= 0; bit--) {   // (p-3)/4 has its top bit at 378; multiplier inlined (two bodies), as in k_deserialize_g1
-        acc = fp28::fp_sqr(acc);
-        if ((fp28c::EXP_P3_4_32[bit >> 5] >> (bit & 31)) & 1) acc = fp28::fp_mul(acc, a);
-    }
-    return acc;
-}
+__device__ __noinline__ Fp fp_pow_p3_4(const Fp& a) { return fp_pow_sw4(a, fp28c::P3_4_SW4); }
 // Square root in Fp2 = Fp[u] / (u^2 + 1) by the complex method: TWO exponentiations in Fp (2 x 570 field multiplications) where rounds 2-5
 // ran two in Fp2 (Adj / Rodriguez-Henriquez: 2 x 1330) — VERDICT r05 #7.  For a = a0 + a1 u with norm n = a0^2 + a1^2:
 //   s = sqrt(n) (a square whenever a is one);  t = (a0 + s) / 2;  r = t^((p-3)/4);  c = r t   (c^2 = t if t is a square, -t if not)

@@ -59,6 +59,9 @@ struct CoopF2 {
     template <int K>
     static __device__ __forceinline__ E neg(const E& a) { return fp28::fp_neg<K>(a); }
     static __device__ __forceinline__ E mul3(const E& a) { return fp28::fp_mul_small<3>(a); }
+    template <int K>
+    static __device__ __forceinline__ E mul_small(const E& a) { return fp28::fp_mul_small<K>(a); }
+    static __device__ __forceinline__ E reduce_small(const E& a) { return fp28::fp_reduce_small(a); }   // component-wise (ec.cuh jac_dbl)
     // b3 a, b3 = 12 (1 + u):  12 (a0 - a1) + 12 (a0 + a1) u — one linear combination with the partner and ONE single-product
     // multiplication by the constant 12 per lane (406 multiply-adds instead of the 602 of a full Fp2 product); a <= 3p, result < 2p
     static __device__ __forceinline__ E mul_b3(const E& a) {

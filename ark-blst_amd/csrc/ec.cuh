@@ -40,6 +40,9 @@ struct FpOps {
     template <int K>
     static FP_HD E neg(const E& a) { return fp28::fp_neg<K>(a); }
     static FP_HD E mul3(const E& a) { return fp28::fp_mul_small<3>(a); }
+    template <int K>
+    static FP_HD E mul_small(const E& a) { return fp28::fp_mul_small<K>(a); }
+    static FP_HD E reduce_small(const E& a) { return fp28::fp_reduce_small(a); }   // value < 127p -> [p, 2.01p) (the Jacobian ladder below)
     static FP_HD E mul_b3(const E& a) { return fp28::fp_mul_small<12>(a); }
     static FP_HD E mul_b3_red(const E& a) { return fp28::fp_mul_call(a, fp28::fp_const(fp28::TWELVE)); }   // 12 a as a field product: < 2p
     // s^2 - 12 e^2 (proj_dbl): s <= 22p, e < 3p
@@ -276,65 +279,68 @@ FP_HD void proj_dbl_n(Proj<F>& a, int k) {
 //   those cases (small-order points do, tests/test_host_model.py and the GPU suite hold them).
 // Bounds: coordinates in X < 10p, Y < 34p, Z < 4p; jac_dbl leaves X < 2.01p, Y < 34p, Z < 4p; jac_add leaves X, Y < 10p, Z < 2p.
 // ------------------------------------------------------------------------------------------------
-struct JacFp {
-    fp28::Fp x, y, z;
+template <class E>
+struct JacE {
+    E x, y, z;
 };
+using JacFp = JacE<fp28::Fp>;
 
 // a <- 2a (dbl-2009-l with X B as a product): A = X^2, B = Y^2, C = B^2, S = X B, E = 3A, X3 = E^2 - 8S, Y3 = E (4S - X3) - 8C, Z3 = 2YZ
 // REDUCE_Y: Y3 is brought below 2.01p as well — for the lane-pair Fp2 field (coop_fp2.cuh), whose squaring forms (a + a')(a + 32p - a') and
-// takes components below 20p only.  The same code serves Fp2 there: every operation below is component-wise except F::mul / F::sqr.
+// takes components below 20p only.  Every operation goes through F, so tests/host/msm_bounds.cpp runs this very code on a field of bounds.
 template <class F, bool REDUCE_Y = false>
-FP_HD void jac_dbl(JacFp& a) {
-    using namespace fp28;
-    const Fp A = F::sqr(a.x), B = F::sqr(a.y), C = F::sqr(B);
-    const Fp S = F::mul(a.x, B);
-    const Fp E = fp_mul_small<3>(A);                                               // < 6p
-    const Fp yz = F::mul(a.y, a.z);                                                // 34p * 4p
-    a.x = fp_reduce_small(fp_sub<32>(F::sqr(E), fp_mul_small<8>(S)));              // 8S < 16p; < 34p before the reduction, < 2.01p after
-    a.y = fp_sub<32>(F::mul(E, fp_sub<4>(fp_mul_small<4>(S), a.x)), fp_mul_small<8>(C));   // 6p * 12p; < 34p
-    if (REDUCE_Y) a.y = fp_reduce_small(a.y);
-    a.z = fp_add(yz, yz);                                                          // < 4p
+FP_HD void jac_dbl(JacE<typename F::E>& a) {
+    using E = typename F::E;
+    const E A = F::sqr(a.x), B = F::sqr(a.y), C = F::sqr(B);
+    const E S = F::mul(a.x, B);
+    const E M = F::template mul_small<3>(A);                                                          // 3 X^2 < 6p
+    const E yz = F::mul(a.y, a.z);                                                                    // 34p * 4p
+    a.x = F::reduce_small(F::template sub<32>(F::sqr(M), F::template mul_small<8>(S)));               // 8S < 16p; < 34p before the reduction, < 2.01p after
+    a.y = F::template sub<32>(F::mul(M, F::template sub<4>(F::template mul_small<4>(S), a.x)), F::template mul_small<8>(C));   // 6p * 12p; < 34p
+    if (REDUCE_Y) a.y = F::reduce_small(a.y);
+    a.z = F::add(yz, yz);                                                                             // < 4p
 }
 
 // a <- a + b (add-2007-bl; Z2_ONE: b is affine, b.z is not read — madd-2007-bl)
 template <class F, bool Z2_ONE>
-FP_HD void jac_add(JacFp& a, const JacFp& b) {
-    using namespace fp28;
-    const Fp z1z1 = F::sqr(a.z);
-    const Fp U2 = F::mul(b.x, z1z1), S2 = F::mul(F::mul(b.y, a.z), z1z1);
-    Fp U1, S1, zsum;
+FP_HD void jac_add(JacE<typename F::E>& a, const JacE<typename F::E>& b) {
+    using E = typename F::E;
+    const E z1z1 = F::sqr(a.z);
+    const E U2 = F::mul(b.x, z1z1), S2 = F::mul(F::mul(b.y, a.z), z1z1);
+    E U1, S1, zsum;
     if (Z2_ONE) {
-        U1 = fp_reduce_small(a.x);                                                 // < 2.01p
-        S1 = fp_reduce_small(a.y);
+        U1 = F::reduce_small(a.x);                                                                    // < 2.01p
+        S1 = F::reduce_small(a.y);
+        zsum = a.z;
     } else {
-        const Fp z2z2 = F::sqr(b.z);
+        const E z2z2 = F::sqr(b.z);
         U1 = F::mul(a.x, z2z2);
         S1 = F::mul(F::mul(a.y, b.z), z2z2);
-        zsum = fp_sub<8>(F::sqr(fp_add(a.z, b.z)), fp_add(z1z1, z2z2));            // 2 Z1 Z2  < 10p
+        zsum = F::template sub<8>(F::sqr(F::add(a.z, b.z)), F::add(z1z1, z2z2));                      // 2 Z1 Z2  < 10p
     }
-    const Fp H = fp_sub<4>(U2, U1);                                                // < 6p
-    const Fp H2 = fp_add(H, H);
-    const Fp I = F::sqr(H2), J = F::mul(H, I), V = F::mul(U1, I);
-    const Fp d = fp_sub<4>(S2, S1);
-    const Fp r = fp_add(d, d);                                                     // < 12p
-    const Fp S1J = F::mul(S1, J);
-    a.x = fp_sub<8>(F::sqr(r), fp_add(J, fp_add(V, V)));                           // J + 2V < 6p; < 10p
-    a.y = fp_sub<8>(F::mul(r, fp_sub<16>(V, a.x)), fp_add(S1J, S1J));              // 12p * 18p; < 10p
-    a.z = Z2_ONE ? F::mul(fp_add(a.z, a.z), H) : F::mul(zsum, H);                  // < 2p
+    const E H = F::template sub<4>(U2, U1);                                                           // < 6p
+    const E H2 = F::add(H, H);
+    const E I = F::sqr(H2), J = F::mul(H, I), V = F::mul(U1, I);
+    const E d = F::template sub<4>(S2, S1);
+    const E r = F::add(d, d);                                                                         // < 12p
+    const E S1J = F::mul(S1, J);
+    a.x = F::template sub<8>(F::sqr(r), F::add(J, F::add(V, V)));                                     // J + 2V < 6p; < 10p
+    a.y = F::template sub<8>(F::mul(r, F::template sub<16>(V, a.x)), F::add(S1J, S1J));               // 12p * 18p; < 10p
+    a.z = Z2_ONE ? F::mul(F::add(zsum, zsum), H) : F::mul(zsum, H);                                   // < 2p
 }
 
 // [|z|] p for the BLS parameter |z| = 0xd201000000010000: 63 doublings with the multiplier of FD (inlined in the kernels), 5 additions
 // with FA's (the shared call), on a copy so that the loop variable's address is never taken (codec_kernels.cuh, round 6)
 template <class FD, class FA, bool AFFINE, bool REDUCE_Y = false>
-FP_HD JacFp jac_mul_z(const JacFp& p) {
-    JacFp r = p;
+FP_HD JacE<typename FD::E> jac_mul_z(const JacE<typename FD::E>& p) {
+    JacE<typename FD::E> r = p;
 #if defined(__HIPCC__)
 #pragma unroll 1
 #endif
     for (int bit = 62; bit >= 0; bit--) {
         jac_dbl<FD, REDUCE_Y>(r);
         if ((fp28c::Z_ABS >> bit) & 1) {
-            JacFp t = r;
+            JacE<typename FD::E> t = r;
             jac_add<FA, AFFINE>(t, p);
             r = t;
         }

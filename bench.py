@@ -607,7 +607,7 @@ def _deserialize_g2_leg(pkg, co, ncpu, device, log_n=18) -> dict:
             "workload": f"2^{log_n} compressed G2 encodings (96 B), decompression (Fp2 square root, complex method: two Fp exponentiations) + on-curve + subgroup check, host buffers in and out",
             "roofline": _valu_roofline("k_deserialize_g2 + k_validate<G2C>", f"~{fp_muls} Fp-mul x {MADS_PER_FP_MUL} MAD per point",
                                        fp_muls * MADS_PER_FP_MUL * n, kms, clock, clock_src,
-                                       dict(zip(("traffic", "traffic_source", "traffic_stale"), _rows_f_traffic("g2", log_n, ("k_deserialize_g2", "k_validate<msmk::G2C, 1>"))),
+                                       dict(zip(("traffic", "traffic_source", "traffic_stale"), _rows_f_traffic("g2", log_n, ("k_deserialize_g2", "k_validate_g2_coop<1>"))),
                                             algorithmic_bytes_per_launch=(96 + 192) * n)),
             "cpu_baseline": {"value": m / cpu_s, "unit": "points/s", "cores": ncpu, "kind": "port", "cpu_model": _cpu_model(), "seconds": cpu_s,
                              "sample": f"{m} of the encodings: Fp2 square root by two Fp2 exponentiations + psi-endomorphism subgroup test in C "

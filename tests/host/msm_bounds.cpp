@@ -59,6 +59,12 @@ struct BoundFp {
     template <int K> static E sub(const E& a, const E& b) { need_subtrahend(b, K, SPREAD_LO); limb(a.l + SPREAD_HI); return {a.v + K, NFORM}; }
     template <int K> static E neg(const E& a) { return sub<K>(zero(), a); }
     static E mul3(const E& a) { limb(3 * a.l); return {3 * a.v, NFORM}; }
+    template <int K> static E mul_small(const E& a) { limb(K * a.l); return {K * a.v, NFORM}; }
+    static E reduce_small(const E& a) {                                                   // fp_reduce_small: N-form in, value < 127p; [p, 2.01p) out
+        if (a.v > 126) fail("reduce_small operand value", a.v, 126);
+        if (a.l > NFORM) fail("reduce_small operand limb", a.l, NFORM);
+        return {2.01, NFORM};
+    }
     static E mul_b3(const E& a) { limb(12 * a.l); return {12 * a.v, NFORM}; }
     static E mul_b3_red(const E& a) { return mul(a, E{1, EXACT}); }                       // times the constant 12 (< p) as a field product
     static E sqr_sub12sqr(const E& s, const E& e) {                                       // one fused reduction (FpOpsInlinePS)
@@ -178,6 +184,50 @@ static void check_g2(const char* tag) {
            std::max(inv.y.c0, inv.y.c1), std::max(pinv.x.c0, pinv.x.c1), std::max(pinv.y.c0, pinv.y.c1), std::max(pinv.z.c0, pinv.z.c1));
 }
 
+// One COMPONENT of the lane-pair Fp2 field (coop_fp2.cuh CoopF2; both lanes of a pair hold values of the same bounds):
+//   mul   a s1 + a' s2 with s1 = b or b', s2 = 32p - b' (carry-free: limbs < 2^29 + 68) or b       needs b <= 31p
+//   sqr   (a + a')(a + 32p - a')  |  (2 a') a                                                        needs a <= 31p
+struct BoundCoop : BoundFp {
+    static E mul(const E& a, const E& b) {
+        if (b.v > 31) fail("coop mul: b", b.v, 31);
+        return reduce(a.v * b.v + a.v * 32.0, a.l * b.l + a.l * SPREAD_HI);
+    }
+    static E sqr(const E& a) {
+        const E u = add(a, a), v = sub<32>(a, a);
+        return reduce(u.v * v.v, u.l * v.l);
+    }
+};
+
+// The Jacobian subgroup ladders (ec.cuh jac_dbl / jac_add, round 6): the invariant under "double, then maybe add the base point or any state".
+template <class F, bool REDUCE_Y, bool GENERAL_ADD>
+static void check_jac(const char* tag) {
+    using J = ec::JacE<BFp>;
+    const J base{BFp{4, NFORM}, BFp{4, NFORM}, F::one()};     // affine inputs x, y < 4p
+    J inv = base;
+    auto mxj = [](const J& a, const J& b) { return J{mx(a.x, b.x), mx(a.y, b.y), mx(a.z, b.z)}; };
+    for (int it = 0;; it++) {
+        J d = inv;
+        ec::jac_dbl<F, REDUCE_Y>(d);
+        J t = d;
+        ec::jac_add<F, true>(t, base);
+        J nx = mxj(mxj(inv, d), t);
+        if (GENERAL_ADD) {
+            J g = d;
+            ec::jac_add<F, false>(g, inv);
+            nx = mxj(nx, g);
+        }
+        const bool fix = nx.x.v == inv.x.v && nx.y.v == inv.y.v && nx.z.v == inv.z.v && nx.x.l == inv.x.l && nx.y.l == inv.y.l && nx.z.l == inv.z.l;
+        inv = nx;
+        if (fix) break;
+        if (it == 63) fail("Jacobian ladder invariant did not converge", it, 63);
+    }
+    // the verdict (ec::g1_torsion_free / k_validate_g2_coop): X vs (beta x) Z^2 through fp_sub<16>, Y + y Z^3, both below the ~50p of fp_is_zero_any
+    const BFp zz = F::sqr(inv.z);
+    const BFp ex = F::template sub<16>(inv.x, F::mul(base.x, zz)), ey = F::add(inv.y, F::mul(base.y, F::mul(zz, inv.z)));
+    if (ex.v > 50 || ey.v > 50) fail("verdict operand", std::max(ex.v, ey.v), 50);
+    printf("%s: Jacobian ladder X < %.2fp, Y < %.2fp, Z < %.2fp\n", tag, inv.x.v, inv.y.v, inv.z.v);
+}
+
 int main() {
     using F = BoundFp;
     // --- accumulate hot loop (k_accumulate): x2 exact < 2p (ingest output), y2 = y or its lazy negation 4p - y
@@ -219,6 +269,9 @@ int main() {
         }
         printf("proj_dbl / proj_add ladder: X < %.0fp, Y < %.0fp, Z < %.0fp\n", d.x.v, d.y.v, d.z.v);
     }
+    // --- the subgroup ladders: G1 (both ladders: the second adds a Jacobian point), G2 on the lane-pair field (affine additions only)
+    check_jac<BoundFp, false, true>("G1");
+    check_jac<BoundCoop, true, false>("G2 (lane pair)");
     // --- G2: hot loop on the inlined Fp2 variant, everything else on the shared-call variant (msm_kernels.cuh: G2C)
     check_g2<BoundFp2<true>, BoundFp2<false>>("G2");
     printf("msm bounds OK: largest product %.0f p^2 (limit %.0f), largest column sum 2^%.2f (limit 2^%.2f), largest limb 2^%.2f\n",

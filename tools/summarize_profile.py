@@ -60,7 +60,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench   # source_hash(): the tree this summary was measured on (the profile ran on a snapshot of it)
 sha_file = f"{src}/source.sha256"
 source_sha = open(sha_file).read().split()[0] if os.path.exists(sha_file) else bench.source_hash()
-json.dump({"source_sha256": source_sha, "source": f"rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*, one pass each) of `python3 {cmd}` "
+extra = {}
+if "bench_rows_f.py" in cmd and "--once" in cmd:
+    extra["calls_profiled"] = 2   # tools/bench_rows_f.py --once: one warm call sizes the buffers, one more of the same size follows (both full size)
+json.dump({**extra, "source_sha256": source_sha, "source": f"rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*, one pass each) of `python3 {cmd}` "
                      "(means over all launches of a kernel in the run, warm-up launches included)",
            "workload": {"group": group, "log_n": log_n, "precomputed": precomputed},
            "kernels": out}, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
