@@ -792,7 +792,7 @@ __global__ void __launch_bounds__(64, CS::MAX_OCC) k_combine(const uint32_t* __r
 //   (top level <= 64 values: inverted on the host, one Fermat inversion)
 //   k_norm_down : per group: inverse of each value from the inverse of the group total
 //   k_norm_final: x = X / Z^2, y = Y / Z^3, back to the reference's form
-constexpr uint32_t NORM_K = 32;
+constexpr uint32_t NORM_K = 8;   // round 6: 32 -> 8 (one lane per group: 2^20 values at fan-out 32 are 512 waves, a quarter of the wave slots; at 8 they fill them: 1.17 -> 0.96 ms, G2 3.09 -> 2.20; 4 is slower again — seven levels)
 
 template <class C>
 __global__ void __launch_bounds__(256, 2) k_norm_load(const uint32_t* __restrict__ raw_jac, uint32_t n, uint32_t* __restrict__ vals) {
