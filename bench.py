@@ -503,14 +503,17 @@ def _pairing_leg(pkg, co, ncpu, device) -> dict:
                                        "(oracle/pairing_oracle.c), an order of magnitude slower per core than assembly libraries", "seconds": cpu_s}}
 
 
-NORM_FP_MULS_PER_POINT = 12          # product tree up + down (fan-out 32): ~5, Z^-2, Z^-3, x and y: 4, conversions in and out: 3
-DESER_FP_MULS_PER_POINT = 570 + 1650  # y = (x^3 + 4)^((p+1)/4): 378 squarings + ~190 products; subgroup test: two 64-bit ladders on complete formulas
+NORM_FP_MULS_PER_POINT = 12          # product tree up + down (fan-out 8): ~3.5, Z^-2, Z^-3, x and y: 4, conversions in and out: 5
+# G1 decoder as the kernels of round 6 execute it (a squaring counts as one multiplication): y = (x^3 + 4)^((p+1)/4) by a sliding window of four
+# bits, 378 squarings + 87 products, + 5 around it = 470; subgroup test: two 63-step Jacobian ladders, 7 per doubling, 5 mixed additions of 11 and 5
+# general ones of 16, + 4 for the verdict = 1021.  (Rounds 2-5: square-and-multiply 570 + complete projective formulas 1650.)
+DESER_FP_MULS_PER_POINT = 470 + 1021
 
 
-# G2 decoder (round 6: Fp2 square root by the complex method): two Fp exponentiations by (p-3)/4 (378 squarings + ~190 products each) = 1136,
-# + ~20 around them; subgroup test: one 64-bit ladder, 63 doublings at 22 Fp-mul + 5 complete additions at 36 = 1566
-# (rounds 2-5 ran two Fp2 exponentiations: 2656 + 1566)
-DESER_G2_FP_MULS_PER_POINT = 1156 + 1566
+# G2 decoder (round 6): Fp2 square root by the complex method, two Fp exponentiations by (p-3)/4 on the sliding window (378 squarings + 87
+# products each) = 930, + ~20 around them; subgroup test: one 63-step Jacobian ladder over Fp2, 4 squarings (2 Fp-mul) + 3 products (3 Fp-mul) = 17
+# per doubling, 5 mixed additions of 29, + ~15 for psi and the verdict = 1231.  (Rounds 2-5: two Fp2 exponentiations 2656 + complete formulas 1566.)
+DESER_G2_FP_MULS_PER_POINT = 950 + 1231
 
 
 def _normalize_leg(pkg, co, ncpu, device, g="g1", log_n=20) -> dict:
@@ -605,7 +608,7 @@ def _deserialize_g2_leg(pkg, co, ncpu, device, log_n=18) -> dict:
     return {"metric": "G2 points/s, deserialize_batch (compressed, validate on), host slices in and out", "value": n / wall, "unit": "points/s", "n": n,
             "call_ms_host_buffers": wall * 1e3, "kernel_ms": kms, "kernel_ms_validate_off": kms_novalidate, "set_bases_from_compressed_ms": load_ms, "bit_exact": ok,
             "workload": f"2^{log_n} compressed G2 encodings (96 B), decompression (Fp2 square root, complex method: two Fp exponentiations) + on-curve + subgroup check, host buffers in and out",
-            "roofline": _valu_roofline("k_deserialize_g2 + k_validate<G2C>", f"~{fp_muls} Fp-mul x {MADS_PER_FP_MUL} MAD per point",
+            "roofline": _valu_roofline("k_deserialize_g2 + k_validate_g2_coop", f"~{fp_muls} Fp-mul x {MADS_PER_FP_MUL} MAD per point",
                                        fp_muls * MADS_PER_FP_MUL * n, kms, clock, clock_src,
                                        dict(zip(("traffic", "traffic_source", "traffic_stale"), _rows_f_traffic("g2", log_n, ("k_deserialize_g2", "k_validate_g2_coop<1>"))),
                                             algorithmic_bytes_per_launch=(96 + 192) * n)),
@@ -655,7 +658,7 @@ def _deserialize_leg(pkg, co, ncpu, device, log_n=20) -> dict:
             "srs_load": {"set_bases_from_compressed_ms": load_ms, "deserialize_then_set_bases_then_validate_ms": three_ms},
             "bit_exact": ok,
             "workload": f"2^{log_n} compressed G1 encodings (48 B), decompression + on-curve + subgroup check, host buffers in and out",
-            "roofline": _valu_roofline("k_deserialize_g1", f"{DESER_FP_MULS_PER_POINT} Fp-mul (square root 570 + subgroup test 1650) x {MADS_PER_FP_MUL} MAD per point",
+            "roofline": _valu_roofline("k_deserialize_g1", f"{DESER_FP_MULS_PER_POINT} Fp-mul (square root 470 + subgroup test 1021) x {MADS_PER_FP_MUL} MAD per point",
                                        mads * n, kms, clock, clock_src,
                                        dict(zip(("traffic", "traffic_source", "traffic_stale"), _rows_f_traffic("g1", log_n, ("k_deserialize_g1",))),
                                             algorithmic_bytes_per_launch=(48 + 96) * n)),
