@@ -860,14 +860,76 @@ __global__ void __launch_bounds__(256, 2) k_norm_final(const uint32_t* __restric
 #pragma unroll 4
     for (int k = 0; k < R; k++) any |= q[2 * R + k];
     E x, y, zi;
-    ElemIO<E>::from_raw(x, q);
-    ElemIO<E>::from_raw(y, q + R);
+    ElemIO<E>::unpack_raw(x, q);                // as in k_norm_down0_final: no change of radix for X and Y
+    ElemIO<E>::unpack_raw(y, q + R);
     ElemIO<E>::load(zi, zinv + (size_t)i * Geo<C>::SLOT);
     E zi2 = F::mul(zi, zi);
     E zi3 = F::mul(zi2, zi);
     uint32_t* o = raw_aff + (size_t)i * Geo<C>::RAW_AFF;
-    ElemIO<E>::to_raw(o, F::mul(x, zi2), any != 0);
-    ElemIO<E>::to_raw(o + R, F::mul(y, zi3), any != 0);
+    ElemIO<E>::pack_raw(o, F::mul(x, zi2), any != 0);
+    ElemIO<E>::pack_raw(o + R, F::mul(y, zi3), any != 0);
+}
+
+// Level 0 of the tree FUSED with what surrounds it (round 6): the up-sweep reads Z straight from the caller's Jacobian points, the down-sweep
+// produces the affine point the moment a Z inverse exists.  Level 0 then keeps only its prefix products: the separate form wrote and re-read
+// the converted Z values and their inverses (2 x 64 B per point each way) and took two launches more per chunk — 1.65 GB of HBM traffic per
+// 2^20-point call against 252 MB algorithmic.  Used when the tree has more than one level (n > 64).
+//   k_norm_up0         : per group of K points: Z_i (raw, infinity -> 1) -> exclusive prefix products + group total (= level 1's value)
+//   k_norm_down0_final : per group, last point first: 1 / Z_i = I * prefix_i, I *= Z_i (re-read, re-converted: one multiplication instead of
+//                        128 B of traffic); x = X / Z^2, y = Y / Z^3 in the reference's form
+template <class C>
+__global__ void __launch_bounds__(256, 2) k_norm_up0(const uint32_t* __restrict__ raw_jac, uint32_t n, uint32_t* __restrict__ pref,
+                                                  uint32_t* __restrict__ tot) {
+    using F = typename C::F;
+    using E = typename F::E;
+    constexpr int R = ElemIO<E>::RAW;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lo = g * NORM_K, hi = lo + NORM_K < n ? lo + NORM_K : n;
+    if (lo >= n) return;
+    E run = F::one();
+    for (uint32_t k = lo; k < hi; k++) {
+        ElemIO<E>::store(pref + (size_t)k * Geo<C>::SLOT, run);
+        const uint32_t* zr = raw_jac + (size_t)k * Geo<C>::RAW_JAC + 2 * R;
+        uint32_t any = 0;
+#pragma unroll 4
+        for (int w = 0; w < R; w++) any |= zr[w];
+        E z;
+        ElemIO<E>::from_raw(z, zr);
+        run = F::mul(run, F::select(any == 0, z, F::one()));
+    }
+    ElemIO<E>::store(tot + (size_t)g * Geo<C>::SLOT, run);
+}
+
+template <class C>
+__global__ void __launch_bounds__(256, 2) k_norm_down0_final(const uint32_t* __restrict__ raw_jac, const uint32_t* __restrict__ pref,
+                                                          const uint32_t* __restrict__ inv_tot, uint32_t n, uint32_t* __restrict__ raw_aff) {
+    using F = typename C::F;
+    using E = typename F::E;
+    constexpr int R = ElemIO<E>::RAW;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lo = g * NORM_K, hi = lo + NORM_K < n ? lo + NORM_K : n;
+    if (lo >= n) return;
+    E I;
+    ElemIO<E>::load(I, inv_tot + (size_t)g * Geo<C>::SLOT);
+    for (uint32_t k = hi; k-- > lo;) {
+        const uint32_t* q = raw_jac + (size_t)k * Geo<C>::RAW_JAC;
+        uint32_t any = 0;
+#pragma unroll 4
+        for (int w = 0; w < R; w++) any |= q[2 * R + w];
+        E x, y, z, p;
+        ElemIO<E>::from_raw(z, q + 2 * R);
+        z = F::select(any == 0, z, F::one());
+        ElemIO<E>::load(p, pref + (size_t)k * Geo<C>::SLOT);
+        const E zi = F::mul(I, p);
+        I = F::mul(I, z);
+        ElemIO<E>::unpack_raw(x, q);            // X, Y stay in the caller's Montgomery form: times an internal-form factor they come out in it
+        ElemIO<E>::unpack_raw(y, q + R);
+        const E zi2 = F::mul(zi, zi);
+        const E zi3 = F::mul(zi2, zi);
+        uint32_t* o = raw_aff + (size_t)k * Geo<C>::RAW_AFF;
+        ElemIO<E>::pack_raw(o, F::mul(x, zi2), any != 0);
+        ElemIO<E>::pack_raw(o + R, F::mul(y, zi3), any != 0);
+    }
 }
 
 // device form <-> reference form for a short vector of field elements (top of the product tree, host inversion)

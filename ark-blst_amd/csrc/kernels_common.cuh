@@ -66,6 +66,22 @@ __device__ __forceinline__ uint32_t fp_to_raw(uint32_t* out, const Fp& a, bool k
     return any;
 }
 
+// The reference's words WITHOUT the change of Montgomery radix, for values that meet an internal-form factor exactly once: the product of
+// x 2^384 (the caller's form, re-limbed) and w 2^392 (internal) under the internal multiplication is (x w) 2^384 — the caller's form again.
+// normalize_batch's x = X / Z^2, y = Y / Z^3 are such products: four conversions (multiplications) per point less (round 6).
+__device__ __forceinline__ void fp_unpack_raw(Fp& r, const uint32_t* raw) {
+    uint32_t w[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) w[k] = raw[k];
+    r = fp28::fp_unpack384(w);
+}
+__device__ __forceinline__ void fp_pack_raw(uint32_t* out, const Fp& a, bool keep) {   // a < 2p (a multiplier output)
+    uint32_t w[12];
+    fp28::fp_pack384(w, fp28::fp_canon_2p(a));
+#pragma unroll
+    for (int k = 0; k < 12; k++) out[k] = keep ? w[k] : 0u;
+}
+
 // element I/O, generic over Fp / Fp2
 template <class E> struct ElemIO;
 template <> struct ElemIO<Fp> {
@@ -75,6 +91,8 @@ template <> struct ElemIO<Fp> {
     static __device__ __forceinline__ Fp shfl_down(const Fp& a, int d) { return shfl_down_fp(a, d); }
     static __device__ __forceinline__ void from_raw(Fp& r, const uint32_t* raw) { fp_from_raw(r, raw); }
     static __device__ __forceinline__ uint32_t to_raw(uint32_t* out, const Fp& a, bool keep) { return fp_to_raw(out, a, keep); }
+    static __device__ __forceinline__ void unpack_raw(Fp& r, const uint32_t* raw) { fp_unpack_raw(r, raw); }
+    static __device__ __forceinline__ void pack_raw(uint32_t* out, const Fp& a, bool keep) { fp_pack_raw(out, a, keep); }
 };
 template <> struct ElemIO<ec::Fp2> {
     static constexpr int SLOT = 32, RAW = 24;
@@ -90,6 +108,8 @@ template <> struct ElemIO<ec::Fp2> {
     static __device__ __forceinline__ uint32_t to_raw(uint32_t* out, const ec::Fp2& a, bool keep) {
         return fp_to_raw(out, a.c0, keep) | fp_to_raw(out + 12, a.c1, keep);
     }
+    static __device__ __forceinline__ void unpack_raw(ec::Fp2& r, const uint32_t* raw) { fp_unpack_raw(r.c0, raw); fp_unpack_raw(r.c1, raw + 12); }
+    static __device__ __forceinline__ void pack_raw(uint32_t* out, const ec::Fp2& a, bool keep) { fp_pack_raw(out, a.c0, keep); fp_pack_raw(out + 12, a.c1, keep); }
 };
 
 struct G1C {                         // /root/reference/src/g1.rs: G1Affine / G1Projective over Fp

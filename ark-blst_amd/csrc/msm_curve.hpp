@@ -774,11 +774,13 @@ int msm_batch_impl(mi_ctx* ctx, const uint8_t* const* scalars, bool scalars_on_d
 }
 
 // normalize_batch on one device.  Host pointers cross PCIe in chunks (io_chunks.hpp):
-//   per chunk, as it lands     k_norm_load (Z values into the tree's level 0)
-//   once                       the product tree up, the <= 64 top values inverted on the host, the tree down — at FULL size: a tree kernel has one
-//                              lane per group of NORM_K values, and cut into chunks its launches (n / 8 / 32 lanes) left most of the machine idle
-//                              (measured: 10 ms instead of 1 ms of kernels for 2^18 G2 points)
-//   per chunk                  k_norm_final, the chunk's affine points leave on the d2h stream while the next chunk is converted  A NULL host pointer with a device pointer: the
+//   per chunk, as it lands     k_norm_up0: Z straight from the caller's points -> prefix products of level 0, group totals = level 1
+//   once                       levels >= 1 of the product tree up, the <= 64 top values inverted on the host, the tree down to level 1 — at FULL
+//                              size: a tree kernel has one lane per group of NORM_K values, and cut into chunks its launches left most of the
+//                              machine idle (measured: 10 ms instead of 1 ms of kernels for 2^18 G2 points)
+//   per chunk                  k_norm_down0_final: level 0's inverses and the affine points in one pass; the chunk's points leave on the d2h
+//                              stream while the next chunk is converted
+// (n <= 64: one level, k_norm_load / host inversion / k_norm_final.)  A NULL host pointer with a device pointer: the
 // data is / stays in device memory (mi_g1_normalize_batch_device, mi_msm_g1_set_bases_from_jacobian: d_out_user == nullptr leaves the
 // affine points in d.io_out).  Scratch lives in the lane's DevState: nothing is allocated in steady state (round 5: six hipMalloc + hipFree per call).
 template <class C>
@@ -794,11 +796,18 @@ void normalize_run(mi_ctx* ctx, DevState& d, const void* h_in, const void* d_in_
     if (!raw_in) { d.io_in.ensure(n * jac_bytes<C>()); raw_in = (const uint32_t*)d.io_in.p; }
     uint32_t* raw_out = (uint32_t*)d_out_user;
     if (!raw_out) { d.io_out.ensure(n * aff_bytes<C>()); raw_out = (uint32_t*)d.io_out.p; }
-    d.nv_vals.ensure(t.total * SLOTB);
+    // more than one level (n > 64): level 0 is fused with the conversions around it (k_norm_up0, k_norm_down0_final) and keeps only its prefix
+    // products — the value and inverse arrays start at level 1
+    const bool fused = top >= 1;
+    const size_t skip = fused ? t.sz[0] : 0;
+    d.nv_vals.ensure((t.total - skip) * SLOTB);
     d.nv_pref.ensure(t.total * SLOTB);
-    d.nv_inv.ensure(t.total * SLOTB);
+    d.nv_inv.ensure((t.total - skip) * SLOTB);
     d.nv_top.ensure(64 * sizeof(FE));
-    auto at = [&](DevBuf& b, size_t l, size_t idx) { return (uint32_t*)((char*)b.p + (t.off[l] + idx) * SLOTB); };
+    auto at = [&](DevBuf& b, size_t l, size_t idx) {
+        const size_t base = (&b == &d.nv_pref) ? t.off[l] : t.off[l] - skip;   // level 0 of vals / inv does not exist when fused (never asked for)
+        return (uint32_t*)((char*)b.p + (base + idx) * SLOTB);
+    };
     // range [lo, lo + cnt) of level 0 seen from level l
     auto level_range = [&](size_t l, size_t lo, size_t cnt, size_t& llo, size_t& lcnt) {
         size_t div = 1;
@@ -821,7 +830,7 @@ void normalize_run(mi_ctx* ctx, DevState& d, const void* h_in, const void* d_in_
                            (const uint32_t*)at(d.nv_pref, l, llo), (const uint32_t*)at(d.nv_inv, l + 1, llo / msmk::NORM_K), (uint32_t)lcnt,
                            at(d.nv_inv, l, llo));
     };
-    const size_t local = 0;                                 // tree levels handled per chunk: none (see above)
+    const size_t local = fused ? 1 : 0;                     // tree levels handled per chunk: level 0 when it is fused with the conversions
     const IoPlan p = io_plan(n, h_in != nullptr || h_out != nullptr, K2);
     const IoOut outs[1] = {{h_out, raw_out, aff_bytes<C>()}};
     IoDrain drain(d);
@@ -831,9 +840,12 @@ void normalize_run(mi_ctx* ctx, DevState& d, const void* h_in, const void* d_in_
         io_range(p, n, j, lo, cnt);
         io_feed(d, p, n, j, h_in, const_cast<uint32_t*>(raw_in), jac_bytes<C>());
         HIP_TRY(hipEventRecord(d.iev[0][j], s));
-        hipLaunchKernelGGL(msmk::k_norm_load<C>, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, s, raw_in + lo * msmk::Geo<C>::RAW_JAC, (uint32_t)cnt,
-                           at(d.nv_vals, 0, lo));
-        for (size_t l = 0; l < local; l++) up(l, lo, cnt);
+        if (fused)
+            hipLaunchKernelGGL(msmk::k_norm_up0<C>, dim3((uint32_t)(((cnt + msmk::NORM_K - 1) / msmk::NORM_K + 255) / 256)), dim3(256), 0, s,
+                               raw_in + lo * msmk::Geo<C>::RAW_JAC, (uint32_t)cnt, at(d.nv_pref, 0, lo), at(d.nv_vals, 1, lo / msmk::NORM_K));
+        else
+            hipLaunchKernelGGL(msmk::k_norm_load<C>, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, s, raw_in + lo * msmk::Geo<C>::RAW_JAC, (uint32_t)cnt,
+                               at(d.nv_vals, 0, lo));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(d.iev[1][j], s));
     }
@@ -861,9 +873,13 @@ void normalize_run(mi_ctx* ctx, DevState& d, const void* h_in, const void* d_in_
         size_t lo, cnt;
         io_range(p, n, j, lo, cnt);
         HIP_TRY(hipEventRecord(d.iev[2][j], s));
-        for (size_t l = local; l-- > 0;) down(l, lo, cnt);
-        hipLaunchKernelGGL(msmk::k_norm_final<C>, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, s, raw_in + lo * msmk::Geo<C>::RAW_JAC,
-                           (const uint32_t*)at(d.nv_inv, 0, lo), (uint32_t)cnt, raw_out + lo * msmk::Geo<C>::RAW_AFF);
+        if (fused)
+            hipLaunchKernelGGL(msmk::k_norm_down0_final<C>, dim3((uint32_t)(((cnt + msmk::NORM_K - 1) / msmk::NORM_K + 255) / 256)), dim3(256), 0, s,
+                               raw_in + lo * msmk::Geo<C>::RAW_JAC, (const uint32_t*)at(d.nv_pref, 0, lo), (const uint32_t*)at(d.nv_inv, 1, lo / msmk::NORM_K),
+                               (uint32_t)cnt, raw_out + lo * msmk::Geo<C>::RAW_AFF);
+        else
+            hipLaunchKernelGGL(msmk::k_norm_final<C>, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, s, raw_in + lo * msmk::Geo<C>::RAW_JAC,
+                               (const uint32_t*)at(d.nv_inv, 0, lo), (uint32_t)cnt, raw_out + lo * msmk::Geo<C>::RAW_AFF);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(d.iev[3][j], s));
     }

@@ -545,10 +545,12 @@ def _normalize_leg(pkg, co, ncpu, device, g="g1", log_n=20) -> dict:
         d_in = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
         d_out = torch.empty(n * aff, dtype=torch.uint8, device="cuda")
         torch.cuda.synchronize()
-        dev_ms = 1e30
+        dev_ms, kms_chunked = 1e30, kms
         for _ in range(3):
             ctx.normalize_batch_device(g, d_in.data_ptr(), n, d_out.data_ptr())
-            dev_ms = min(dev_ms, ctx.profile()["total_ms"])
+            pr = ctx.profile()
+            if pr["total_ms"] < dev_ms:   # kernels_ms: the kernels at full size (the host-slice call launches level 0 once per PCIe chunk, under the copies)
+                dev_ms, kms = pr["total_ms"], pr["accumulate_ms"]
         dev_ok = d_out.cpu().numpy().tobytes() == out
         del d_in, d_out
     t1 = time.perf_counter()
@@ -561,7 +563,7 @@ def _normalize_leg(pkg, co, ncpu, device, g="g1", log_n=20) -> dict:
     gbs = (jb + aff) * n / (kms * 1e-3) / 1e9
     traffic, tsrc, tstale = _rows_f_traffic(g, log_n, ("k_norm_",))
     return {"metric": f"{G} points/s, normalize_batch (Jacobian -> affine, one inversion), host slices in and out", "value": n / (best * 1e-3), "unit": "points/s", "n": n,
-            "call_ms_host_buffers": best, "kernels_ms": kms, "call_ms_device_buffers": dev_ms, "python_binding_wall_ms": py_ms, "bit_exact": ok,
+            "call_ms_host_buffers": best, "kernels_ms": kms, "kernels_ms_chunked_host_call": kms_chunked, "call_ms_device_buffers": dev_ms, "python_binding_wall_ms": py_ms, "bit_exact": ok,
             "workload": f"2^{log_n} {G} Jacobian points with non-trivial Z; value = the C call with host buffers in and out (PCIe-inclusive, what the trait's "
                         "caller pays); kernels_ms and the device-buffer call beside it",
             "roofline": {"bound": "hbm", "kernel": "k_norm_load + k_norm_up/down x levels + k_norm_final", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
