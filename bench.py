@@ -859,19 +859,40 @@ def main() -> None:
             "comm": None, "repeats": 0,
             "path": ("mi_msm_%s_allgather_fold: window sums in device memory -> ncclAllGather -> one D2H of the gathered block -> mi_%s_fold_windows" % (g, g))
             if on_gpu else ("rehearsal: mi_msm_%s_device_windows -> host all_gather (gloo) -> mi_%s_fold_windows" % (g, g))}
-    win_dev = torch.empty(pkg.MAX_WINDOWS * jac_bytes, dtype=torch.uint8, device="cuda") if exchange and not on_gpu else None
+    win_dev = torch.empty(pkg.MAX_WINDOWS * jac_bytes, dtype=torch.uint8, device="cuda") if exchange else None
 
     def setup_exchange():
         if on_gpu:
-            uid = [pkg.rccl_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            xchg["comm"] = pkg.RcclComm(leg.ctx, uid[0], world, rank)   # collective: ncclCommInitRank
-            xchg["comm"].allgather_fold(g, leg.d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)   # untimed: ragged shards agree on a window size here
-            t = xchg["comm"].timing()
-            xchg["info"] = (t["window_bits"], t["num_windows"])
-            xchg["bytes_per_rank"] = t["bytes_per_rank"]
-            return
-        # gloo rehearsal: learn the window geometry, make every rank agree on it, size the gather buffer
+            # The in-library exchange first.  It has never met a second physical GPU: if ANY rank cannot set it up — its own
+            # communicator next to torch's, the first collective — every rank falls back to the same steps with torch.distributed's
+            # all-gather on device tensors (RCCL as well), and the line says so.  The decision is collective: a rank never waits in a
+            # collective the others have left (the library's deadline ends a wait on a rank that failed earlier).
+            err = None
+            try:
+                if os.environ.get("ARKBLST_AMD_BENCH_EXCHANGE") == "torch":
+                    raise RuntimeError("ARKBLST_AMD_BENCH_EXCHANGE=torch")
+                uid = [pkg.rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                xchg["comm"] = pkg.RcclComm(leg.ctx, uid[0], world, rank)   # collective: ncclCommInitRank
+                xchg["comm"].allgather_fold(g, leg.d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)   # untimed: ragged shards agree on a window size here
+                t = xchg["comm"].timing()
+                xchg["info"] = (t["window_bits"], t["num_windows"])
+                xchg["bytes_per_rank"] = t["bytes_per_rank"]
+            except Exception as e:   # noqa: BLE001 - whatever went wrong, the other ranks must learn of it
+                err = f"{type(e).__name__}: {e}"
+            flag = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                return
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            xchg["comm"] = None
+            xchg["backend"] = "rccl (torch.distributed all_gather on device tensors)"
+            xchg["fallback_reason"] = next((e for e in errs if e), "unknown")
+            xchg["path"] = "FALLBACK: mi_msm_%s_device_windows -> torch.distributed all_gather_into_tensor (device, RCCL) -> one D2H -> mi_%s_fold_windows" % (g, g)
+            if rank == 0:
+                print(f"[bench] in-library exchange unavailable ({xchg['fallback_reason']}); using torch.distributed's all-gather", file=sys.stderr, flush=True)
+        # torch collective (gloo rehearsal, or the fallback above): learn the window geometry, make every rank agree on it, size the gather buffer
         info = leg.ctx.msm_device_windows(g, leg.d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL, win_dev.data_ptr())
         infos = [None] * world
         dist.all_gather_object(infos, info)
@@ -882,12 +903,12 @@ def main() -> None:
             assert len(set(infos)) == 1, infos
         xchg["info"] = info
         xchg["bytes_per_rank"] = info[1] * jac_bytes
-        xchg["gather_host"] = torch.empty(world * info[1] * jac_bytes, dtype=torch.uint8)
+        xchg["gather_host"] = torch.empty(world * info[1] * jac_bytes, dtype=torch.uint8, device=cdev)
 
     def step() -> bytes:
         if not exchange:
             return leg.call()
-        if on_gpu:
+        if on_gpu and xchg["comm"] is not None:
             out = xchg["comm"].allgather_fold(g, leg.d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL)
             t = xchg["comm"].timing_raw()
             xchg["msm_s"] += t.msm_ms * 1e-3
@@ -899,8 +920,8 @@ def main() -> None:
         info = leg.ctx.msm_device_windows(g, leg.d_scalars.data_ptr(), n, pkg.SCALAR_CANONICAL, win_dev.data_ptr())
         t_b = time.perf_counter()
         nb = info[1] * jac_bytes
-        dist.all_gather_into_tensor(xchg["gather_host"], win_dev[:nb].cpu())
-        out = pkg.fold_windows(g, xchg["gather_host"].numpy(), world, info[1], *info)
+        dist.all_gather_into_tensor(xchg["gather_host"], win_dev[:nb] if on_gpu else win_dev[:nb].cpu())
+        out = pkg.fold_windows(g, xchg["gather_host"].cpu().numpy(), world, info[1], *info)
         t_c = time.perf_counter()
         xchg["msm_s"] += t_b - t_a
         xchg["exchange_s"] += t_c - t_b
@@ -1099,6 +1120,8 @@ def main() -> None:
                                "windows": xchg["info"][1], "window_bits": xchg["info"][0], "path": xchg["path"],
                                "rank_msm_ms": [round(x, 4) for x in rm], "exchange_incl_wait_ms": xchg["exchange_s"] / ks * 1e3,
                                "window_size_repeats_in_timed_steps": xchg["repeats"]}
+            if xchg.get("fallback_reason"):
+                out["exchange"]["fallback_reason"] = xchg["fallback_reason"][:300]
             detail["exchange"] = {"expected_ms_source": exp_src}
         if cpu_baseline:
             out["cpu_baseline"] = cpu_baseline

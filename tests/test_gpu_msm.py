@@ -1081,6 +1081,15 @@ def test_bench_exchange_runs_under_one_rank_rccl(group):
     assert d["n_gpus"] == 1 and d["bit_exact"] is True and d["metric"].startswith(group.upper())
     assert d["exchange"]["backend"].startswith("rccl") and d["exchange"]["world_size"] == 1 and d["exchange"]["windows"] == d["config"]["num_windows"]
     assert d["exchange_ms"] > 0 and d["msm_ms"] > 0 and d["exchange"]["window_size_repeats_in_timed_steps"] == 0
+    assert "fallback_reason" not in d["exchange"] and d["exchange"]["backend"] == "rccl (in-library)"
+    if group == "g1":
+        # round 6: the in-library exchange has never met a second physical GPU; when any rank cannot set it up, ALL ranks switch (a collective
+        # decision) to torch.distributed's all-gather on the device window sums and the line says why.  Forced here through the environment.
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(env, ARKBLST_AMD_BENCH_EXCHANGE="torch"))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["bit_exact"] is True and d["exchange"]["backend"].startswith("rccl (torch.distributed")
+        assert "ARKBLST_AMD_BENCH_EXCHANGE" in d["exchange"]["fallback_reason"] and d["exchange"]["path"].startswith("FALLBACK")
 
 
 @pytest.mark.parametrize("group", ["g1", "g2"])
