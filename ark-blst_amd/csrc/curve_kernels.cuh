@@ -818,11 +818,12 @@ __global__ void __launch_bounds__(256, 2) k_norm_up(const uint32_t* __restrict__
     uint32_t g = blockIdx.x * 256 + threadIdx.x;
     uint32_t lo = g * NORM_K, hi = lo + NORM_K < m ? lo + NORM_K : m;
     if (lo >= m) return;
-    E run = F::one();
+    E run = F::one(), nv;
+    ElemIO<E>::load(nv, vals + (size_t)lo * Geo<C>::SLOT);   // the next value is in flight while the current product runs (a lane walks its group alone)
     for (uint32_t k = lo; k < hi; k++) {
+        const E v = nv;
+        if (k + 1 < hi) ElemIO<E>::load(nv, vals + (size_t)(k + 1) * Geo<C>::SLOT);
         ElemIO<E>::store(pref + (size_t)k * Geo<C>::SLOT, run);
-        E v;
-        ElemIO<E>::load(v, vals + (size_t)k * Geo<C>::SLOT);
         run = F::mul(run, v);
     }
     ElemIO<E>::store(tot + (size_t)g * Geo<C>::SLOT, run);
@@ -836,12 +837,16 @@ __global__ void __launch_bounds__(256, 2) k_norm_down(const uint32_t* __restrict
     uint32_t g = blockIdx.x * 256 + threadIdx.x;
     uint32_t lo = g * NORM_K, hi = lo + NORM_K < m ? lo + NORM_K : m;
     if (lo >= m) return;
-    E I;
+    E I, np_, nv;
     ElemIO<E>::load(I, inv_tot + (size_t)g * Geo<C>::SLOT);
+    ElemIO<E>::load(np_, pref + (size_t)(hi - 1) * Geo<C>::SLOT);   // as in k_norm_up: the next step's operands are in flight during this one's products
+    ElemIO<E>::load(nv, vals + (size_t)(hi - 1) * Geo<C>::SLOT);
     for (uint32_t k = hi; k-- > lo;) {
-        E p, v;
-        ElemIO<E>::load(p, pref + (size_t)k * Geo<C>::SLOT);
-        ElemIO<E>::load(v, vals + (size_t)k * Geo<C>::SLOT);
+        const E p = np_, v = nv;
+        if (k > lo) {
+            ElemIO<E>::load(np_, pref + (size_t)(k - 1) * Geo<C>::SLOT);
+            ElemIO<E>::load(nv, vals + (size_t)(k - 1) * Geo<C>::SLOT);
+        }
         ElemIO<E>::store(inv_vals + (size_t)k * Geo<C>::SLOT, F::mul(I, p));
         I = F::mul(I, v);
     }
@@ -886,15 +891,29 @@ __global__ void __launch_bounds__(256, 2) k_norm_up0(const uint32_t* __restrict_
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     const uint32_t lo = g * NORM_K, hi = lo + NORM_K < n ? lo + NORM_K : n;
     if (lo >= n) return;
+    // the next point's Z words are fetched while the current product runs (one lane walks its group: without the prefetch every step
+    // waits for its own gather — 104 -> ~60 us at 2^20 points)
+    uint32_t zw[R], nw[R];
+    {
+        const uint32_t* zr = raw_jac + (size_t)lo * Geo<C>::RAW_JAC + 2 * R;
+#pragma unroll
+        for (int w = 0; w < R; w++) nw[w] = zr[w];
+    }
     E run = F::one();
     for (uint32_t k = lo; k < hi; k++) {
+#pragma unroll
+        for (int w = 0; w < R; w++) zw[w] = nw[w];
+        if (k + 1 < hi) {
+            const uint32_t* zr = raw_jac + (size_t)(k + 1) * Geo<C>::RAW_JAC + 2 * R;
+#pragma unroll
+            for (int w = 0; w < R; w++) nw[w] = zr[w];
+        }
         ElemIO<E>::store(pref + (size_t)k * Geo<C>::SLOT, run);
-        const uint32_t* zr = raw_jac + (size_t)k * Geo<C>::RAW_JAC + 2 * R;
         uint32_t any = 0;
-#pragma unroll 4
-        for (int w = 0; w < R; w++) any |= zr[w];
+#pragma unroll
+        for (int w = 0; w < R; w++) any |= zw[w];
         E z;
-        ElemIO<E>::from_raw(z, zr);
+        ElemIO<E>::from_raw(z, zw);
         run = F::mul(run, F::select(any == 0, z, F::one()));
     }
     ElemIO<E>::store(tot + (size_t)g * Geo<C>::SLOT, run);
@@ -911,19 +930,42 @@ __global__ void __launch_bounds__(256, 2) k_norm_down0_final(const uint32_t* __r
     if (lo >= n) return;
     E I;
     ElemIO<E>::load(I, inv_tot + (size_t)g * Geo<C>::SLOT);
+    // as in k_norm_up0: the next point (3 R words) and its prefix product are in flight while the current point's seven products run.  For Fp
+    // only: over Fp2 the two staged points are 144 registers and the loop spills 152 (the compiler hoists the plain loads as far as it can anyway).
+    constexpr bool PF = R == 12;
+    uint32_t cw[PF ? 3 * R : 1], nw[PF ? 3 * R : 1];
+    E p, np_;
+    if constexpr (PF) {
+        const uint32_t* q = raw_jac + (size_t)(hi - 1) * Geo<C>::RAW_JAC;
+#pragma unroll
+        for (int w = 0; w < 3 * R; w++) nw[w] = q[w];
+        ElemIO<E>::load(np_, pref + (size_t)(hi - 1) * Geo<C>::SLOT);
+    }
     for (uint32_t k = hi; k-- > lo;) {
-        const uint32_t* q = raw_jac + (size_t)k * Geo<C>::RAW_JAC;
+        if constexpr (PF) {
+#pragma unroll
+            for (int w = 0; w < 3 * R; w++) cw[w] = nw[w];
+            p = np_;
+            if (k > lo) {
+                const uint32_t* q = raw_jac + (size_t)(k - 1) * Geo<C>::RAW_JAC;
+#pragma unroll
+                for (int w = 0; w < 3 * R; w++) nw[w] = q[w];
+                ElemIO<E>::load(np_, pref + (size_t)(k - 1) * Geo<C>::SLOT);
+            }
+        } else {
+            ElemIO<E>::load(p, pref + (size_t)k * Geo<C>::SLOT);
+        }
+        const uint32_t* src = PF ? cw : raw_jac + (size_t)k * Geo<C>::RAW_JAC;
         uint32_t any = 0;
-#pragma unroll 4
-        for (int w = 0; w < R; w++) any |= q[2 * R + w];
-        E x, y, z, p;
-        ElemIO<E>::from_raw(z, q + 2 * R);
+#pragma unroll
+        for (int w = 0; w < R; w++) any |= src[2 * R + w];
+        E x, y, z;
+        ElemIO<E>::from_raw(z, src + 2 * R);
         z = F::select(any == 0, z, F::one());
-        ElemIO<E>::load(p, pref + (size_t)k * Geo<C>::SLOT);
         const E zi = F::mul(I, p);
         I = F::mul(I, z);
-        ElemIO<E>::unpack_raw(x, q);            // X, Y stay in the caller's Montgomery form: times an internal-form factor they come out in it
-        ElemIO<E>::unpack_raw(y, q + R);
+        ElemIO<E>::unpack_raw(x, src);          // X, Y stay in the caller's Montgomery form: times an internal-form factor they come out in it
+        ElemIO<E>::unpack_raw(y, src + R);
         const E zi2 = F::mul(zi, zi);
         const E zi3 = F::mul(zi2, zi);
         uint32_t* o = raw_aff + (size_t)k * Geo<C>::RAW_AFF;
