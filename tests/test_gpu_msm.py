@@ -45,6 +45,39 @@ def test_g1_msm_small_vs_oracle(ctx, co, pkg, n):
         assert _canon(co, "g1", got) == co.dlog_expected("g1", scalars, SEED_B, n)
 
 
+@pytest.mark.parametrize("n", [3, 4096, 150000])
+def test_g1_msm_lands_on_a_published_point(ctx, co, o, pkg, n):
+    """An anchor from outside this repository and outside the reference (which holds no MSM vector): an MSM whose scalars are chosen so that
+    sum(s_i k_i) = 2 modulo r over the suite's bases [k_i]G must give [2]G, whose compressed encoding a572cbea...0f4e is the published BLS12-381
+    public key of the secret key 2 (the generator's, 97f1d3a7...c6bb, that of the secret key 1).  All scalars but the last are random: every
+    window, sign fold and bucket of the HIP path takes part, and the result is compared with a constant, not with another implementation."""
+    import ctypes as C
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle import PUBLIC_PK_SK1, PUBLIC_PK_SK2
+
+    bases = co.gen_bases("g1", SEED_B, n, 4)                   # [k_i]G with the generator's k_i (oracle/msm_oracle.c orc_g1_gen_bases)
+    sc = bytearray(co.gen_scalars(SEED_S, n))
+    sc[32 * (n - 1):] = bytes(32)                              # last scalar 0: acc = sum over the others
+
+    def dot(v):
+        out = C.create_string_buffer(32)
+        co.lib().orc_dot_mod_r(bytes(v), SEED_B, n, out)
+        return int.from_bytes(out.raw, "little")
+
+    acc = dot(sc)
+    unit = bytearray(32 * n)
+    unit[32 * (n - 1)] = 1
+    k_last = dot(unit)
+    sc[32 * (n - 1):] = ((2 - acc) * pow(k_last, -1, o.R_ORDER) % o.R_ORDER).to_bytes(32, "little")
+    assert dot(sc) == 2
+    got = _canon(co, "g1", ctx.msm("g1", bases, bytes(sc), n, pkg.SCALAR_CANONICAL))
+    assert o.g1_compress(o.affine_from_bytes(o.F1, got)).hex() == PUBLIC_PK_SK2
+    assert o.g1_compress(o.G1_GEN).hex() == PUBLIC_PK_SK1
+
+
 def test_g1_msm_montgomery_scalars(ctx, co, pkg):
     n = 777
     bases = co.gen_bases("g1", SEED_B, n, 4)

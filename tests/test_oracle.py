@@ -94,6 +94,32 @@ def test_g1_encoding_oracle_vs_fixtures(o, golden):
     assert (beta * o.G1_X % o.P, o.G1_Y) == o.aff_neg(o.F1, q)
 
 
+PUBLIC_PK_SK1 = "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"
+PUBLIC_PK_SK2 = "a572cbea904d67468808c8eb50a9450c9721db309128012543902d0ac358a62ae28f75bb8f1c7c42c39a8c5529bf0f4e"
+
+
+def test_public_known_answers_for_the_group_law(o, co):
+    """An anchor from OUTSIDE this repository and outside /root/reference (which holds no MSM vector): the BLS12-381 public keys of the
+    secret keys 1 and 2 in the ZCash / IETF compressed encoding — the generator and [2]G, constants that circulate in the BLS signature test
+    vectors of every implementation (pk = [sk]G on G1).  They pin doubling, the encoding and — through sums that must land on [2]G — the MSM
+    oracle to a published value, not only to itself."""
+    assert o.g1_compress(o.G1_GEN).hex() == PUBLIC_PK_SK1
+    two_g = o.aff_add(o.F1, o.G1_GEN, o.G1_GEN)
+    assert o.g1_compress(two_g).hex() == PUBLIC_PK_SK2
+    assert o.g1_compress(o.scalar_mul(o.F1, o.G1_GEN, 2)).hex() == PUBLIC_PK_SK2
+    # the C oracle's Pippenger: 300 copies of G with scalars that sum to 2 modulo r
+    import random
+
+    rnd = random.Random(2)
+    n = 300
+    ks = [rnd.randrange(o.R_ORDER) for _ in range(n - 1)]
+    ks.append((2 - sum(ks)) % o.R_ORDER)
+    bases = o.affine_to_bytes(o.F1, o.G1_GEN) * n
+    sc = b"".join(k.to_bytes(32, "little") for k in ks)
+    got = co.to_affine("g1", co.msm("g1", bases, sc, n, 0, 4))
+    assert o.g1_compress(o.affine_from_bytes(o.F1, got)).hex() == PUBLIC_PK_SK2
+
+
 def test_g2_encoding_oracle_vs_fixtures(o, golden):
     assert o.g2_compress(o.G2_GEN).hex().startswith("93e02b6052719f607dacd3a088274f65596bd0d09920b61a")
     for case in golden["g2_encoding"]:
